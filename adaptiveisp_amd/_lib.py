@@ -1,0 +1,139 @@
+"""ctypes binding of csrc/libadaisp.so — the C-ABI declared in include/adaisp.h.
+
+PyTorch is plumbing here: it owns device memory and the HIP stream; every image operation below is a
+kernel from the shared library. Nothing in this module falls back to eager PyTorch or to the CPU.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libadaisp.so")
+
+OP_ZERO, OP_EXPOSURE, OP_GAMMA, OP_CCM, OP_SHARPEN, OP_NLM, OP_TONE = -1, 0, 1, 2, 3, 4, 5
+OP_CONTRAST, OP_SATPLUS, OP_WNB, OP_WB, OP_USM, OP_SHARPEN_V2, OP_COLOR = 6, 7, 8, 9, 10, 11, 12
+MAX_PARAMS = 24
+CLIP01 = 1
+ABI_VERSION = 2
+
+EXPORTS = ("adaisp_forward", "adaisp_process", "adaisp_backward_params", "adaisp_pool64", "adaisp_num_params",
+           "adaisp_strerror", "adaisp_abi_version")
+
+_lib = None
+
+
+class AdaispError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libadaisp.so (once). Raises — never degrades — if the library is absent or stale."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise AdaispError(f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(hipcc --offload-arch=gfx950). There is no CPU/eager fallback for the ISP path.")
+    L = ctypes.CDLL(LIB_PATH)
+    vp, ci, cu = ctypes.c_void_p, ctypes.c_int, ctypes.c_uint
+    L.adaisp_forward.argtypes = [vp, vp, vp, vp, vp, ci, ci, ci, ci, cu, vp]
+    L.adaisp_process.argtypes = [ci, vp, vp, vp, ci, ci, ci, ci, cu, vp]
+    L.adaisp_backward_params.argtypes = [vp, vp, vp, vp, ci, vp, ci, ci, ci, cu, vp]
+    L.adaisp_pool64.argtypes = [vp, vp, ci, ci, ci, vp]
+    L.adaisp_num_params.argtypes = [ci]
+    L.adaisp_strerror.argtypes = [ci]
+    L.adaisp_strerror.restype = ctypes.c_char_p
+    for name in ("adaisp_forward", "adaisp_process", "adaisp_backward_params", "adaisp_pool64", "adaisp_num_params",
+                 "adaisp_abi_version"):
+        getattr(L, name).restype = ci
+    if L.adaisp_abi_version() != ABI_VERSION:
+        raise AdaispError(f"libadaisp.so ABI {L.adaisp_abi_version()} != expected {ABI_VERSION}: rebuild")
+    _lib = L
+    return L
+
+
+def _check(rc, what):
+    if rc != 0:
+        raise AdaispError(f"{what} failed: {load().adaisp_strerror(rc).decode()} ({rc})")
+
+
+def _dev_f32(t, name):
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name} must be a torch.Tensor")
+    if not t.is_cuda:
+        raise AdaispError(f"{name} is on {t.device}: the ISP kernels run on the HIP device only (no CPU fallback)")
+    if t.dtype != torch.float32:
+        raise TypeError(f"{name} must be float32, got {t.dtype}")
+    return t.contiguous()
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _img_shape(img):
+    if img.dim() != 4 or img.shape[1] != 3:
+        raise ValueError(f"expected a [B,3,H,W] image, got {tuple(img.shape)}")
+    return int(img.shape[0]), int(img.shape[2]), int(img.shape[3])
+
+
+def process(op, img, params, clip=False, out=None):
+    """adaisp_process: one host-known op for the whole batch. params [B,n] (regressed)."""
+    L = load()
+    img = _dev_f32(img, "img")
+    B, H, W = _img_shape(img)
+    params = _dev_f32(params.reshape(B, -1), "params")
+    if out is None:
+        out = torch.empty_like(img)
+    with torch.cuda.device(img.device):
+        rc = L.adaisp_process(int(op), img.data_ptr(), out.data_ptr(), params.data_ptr(), params.shape[1], B, H, W,
+                              CLIP01 if clip else 0, _stream())
+    _check(rc, "adaisp_process")
+    return out
+
+
+def forward(img, op_ids, params, clip=True, pooled=None, out=None):
+    """adaisp_forward: image b is filtered by op_ids[b] (int32, device). params [B,stride]."""
+    L = load()
+    img = _dev_f32(img, "img")
+    B, H, W = _img_shape(img)
+    params = _dev_f32(params.reshape(B, -1), "params")
+    if op_ids.dtype != torch.int32 or not op_ids.is_cuda:
+        raise TypeError("op_ids must be an int32 device tensor")
+    op_ids = op_ids.contiguous()
+    if out is None:
+        out = torch.empty_like(img)
+    with torch.cuda.device(img.device):
+        rc = L.adaisp_forward(img.data_ptr(), out.data_ptr(), pooled.data_ptr() if pooled is not None else None,
+                              op_ids.data_ptr(), params.data_ptr(), params.shape[1], B, H, W,
+                              CLIP01 if clip else 0, _stream())
+    _check(rc, "adaisp_forward")
+    return out
+
+
+def backward_params(img, grad_out, op_ids, params, clip=True):
+    L = load()
+    img = _dev_f32(img, "img")
+    grad_out = _dev_f32(grad_out, "grad_out")
+    B, H, W = _img_shape(img)
+    params = _dev_f32(params.reshape(B, -1), "params")
+    grad = torch.empty_like(params)
+    with torch.cuda.device(img.device):
+        rc = L.adaisp_backward_params(img.data_ptr(), grad_out.data_ptr(), op_ids.contiguous().data_ptr(),
+                                      params.data_ptr(), params.shape[1], grad.data_ptr(), B, H, W,
+                                      CLIP01 if clip else 0, _stream())
+    _check(rc, "adaisp_backward_params")
+    return grad
+
+
+def pool64(img):
+    """AdaptiveAvgPool2d((64,64)) of a [B,3,H,W] device image."""
+    L = load()
+    img = _dev_f32(img, "img")
+    B, H, W = _img_shape(img)
+    out = torch.empty((B, 3, 64, 64), dtype=torch.float32, device=img.device)
+    with torch.cuda.device(img.device):
+        rc = L.adaisp_pool64(img.data_ptr(), out.data_ptr(), B, H, W, _stream())
+    _check(rc, "adaisp_pool64")
+    return out

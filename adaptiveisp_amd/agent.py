@@ -1,0 +1,176 @@
+"""Policy network — host-side mirror of the reference's agent.py (Agent, FeatureExtractor,
+pdf_sample, one_hot), re-organised around the HIP ISP kernels.
+
+The reference runs ALL filters on the full-resolution batch every step, stacks the ten results and
+keeps one per image with a one-hot multiply-sum (agent.py:103-116,154). Here the heads still regress
+every filter's parameters (tiny [B,n] tensors), but only the SELECTED filter touches pixels: the
+per-image op ids stay on the device and one `adaisp_forward` call filters the batch. Everything the
+caller can observe is unchanged: argument/return tuples, debug_info keys, state-dict keys, the
+state update, the penalty terms and the selection arithmetic (int64, bit-exact).
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from .isp.isp_function import isp_apply_selected
+from .nets import FeatureExtractor as _Trunk
+from .nets import Pool64
+from . import _lib
+from .util import STATE_DROPOUT_BEGIN, STATE_REWARD_DIM, STATE_STEP_DIM, STATE_STOPPED_DIM, enrich_image_input
+
+
+def pdf_sample(pdf, uniform_noise):
+    """Inverse-CDF sampling: index = #{k : cdf_exclusive[k] < u} - 1 (reference agent.py:12-16).
+    u == 0 yields -1, i.e. an all-zero one-hot row."""
+    pdf = pdf / (torch.sum(pdf, dim=1, keepdim=True) + 1e-36)
+    below = torch.less(torch.cumsum(pdf, dim=1) - pdf, uniform_noise)
+    return torch.sum(below.to(torch.int32), dim=1) - 1
+
+
+def one_hot(num_class, index):
+    """int64 [B,num_class]; rows for indices outside 0..num_class-1 are all zero (reference agent.py:18-23)."""
+    classes = torch.arange(num_class, device=index.device, dtype=index.dtype)
+    return (index[:, None] == classes[None, :]).to(torch.int64)
+
+
+class FeatureExtractor(_Trunk):
+    def __init__(self, shape=(14, 64, 64), mid_channels=32, output_dim=4096, dropout_prob=0.5):
+        super().__init__(shape=shape, mid_channels=mid_channels, output_dim=output_dim, dropout_prob=dropout_prob)
+
+
+class Agent(nn.Module):
+    def __init__(self, cfg, shape=(16, 64, 64), device='cuda'):
+        super().__init__()
+        self.cfg = cfg
+        self.feature_extractor = FeatureExtractor(shape=shape, mid_channels=cfg.base_channels,
+                                                  output_dim=cfg.feature_extractor_dims,
+                                                  dropout_prob=1.0 - cfg.dropout_keep_prob)
+        self.filters = []
+        for make in self.cfg.filters:
+            flt = make(self.cfg, predict=True).to(device)
+            setattr(self, flt.get_short_name(), flt)     # state-dict prefix = short name ("E.", "S+.", ...)
+            self.filters.append(flt)
+        self.action_selection = FeatureExtractor(shape=shape, mid_channels=cfg.base_channels,
+                                                 output_dim=cfg.feature_extractor_dims,
+                                                 dropout_prob=1.0 - cfg.dropout_keep_prob)
+        self.fc1 = nn.Linear(cfg.feature_extractor_dims, cfg.fc1_size)
+        self.lrelu = nn.LeakyReLU(negative_slope=0.2)
+        self.fc2 = nn.Linear(cfg.fc1_size, len(self.filters))
+        self.softmax = nn.Softmax(dim=1)
+        self.down_sample = Pool64((shape[1], shape[2]))
+        self.runtime = torch.tensor(cfg.filters_runtime, requires_grad=False).to(device)
+        # action id -> kernel op code; entry 0 serves the all-zero one-hot (id -1)
+        self._op_table_host = [_lib.OP_ZERO] + [int(f.op_code) for f in self.filters]
+        self._op_table = None
+        self._param_width = max(f.get_num_filter_parameters() for f in self.filters)
+
+    # ------------------------------------------------------------------------------------------
+    def _op_ids(self, selected):
+        if self._op_table is None or self._op_table.device != selected.device:
+            self._op_table = torch.tensor(self._op_table_host, dtype=torch.int32, device=selected.device)
+        return self._op_table[(selected + 1).clamp(0, len(self.filters))]
+
+    def _packed_params(self, params, selected):
+        """[B,width] row b = flattened parameters of filter selected[b] (zeros for id -1). Differentiable."""
+        B = selected.shape[0]
+        table = torch.stack([torch.nn.functional.pad(p.reshape(B, -1), (0, self._param_width - p[0].numel()))
+                             for p in params], dim=1)                       # [B,F,width]
+        idx = selected.clamp(0, len(params) - 1).view(B, 1, 1).expand(B, 1, self._param_width)
+        return table.gather(1, idx).squeeze(1)
+
+    def _apply_isp(self, img, packed, op_ids):
+        """The one place pixels are touched: selected filter + clip to [0,1] (Filter.forward semantics)."""
+        return isp_apply_selected(img, packed, op_ids, clip=True)
+
+    # ------------------------------------------------------------------------------------------
+    def forward(self, inp, progress, high_res=None, selected_filter_id=None):
+        train = 1 if self.training else 0
+        x, z, states = inp
+        num_filters = len(self.filters)
+        selection_noise = z[:, 0:1]
+
+        x_down = self.down_sample(x)
+        if not self.cfg.shared_feature_extractor:
+            raise ValueError("current just support shared_feature_extractor")
+        net_in = enrich_image_input(self.cfg, x_down, states)
+        filter_features = self.feature_extractor(net_in)
+
+        # every filter's heads (cheap), no pixels yet
+        params, filter_debug_info = [], []
+        for flt in self.filters:
+            feats, mask_parameters = flt.extract_parameters(filter_features)
+            p = flt.filter_param_regressor(feats)
+            flt.mask_parameters = mask_parameters
+            flt.mask = flt.get_mask(x, mask_parameters)
+            params.append(p)
+            filter_debug_info.append({'filter_parameters': p[0], 'mask': flt.mask[0]})
+
+        # action selection
+        selector = self.lrelu(self.fc1(self.action_selection(net_in)))
+        pdf = self.softmax(self.fc2(selector)) + 1e-37
+        pdf = pdf * (1 - self.cfg.exploration) + self.cfg.exploration * 1.0 / num_filters
+        pdf = pdf / (torch.sum(pdf, dim=1, keepdim=True) + 1e-30)
+        entropy = torch.sum(-pdf * torch.log(pdf), dim=1)[:, None]
+        random_filter_id = pdf_sample(pdf, selection_noise)
+        max_filter_id = torch.argmax(pdf, dim=1).to(torch.int32)
+        if selected_filter_id is not None:
+            selected_filter_id = torch.full((max_filter_id.shape[0],), int(selected_filter_id), dtype=torch.int64,
+                                            device=max_filter_id.device)
+        else:
+            selected_filter_id = (train * random_filter_id + (1 - train) * max_filter_id).to(torch.int64)
+        filter_one_hot = one_hot(num_filters, selected_filter_id)
+        surrogate = torch.sum(filter_one_hot * torch.log(pdf + 1e-10), dim=1, keepdim=True)
+
+        # pixels: only the selected filter runs
+        op_ids = self._op_ids(selected_filter_id)
+        packed = self._packed_params(params, selected_filter_id)
+        x = self._apply_isp(x, packed, op_ids)
+        if high_res is not None:
+            high_res_output = self._apply_isp(high_res, packed, op_ids)
+
+        debug_info = {
+            'state': states,
+            'selected_filter_id': selected_filter_id[0],
+            'filter_debug_info': filter_debug_info,
+            'pdf': pdf[0],
+            'selected_filter': selected_filter_id,
+        }
+
+        def debugger(debug_info, combined=True):
+            raise NotImplementedError("the drawing debugger needs cv2 and is outside the ISP hot path")
+
+        debugger.width = int(x.shape[2])
+
+        # state update (reference agent.py:234-259)
+        step = states[:, STATE_STEP_DIM:STATE_STEP_DIM + 1]
+        is_last_step = (torch.abs(step + 1 - self.cfg.test_steps) < 1e-4).to(torch.float32)
+        submitted = is_last_step
+        filter_usage = states[:, STATE_STEP_DIM + 1:]
+        assert filter_usage.dim() == filter_one_hot.dim()
+        early_stop_penalty = (1 - is_last_step) * submitted * self.cfg.early_stop_penalty
+        usage_penalty = torch.sum(filter_usage * filter_one_hot, dim=1, keepdim=True)
+        new_states = [None] * (STATE_DROPOUT_BEGIN + 1)
+        new_states[STATE_REWARD_DIM] = submitted
+        new_states[STATE_STOPPED_DIM] = submitted
+        new_states[STATE_STEP_DIM] = step + 1
+        new_states[STATE_STEP_DIM + 1] = torch.maximum(filter_usage, filter_one_hot)
+        new_states = torch.cat(new_states, dim=1)
+
+        if self.cfg.clamp:
+            x = torch.clip(x, min=0.0, max=5.0)
+
+        entropy_penalty = (1.0 - progress) * self.cfg.exploration_penalty * (-entropy + math.log(num_filters))
+        runtime_penalty = 0.0
+        if self.cfg.filter_runtime_penalty:
+            runtime_penalty = torch.sum(filter_one_hot * self.runtime.to(x.device), dim=1, keepdim=True)
+            runtime_penalty = self.cfg.filter_runtime_penalty_lambda * runtime_penalty
+        # mean(clip(x - 1, min=0)^2) of the reference (agent.py:279) is identically 0: the kernel has already
+        # clipped x to [0,1], so the full-resolution pass that term would cost is skipped.
+        over_range = torch.zeros_like(entropy)
+        penalty = over_range + entropy_penalty + usage_penalty * self.cfg.filter_usage_penalty + \
+            early_stop_penalty + runtime_penalty
+
+        if high_res is None:
+            return (x, new_states, surrogate, penalty), debug_info, debugger
+        return (x, new_states, high_res_output), debug_info, debugger

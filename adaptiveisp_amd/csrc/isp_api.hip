@@ -1,0 +1,113 @@
+// C-ABI of libadaisp.so (see include/adaisp.h). Argument checking + kernel-family dispatch only:
+// never allocates, never synchronises, enqueues on the caller's stream, keeps no global state.
+#include "isp_internal.h"
+
+using namespace adaisp;
+
+namespace {
+
+int check_common(const float* img, const float* out, const float* params, int pstride, int B, int H, int W) {
+    if (!img || !out || !params) return ADAISP_EINVAL;
+    if (B <= 0 || H <= 0 || W <= 0 || pstride <= 0) return ADAISP_EINVAL;
+    if (B > 65535) return ADAISP_ESHAPE;
+    return ADAISP_OK;
+}
+
+bool ranges_overlap(const float* a, const float* b, long n) {
+    return (a < b + n) && (b < a + n);
+}
+
+}  // namespace
+
+extern "C" {
+
+int adaisp_abi_version(void) { return ADAISP_ABI_VERSION; }
+
+const char* adaisp_strerror(int code) {
+    switch (code) {
+        case ADAISP_OK: return "ok";
+        case ADAISP_EINVAL: return "invalid argument (null pointer, non-positive size or stride)";
+        case ADAISP_EOP: return "unknown op code";
+        case ADAISP_EALIAS: return "out aliases img for a stencil op";
+        case ADAISP_ESHAPE: return "shape not supported by this op";
+        case ADAISP_ELAUNCH: return "kernel launch failed";
+        default: return "unknown error";
+    }
+}
+
+int adaisp_num_params(int op) {
+    switch (op) {
+        case ADAISP_OP_ZERO: return 0;
+        case ADAISP_OP_EXPOSURE: case ADAISP_OP_GAMMA: case ADAISP_OP_SHARPEN: case ADAISP_OP_NLM:
+        case ADAISP_OP_CONTRAST: case ADAISP_OP_SATPLUS: case ADAISP_OP_WNB: case ADAISP_OP_SHARPEN_V2:
+            return 1;
+        case ADAISP_OP_USM: return 2;
+        case ADAISP_OP_WB: return 3;
+        case ADAISP_OP_TONE: return 8;
+        case ADAISP_OP_CCM: return 9;
+        case ADAISP_OP_COLOR: return 24;
+        default: return -1;
+    }
+}
+
+int adaisp_pool64(const float* img, float* pooled, int B, int H, int W, void* stream) {
+    if (!img || !pooled || B <= 0 || H <= 0 || W <= 0) return ADAISP_EINVAL;
+    if (B > 65535 || W > 16384) return ADAISP_ESHAPE;
+    return launch_pool64(img, pooled, B, H, W, static_cast<hipStream_t>(stream)) == hipSuccess ? ADAISP_OK
+                                                                                                : ADAISP_ELAUNCH;
+}
+
+int adaisp_process(int op, const float* img, float* out, const float* params, int param_stride, int B, int H, int W,
+                   unsigned flags, void* stream) {
+    int rc = check_common(img, out, params, param_stride, B, H, W);
+    if (rc) return rc;
+    const int np = adaisp_num_params(op);
+    if (np < 0) return ADAISP_EOP;
+    if (np > param_stride) return ADAISP_EINVAL;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    Batch a{img, out, nullptr, op, params, param_stride, B, H, W, flags};
+    hipError_t e;
+    if (op_is_pointwise(op)) {
+        e = launch_pointwise(a, s);
+    } else {
+        if (ranges_overlap(img, out, (long)B * 3 * H * W)) return ADAISP_EALIAS;
+        if (op == ADAISP_OP_NLM) {
+            e = launch_nlm(a, s);
+        } else {
+            if (H < 3 || W < 3) return ADAISP_ESHAPE;   // valid 3x3 conv / reflect pad 2 need >= 3
+            e = launch_conv(a, s);
+        }
+    }
+    return e == hipSuccess ? ADAISP_OK : ADAISP_ELAUNCH;
+}
+
+int adaisp_forward(const float* img, float* out, float* pooled64_next, const int32_t* filter_id, const float* params,
+                   int param_stride, int B, int H, int W, unsigned flags, void* stream) {
+    int rc = check_common(img, out, params, param_stride, B, H, W);
+    if (rc) return rc;
+    if (!filter_id) return ADAISP_EINVAL;
+    if (ranges_overlap(img, out, (long)B * 3 * H * W)) return ADAISP_EALIAS;
+    if (pooled64_next && W > 16384) return ADAISP_ESHAPE;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    Batch a{img, out, filter_id, 0, params, param_stride, B, H, W, flags};
+    // The ids live on the device, so each kernel family is enqueued for the whole batch and its
+    // workgroups return at once for images whose op belongs to another family.
+    if (launch_pointwise(a, s) != hipSuccess) return ADAISP_ELAUNCH;
+    if (H >= 3 && W >= 3 && launch_conv(a, s) != hipSuccess) return ADAISP_ELAUNCH;
+    if (launch_nlm(a, s) != hipSuccess) return ADAISP_ELAUNCH;
+    if (pooled64_next && launch_pool64(out, pooled64_next, B, H, W, s) != hipSuccess) return ADAISP_ELAUNCH;
+    return ADAISP_OK;
+}
+
+int adaisp_backward_params(const float* img, const float* grad_out, const int32_t* filter_id, const float* params,
+                           int param_stride, float* grad_params, int B, int H, int W, unsigned flags, void* stream) {
+    if (!img || !grad_out || !filter_id || !params || !grad_params) return ADAISP_EINVAL;
+    if (B <= 0 || H <= 0 || W <= 0 || param_stride <= 0) return ADAISP_EINVAL;
+    if (B > 65535) return ADAISP_ESHAPE;
+    return launch_backward_params(img, grad_out, filter_id, params, param_stride, grad_params, B, H, W, flags,
+                                  static_cast<hipStream_t>(stream)) == hipSuccess
+               ? ADAISP_OK
+               : ADAISP_ELAUNCH;
+}
+
+}  // extern "C"

@@ -1,0 +1,179 @@
+// Small-stencil ISP filters for gfx950: the 3x3 sharpen pair (adjust_sharpness / sharpness) and
+// the 5x5 gaussian unsharp mask. LDS-staged 2-D tiles: a 256-thread workgroup owns a 64x32 output
+// tile; the tile plus halo of all three planes is staged once into LDS with 16-B global loads
+// (quad-aligned columns x0-4 .. x0+67), then every lane produces 4 px x 2 rows per plane and
+// stores 16 B per plane per row. HBM traffic stays at the algorithmic 24 B/px: halo re-reads of
+// neighbouring tiles are served by L2.
+//
+// Reference: isp/sharpen.py:105-142 (adjust_sharpness), :145-182 (sharpness), :63-102 (unsharp_mask).
+#include "isp_internal.h"
+
+namespace adaisp {
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int TW = 64, TH = 32;
+constexpr int PITCH = TW + 8;           // quad-aligned columns x0-4 .. x0+TW+3
+constexpr int MAXR = 2;
+constexpr int ROWS_MAX = TH + 2 * MAXR;
+
+enum Mode { kAdjust = 0, kSharpness = 1, kUSM = 2 };
+
+// torch 'reflect' padding index (edge not repeated); valid for -n < i < 2n-1.
+__device__ __forceinline__ int reflect(int i, int n) {
+    if (i < 0) i = -i;
+    if (i >= n) i = 2 * n - 2 - i;
+    return i;
+}
+
+template <int R, int MODE, bool VEC>
+__device__ void conv_tile(float* __restrict__ lds, const float* __restrict__ in, float* __restrict__ out,
+                          const float* __restrict__ p, int H, int W) {
+    constexpr int ROWS = TH + 2 * R;
+    constexpr int QPR = PITCH / 4;  // quads per staged row
+    const int tid = threadIdx.x;
+    const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
+    const long plane = (long)H * W;
+
+    // ---- stage tile + halo of the 3 planes ------------------------------------------------------
+    for (int q = tid; q < 3 * ROWS * QPR; q += kThreads) {
+        const int c = q / (ROWS * QPR);
+        const int rem = q - c * (ROWS * QPR);
+        const int ly = rem / QPR, lq = rem - ly * QPR;
+        int gy = y0 - R + ly;
+        const int gx = x0 - 4 + 4 * lq;
+        const float* src = in + c * plane;
+        float4 v;
+        if (MODE == kUSM) gy = reflect(gy, H);
+        const bool row_ok = (gy >= 0) && (gy < H);
+        if (VEC && row_ok && gx >= 0 && gx + 3 < W) {
+            v = *reinterpret_cast<const float4*>(src + (long)gy * W + gx);
+        } else {
+            float t[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                int xx = gx + k;
+                if (MODE == kUSM) {
+                    // columns further than the reflect range (only in the unused part of the quad margin
+                    // or beyond the image's right edge of a partial tile) are never consumed
+                    xx = (xx > -W && xx < 2 * W - 1) ? reflect(xx, W) : 0;
+                    t[k] = row_ok ? src[(long)gy * W + xx] : 0.0f;
+                } else {
+                    t[k] = (row_ok && xx >= 0 && xx < W) ? src[(long)gy * W + xx] : 0.0f;
+                }
+            }
+            v = make_float4(t[0], t[1], t[2], t[3]);
+        }
+        *reinterpret_cast<float4*>(lds + (c * ROWS + ly) * PITCH + 4 * lq) = v;
+    }
+
+    // ---- per-image weights ------------------------------------------------------------------------
+    float w[2 * R + 1][2 * R + 1];
+    float amount;
+    if (MODE == kUSM) {
+        // _get_gaussian_kernel1d (isp/sharpen.py:15-23): pdf = exp(-0.5 * (x / sigma)^2), x = -2..2
+        const float sigma = p[0];
+        amount = p[1];
+        float g1[5], sum = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            const float t = (float)(i - 2) / sigma;
+            g1[i] = expf(-0.5f * (t * t));
+            sum += g1[i];
+        }
+#pragma unroll
+        for (int i = 0; i < 5; ++i) g1[i] = g1[i] / sum;
+#pragma unroll
+        for (int i = 0; i < 2 * R + 1; ++i)
+#pragma unroll
+            for (int j = 0; j < 2 * R + 1; ++j) w[i][j] = g1[i] * g1[j];
+    } else {
+        amount = p[0];
+        const float a = 1.0f / 13.0f, c5 = 5.0f / 13.0f;  // ones(3,3) with centre 5, divided by its sum
+#pragma unroll
+        for (int i = 0; i < 2 * R + 1; ++i)
+#pragma unroll
+            for (int j = 0; j < 2 * R + 1; ++j) w[i][j] = (i == R && j == R) ? c5 : a;
+    }
+    __syncthreads();
+
+    // ---- 4 px x 2 rows per lane per plane ---------------------------------------------------------
+    const int tx = tid & 15, ty = tid >> 4;
+    const int gx = x0 + 4 * tx;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        const int ly = ty + 16 * half;          // output row inside the tile
+        const int gy = y0 + ly;
+        if (gy >= H || gx >= W) continue;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float v[2 * R + 1][4 + 2 * R];
+#pragma unroll
+            for (int i = 0; i < 2 * R + 1; ++i)
+#pragma unroll
+                for (int j = 0; j < 4 + 2 * R; ++j)
+                    v[i][j] = lds[(c * ROWS + ly + i) * PITCH + 4 + 4 * tx - R + j];
+            float o[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float blur = 0.0f;
+#pragma unroll
+                for (int i = 0; i < 2 * R + 1; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2 * R + 1; ++j) blur = fmaf(w[i][j], v[i][k + j], blur);
+                const float ctr = v[R][k + R];
+                if (MODE != kUSM) {
+                    // the 1-px frame keeps the image (valid conv + zero-padded mask + where, sharpen.py:133-138)
+                    const int xx = gx + k;
+                    if (gy == 0 || gy == H - 1 || xx == 0 || xx >= W - 1) blur = ctr;
+                }
+                float r;
+                if (MODE == kAdjust) r = ctr * amount + blur * (1.0f - amount);
+                else r = ctr + (ctr - blur) * amount;
+                o[k] = clamp01(r);
+            }
+            float* dst = out + c * plane + (long)gy * W + gx;
+            if (VEC && gx + 3 < W) {
+                *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (gx + k < W) dst[k] = o[k];
+            }
+        }
+    }
+}
+
+template <bool VEC>
+__global__ __launch_bounds__(kThreads) void k_conv(const float* __restrict__ img, float* __restrict__ out,
+                                                   const int32_t* __restrict__ ids, int uniform_op,
+                                                   const float* __restrict__ params, int pstride, int H, int W) {
+    __shared__ __attribute__((aligned(16))) float lds[3 * ROWS_MAX * PITCH];
+    const int b = blockIdx.z;
+    const int op = ids ? ids[b] : uniform_op;
+    const long off = (long)b * 3 * H * W;
+    const float* p = params + (long)b * pstride;
+    switch (op) {
+        case ADAISP_OP_SHARPEN:    conv_tile<1, kAdjust, VEC>(lds, img + off, out + off, p, H, W); break;
+        case ADAISP_OP_SHARPEN_V2: conv_tile<1, kSharpness, VEC>(lds, img + off, out + off, p, H, W); break;
+        case ADAISP_OP_USM:        conv_tile<2, kUSM, VEC>(lds, img + off, out + off, p, H, W); break;
+        default: break;
+    }
+}
+
+}  // namespace
+
+hipError_t launch_conv(const Batch& a, hipStream_t s) {
+    const bool vec = (a.W % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.img) & 15) == 0) &&
+                     ((reinterpret_cast<uintptr_t>(a.out) & 15) == 0);
+    dim3 grid((a.W + TW - 1) / TW, (a.H + TH - 1) / TH, a.B);
+    if (vec)
+        hipLaunchKernelGGL(k_conv<true>, grid, dim3(kThreads), 0, s, a.img, a.out, a.ids, a.uniform_op, a.params,
+                           a.pstride, a.H, a.W);
+    else
+        hipLaunchKernelGGL(k_conv<false>, grid, dim3(kThreads), 0, s, a.img, a.out, a.ids, a.uniform_op, a.params,
+                           a.pstride, a.H, a.W);
+    return hipGetLastError();
+}
+
+}  // namespace adaisp

@@ -1,0 +1,179 @@
+#!/usr/bin/env python3
+"""Golden-vector generator: imports the REFERENCE (OpenImagingLab/AdaptiveISP at /root/reference)
+unmodified and records inputs -> outputs of the ISP hot path as small .npz fixtures.
+
+Runs ONLY in the build container (the reference never travels to the GPU box); the fixtures it
+writes are committed next to it. Absent third-party modules are stubbed: cv2,
+easydict, skimage are used only by visualisation/demo code; torchvision's `torch_pad` IS
+torch.nn.functional.pad in the pinned torchvision 0.15.2.
+
+    python tests/golden/gen_golden.py
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+sys.dont_write_bytecode = True
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+from _synth import synth_state_dict, test_image  # noqa: E402
+
+
+def _stub(name, **attrs):
+    m = types.ModuleType(name)
+    m.__dict__.update(attrs)
+    sys.modules[name] = m
+    return m
+
+
+def import_reference(root="/root/reference"):
+    _stub("cv2")
+    _stub("easydict", EasyDict=dict)
+    sk = _stub("skimage"); sk.io = _stub("skimage.io")
+    tv = _stub("torchvision"); tv.transforms = _stub("torchvision.transforms")
+    tv.transforms.functional_tensor = _stub("torchvision.transforms.functional_tensor",
+                                            torch_pad=torch.nn.functional.pad)
+    import matplotlib
+    matplotlib.use("Agg")
+    sys.path.insert(0, root)
+    from isp import filters
+    from config import cfg
+    import agent
+    import value
+    return filters, cfg, agent, value
+
+
+def main():
+    import warnings
+    warnings.filterwarnings("ignore")
+    torch.set_num_threads(4)
+    filters, cfg, agent_mod, value_mod = import_reference()
+    T = torch.from_numpy
+
+    # ---------------------------------------------------------------- A. every filter: process + forward
+    out = {}
+    img = test_image(2, 24, 40, seed=11)
+    out["img"] = img
+    classes = [
+        ("E", filters.ExposureFilter), ("G", filters.GammaFilter), ("CCM", filters.CCMFilter),
+        ("Shr", filters.SharpenFilter), ("NLM", filters.DenoiseFilter), ("T", filters.ToneFilter),
+        ("Ct", filters.ContrastFilter), ("S+", filters.SaturationPlusFilter), ("BW", filters.WNBFilter),
+        ("W", filters.ImprovedWhiteBalanceFilter), ("USM", filters.SharpenUSMFilter),
+        ("ShrV2", filters.SharpenFilterV2), ("C", filters.ColorFilter),
+    ]
+    rng = np.random.default_rng(5)
+    with torch.no_grad():
+        for name, cls in classes:
+            f = cls(cfg, predict=False)
+            n = f.get_num_filter_parameters()
+            feat = rng.normal(0.0, 1.2, (2, n)).astype(np.float32)
+            if name == "USM":
+                feat[:, 0] = np.abs(feat[:, 0]) * 0.5 + 0.2      # keep sigma away from 0 (NaN kernel)
+            param = f.filter_param_regressor(T(feat))
+            proc = f.process(T(img), param)
+            fwd, _, _ = f.forward(T(img), specified_parameter=param)
+            key = name.replace("+", "p")
+            out[f"{key}.feat"] = feat
+            out[f"{key}.param"] = param.reshape(2, -1).numpy()
+            out[f"{key}.process"] = proc.numpy()
+            out[f"{key}.forward"] = fwd.numpy()
+    np.savez_compressed(os.path.join(HERE, "filters.npz"), **out)
+
+    # ---------------------------------------------------------------- B. NLM wrap-around cases
+    out = {}
+    nlm = filters.DenoiseFilter(cfg, predict=False)
+    with torch.no_grad():
+        for tag, shape, hs, seed in (("a", (2, 20, 28), [0.08, 0.5], 21), ("tiny", (1, 6, 9), [0.3], 22),
+                                     ("odd", (1, 37, 70), [0.02], 23)):
+            x = test_image(shape[0], shape[1], shape[2], seed=seed, special=False)
+            x += np.random.default_rng(seed).normal(0, 0.02, x.shape).astype(np.float32)
+            h = np.asarray(hs, np.float32).reshape(-1, 1)
+            out[f"{tag}.img"] = x
+            out[f"{tag}.h"] = h
+            out[f"{tag}.out"] = nlm.process(T(x), T(h)).numpy()
+    np.savez_compressed(os.path.join(HERE, "nlm.npz"), **out)
+
+    # ---------------------------------------------------------------- C. adaptive 64x64 pooling
+    out = {}
+    pool = torch.nn.AdaptiveAvgPool2d((64, 64))
+    for tag, (B, H, W) in (("a", (1, 72, 100)), ("small", (2, 30, 50)), ("exact", (1, 128, 64)), ("hd", (1, 90, 160))):
+        x = test_image(B, H, W, seed=31 + H, special=False)
+        out[f"{tag}.img"] = x
+        out[f"{tag}.out"] = pool(T(x)).numpy()
+    np.savez_compressed(os.path.join(HERE, "pool64.npz"), **out)
+
+    # ---------------------------------------------------------------- D. Agent.forward (eval), E. Value.forward
+    out = {}
+    ag = agent_mod.Agent(cfg, shape=(6 + len(cfg.filters), 64, 64), device="cpu")
+    ag.load_state_dict(synth_state_dict(ag, seed=0))
+    ag.eval()
+    va = value_mod.Value(cfg, shape=(9 + len(cfg.filters), 64, 64))
+    va.load_state_dict(synth_state_dict(va, seed=1))
+    va.eval()
+    x = test_image(2, 32, 48, seed=41)
+    z = np.random.default_rng(42).random((2, cfg.z_dim)).astype(np.float32)
+    s0 = np.zeros((2, cfg.num_state_dim), np.float32)
+    s1 = s0.copy(); s1[:, 2] = 4.0; s1[0, 3 + 5] = 1.0; s1[1, 3 + 2] = 1.0     # step 4 (-> last), some usage
+    out["x"], out["z"], out["s0"], out["s1"] = x, z, s0, s1
+    cap = {}
+    ag.fc2.register_forward_hook(lambda m, i, o: cap.__setitem__("logits", o.detach().clone()))
+    ag.feature_extractor.register_forward_hook(lambda m, i, o: cap.__setitem__("features", o.detach().clone()))
+    with torch.no_grad():
+        for tag, st, prog in (("s0", s0, 1.0), ("s1", s1, 0.25)):
+            (xo, ns, sur, pen), dbg, _ = ag((T(x), T(z), T(st)), prog)
+            out[f"{tag}.progress"] = np.float32(prog)
+            out[f"{tag}.x"] = xo.numpy(); out[f"{tag}.new_states"] = ns.numpy()
+            out[f"{tag}.surrogate"] = sur.numpy(); out[f"{tag}.penalty"] = pen.numpy()
+            out[f"{tag}.selected"] = dbg["selected_filter"].numpy().astype(np.int64)
+            out[f"{tag}.pdf0"] = dbg["pdf"].numpy()
+            out[f"{tag}.logits"] = cap["logits"].numpy()
+            out[f"{tag}.features"] = cap["features"].numpy()
+        # teacher-forced selection of every filter (same params, progress 1.0, states s0)
+        for k in range(len(cfg.filters)):
+            (xo, ns, sur, pen), dbg, _ = ag((T(x), T(z), T(s0)), 1.0, selected_filter_id=k)
+            out[f"forced{k}.x"] = xo.numpy()
+            out[f"forced{k}.new_states"] = ns.numpy()
+            out[f"forced{k}.penalty"] = pen.numpy()
+            out[f"forced{k}.param0"] = dbg["filter_debug_info"][k]["filter_parameters"].reshape(-1).numpy()
+        # high-res path: params from the low-res image applied to a second tensor (agent.py:155-157)
+        xh = test_image(2, 40, 72, seed=43)
+        (xo, ns, hro), dbg, _ = ag((T(x), T(z), T(s0)), 1.0, high_res=T(xh), selected_filter_id=5)
+        out["hr.in"], out["hr.x"], out["hr.out"] = xh, xo.numpy(), hro.numpy()
+        # 5-step teacher-forced trajectory, schedule S_mixed = [E, CCM, NLM, Shr, T]
+        xt, st = T(x), T(s0)
+        for step, k in enumerate([0, 2, 4, 3, 5]):
+            (xt, st, sur, pen), dbg, _ = ag((xt, T(z), st), 1.0, selected_filter_id=k)
+            out[f"traj{step}.x"] = xt.numpy(); out[f"traj{step}.states"] = st.numpy()
+            out[f"traj{step}.penalty"] = pen.numpy()
+        out["value.s0"] = va(T(x), T(s0)).numpy()
+        out["value.s1"] = va(T(x), T(s1)).numpy()
+        out["value.none"] = value_mod.Value(cfg, shape=(6, 64, 64)).eval()(T(x)).numpy() * 0  # shape check only
+    np.savez_compressed(os.path.join(HERE, "agent.npz"), **out)
+    import json
+    with open(os.path.join(HERE, "state_dict_keys.json"), "w") as f:
+        json.dump({"agent": {k: list(v.shape) for k, v in ag.state_dict().items()},
+                   "value": {k: list(v.shape) for k, v in va.state_dict().items()}}, f, indent=0)
+
+    # ---------------------------------------------------------------- F. integer stages: pdf_sample / one_hot
+    out = {}
+    r = np.random.default_rng(7)
+    pdf = r.random((24, 10)).astype(np.float32) ** 3
+    pdf /= pdf.sum(1, keepdims=True)
+    u = r.random((24, 1)).astype(np.float32)
+    u[0, 0] = 0.0                                  # -> index -1 -> all-zero one-hot
+    u[1, 0] = np.nextafter(np.float32(1.0), np.float32(0.0))
+    u[2, 0] = pdf[2, 0]                            # exactly on a cdf boundary
+    idx = agent_mod.pdf_sample(T(pdf), T(u))
+    out["pdf"], out["u"], out["idx"] = pdf, u, idx.numpy().astype(np.int64)
+    out["one_hot"] = agent_mod.one_hot(10, idx.to(torch.int64)).numpy()
+    np.savez_compressed(os.path.join(HERE, "select.npz"), **out)
+
+    tot = sum(os.path.getsize(os.path.join(HERE, f)) for f in os.listdir(HERE) if f.endswith(".npz"))
+    print("fixtures written, total bytes:", tot)
+
+
+if __name__ == "__main__":
+    main()

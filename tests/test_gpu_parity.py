@@ -1,0 +1,191 @@
+"""HIP kernels vs the oracle / the reference's golden vectors, through the C-ABI (libadaisp.so).
+Tolerances: integer/selection stages exact; fp32 filters 1e-5 relative (north_star), with a small
+absolute floor for values near zero."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+OPS = {"E": 0, "G": 1, "CCM": 2, "Shr": 3, "NLM": 4, "T": 5, "Ct": 6, "Sp": 7, "BW": 8, "W": 9, "USM": 10,
+       "ShrV2": 11, "C": 12}
+RTOL, ATOL = 1e-5, 2e-6
+
+
+def dev():
+    assert torch.cuda.is_available(), "run with -m gpu on the MI355X box"
+    return torch.device("cuda:0")
+
+
+def gpu_process(op, img, params, clip):
+    from adaptiveisp_amd import _lib
+    out = _lib.process(op, torch.from_numpy(img).to(dev()), torch.from_numpy(np.asarray(params, np.float32)).to(dev()),
+                       clip=clip)
+    torch.cuda.synchronize()
+    return out.cpu().numpy()
+
+
+def rand_params(op, B, rng):
+    """Regressed-range parameters for op."""
+    if op in (OPS["E"],): return rng.uniform(-3.0, 3.0, (B, 1))
+    if op == OPS["G"]: return rng.uniform(0.4, 2.8, (B, 1))
+    if op == OPS["CCM"]: return rng.uniform(0.2, 2.0, (B, 9)) * np.where(rng.random((B, 9)) < 0.2, -0.3, 1.0)
+    if op in (OPS["Shr"], OPS["ShrV2"]): return rng.uniform(0.0, 10.0, (B, 1))
+    if op == OPS["NLM"]: return rng.uniform(0.02, 0.9, (B, 1))
+    if op == OPS["T"]: return rng.uniform(0.5, 2.0, (B, 8))
+    if op == OPS["C"]: return rng.uniform(0.9, 1.1, (B, 24))
+    if op == OPS["Ct"]: return rng.uniform(-0.95, 0.95, (B, 1))
+    if op in (OPS["Sp"], OPS["BW"]): return rng.uniform(0.02, 0.98, (B, 1))
+    if op == OPS["W"]: return rng.uniform(0.6, 1.6, (B, 3))
+    if op == OPS["USM"]: return np.stack([rng.uniform(0.3, 2.0, B), rng.uniform(0.0, 2.0, B)], 1)
+    raise KeyError(op)
+
+
+@pytest.mark.parametrize("name", sorted(OPS))
+@pytest.mark.parametrize("mode", ["process", "forward"])
+def test_golden_vectors(golden, name, mode):
+    """Same inputs as the reference run in the build container -> same outputs."""
+    g = golden("filters")
+    out = gpu_process(OPS[name], g["img"], g[f"{name}.param"], clip=(mode == "forward"))
+    np.testing.assert_allclose(out, g[f"{name}.{mode}"], rtol=RTOL, atol=ATOL)
+
+
+@pytest.mark.parametrize("tag", ["a", "tiny", "odd"])
+def test_golden_nlm_wrap(golden, tag):
+    g = golden("nlm")
+    out = gpu_process(OPS["NLM"], g[f"{tag}.img"], g[f"{tag}.h"], clip=True)
+    np.testing.assert_allclose(out, g[f"{tag}.out"], rtol=RTOL, atol=ATOL)
+
+
+@pytest.mark.parametrize("tag", ["a", "small", "exact", "hd"])
+def test_golden_pool64(golden, tag):
+    from adaptiveisp_amd import _lib
+    g = golden("pool64")
+    out = _lib.pool64(torch.from_numpy(g[f"{tag}.img"]).to(dev())).cpu().numpy()
+    np.testing.assert_allclose(out, g[f"{tag}.out"], rtol=RTOL, atol=1e-7)
+
+
+SHAPES = [(2, 64, 128), (1, 37, 53), (3, 5, 7), (1, 3, 3), (1, 33, 260), (2, 96, 64)]
+
+
+@pytest.mark.parametrize("name", sorted(OPS))
+@pytest.mark.parametrize("shape", SHAPES)
+def test_vs_oracle_shapes(oracle_mod, name, shape):
+    """Vector and scalar paths, ragged tiles, minimum sizes; inputs include out-of-range values."""
+    from _synth import test_image
+    B, H, W = shape
+    rng = np.random.default_rng(abs(hash((name, shape))) % (2 ** 31))
+    img = test_image(B, H, W, seed=H * 1000 + W)
+    img += rng.normal(0, 0.01, img.shape).astype(np.float32)
+    if name not in ("NLM",):
+        img[:, :, H // 2] *= 3.0                       # a bright row that leaves [0,1]
+    p = rand_params(OPS[name], B, rng).astype(np.float32)
+    for clip in (False, True):
+        out = gpu_process(OPS[name], img, p, clip)
+        ref = oracle_mod.forward(img, OPS[name], p, clip=clip)
+        np.testing.assert_allclose(out, ref, rtol=RTOL, atol=ATOL, err_msg=f"{name} {shape} clip={clip}")
+
+
+def test_mixed_ids_one_call(oracle_mod):
+    """adaisp_forward: every op (and the zero image) in one batch, ids on the device, fused pooling."""
+    from _synth import test_image
+    from adaptiveisp_amd import _lib
+    ids = np.array([-1] + list(range(13)), np.int32)
+    B = len(ids)
+    rng = np.random.default_rng(3)
+    img = test_image(B, 72, 100, seed=9)
+    params = np.zeros((B, 24), np.float32)
+    for b, op in enumerate(ids):
+        if op >= 0:
+            p = rand_params(int(op), 1, rng)
+            params[b, :p.shape[1]] = p[0]
+    pooled = torch.empty(B, 3, 64, 64, device=dev())
+    out = _lib.forward(torch.from_numpy(img).to(dev()), torch.from_numpy(ids).to(dev()),
+                       torch.from_numpy(params).to(dev()), clip=True, pooled=pooled)
+    torch.cuda.synchronize()
+    ref = oracle_mod.forward(img, ids, params, clip=True)
+    np.testing.assert_allclose(out.cpu().numpy(), ref, rtol=RTOL, atol=ATOL)
+    assert not out[0].any()
+    np.testing.assert_allclose(pooled.cpu().numpy(), oracle_mod.pool64(ref), rtol=RTOL, atol=1e-6)
+    # the per-op entry point runs the same kernels: bit-identical to the mixed call
+    for b, op in enumerate(ids):
+        one = _lib.process(int(op), torch.from_numpy(img[b:b + 1]).to(dev()), torch.from_numpy(params[b:b + 1]).to(dev()),
+                           clip=True)
+        assert torch.equal(one[0], out[b]), f"op {op}"
+
+
+def test_error_paths():
+    from adaptiveisp_amd import _lib
+    x = torch.rand(1, 3, 8, 8, device=dev())
+    p = torch.ones(1, 9, device=dev())
+    with pytest.raises(_lib.AdaispError, match="alias"):
+        _lib.process(OPS["Shr"], x, p, out=x)
+    with pytest.raises(_lib.AdaispError, match="shape"):
+        _lib.process(OPS["USM"], torch.rand(1, 3, 2, 8, device=dev()), p)
+    with pytest.raises(_lib.AdaispError, match="unknown op"):
+        _lib.process(77, x, p)
+    y = _lib.process(OPS["E"], x.clone(), p, out=None)
+    z = x.clone()
+    _lib.process(OPS["E"], z, p, out=z)                      # pointwise ops may run in place
+    assert torch.equal(y, z)
+
+
+# ---- BASELINE.json sizes: properties that need no oracle run ---------------------------------------------
+
+def _full(B=8, H=720, W=1280, seed=1235):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return (torch.rand(B, 3, H, W, generator=g) ** 2.2 * 0.5).to(dev())
+
+
+def test_fullsize_identities():
+    from adaptiveisp_amd import _lib
+    x = _full()
+    B = x.shape[0]
+    one = torch.ones(B, 1, device=dev())
+    # identity parameterisations are exact
+    assert torch.equal(_lib.process(OPS["W"], x, torch.ones(B, 3, device=dev())), x)
+    eye = torch.eye(3, device=dev()).reshape(1, 9).repeat(B, 1)
+    assert torch.equal(_lib.process(OPS["CCM"], x, eye * 2.0), x)              # rows are re-normalised
+    assert torch.equal(_lib.process(OPS["E"], x, one * 0.0), x)
+    assert torch.equal(_lib.process(OPS["G"], x.clamp_min(0.001), one), x.clamp_min(0.001))
+    assert torch.equal(_lib.process(OPS["BW"], x, one * 0.0), x)
+    assert torch.equal(_lib.process(OPS["Sp"], x, one * 0.0), x)
+    assert torch.equal(_lib.process(OPS["Shr"], x, one), x)                      # factor 1 keeps the image
+    assert torch.equal(_lib.process(OPS["ShrV2"], x, one * 0.0), x)
+    # exposure: +1 EV then -1 EV is the identity up to two roundings of exp()
+    y = _lib.process(OPS["E"], _lib.process(OPS["E"], x, one), x.new_full((B, 1), -1.0))
+    torch.testing.assert_close(y, x, rtol=1e-6, atol=0)
+    # a flat tone curve is the identity on [0,1] up to rounding
+    t = _lib.process(OPS["T"], x, torch.full((B, 8), 1.3, device=dev()))
+    torch.testing.assert_close(t, x, rtol=2e-6, atol=1e-7)
+    # clip is idempotent and bounds the output
+    c = _lib.process(OPS["E"], x, one * 3.0, clip=True)
+    assert float(c.max()) <= 1.0 and float(c.min()) >= 0.0
+    assert torch.equal(_lib.process(OPS["W"], c, torch.ones(B, 3, device=dev()), clip=True), c)
+
+
+def test_fullsize_nlm_properties():
+    from adaptiveisp_amd import _lib
+    x = _full(B=2)
+    # h -> 0: only the zero shift keeps weight 1, the filter returns the (clamped) image exactly
+    y = _lib.process(OPS["NLM"], x, torch.zeros(2, 1, device=dev()))
+    assert torch.equal(y, x)
+    # a constant image is a fixed point for any h, and the output is a convex combination of inputs
+    c = torch.full_like(x, 0.375)
+    torch.testing.assert_close(_lib.process(OPS["NLM"], c, torch.full((2, 1), 0.5, device=dev())), c, rtol=1e-6,
+                               atol=0)
+    z = _lib.process(OPS["NLM"], x, torch.full((2, 1), 0.3, device=dev()))
+    assert float(z.max()) <= float(x.max()) + 1e-6 and float(z.min()) >= float(x.min()) - 1e-6
+    # circular boundary: rolling the input rolls the output (torch.roll semantics of the reference)
+    xr = torch.roll(x, shifts=(17, -29), dims=(2, 3)).contiguous()
+    zr = _lib.process(OPS["NLM"], xr, torch.full((2, 1), 0.3, device=dev()))
+    assert torch.equal(zr, torch.roll(z, shifts=(17, -29), dims=(2, 3)))
+
+
+def test_fullsize_pool_checksum():
+    from adaptiveisp_amd import _lib
+    x = _full(B=8)
+    p = _lib.pool64(x)
+    # 1280 = 64*20 columns tile exactly; rows overlap (720/64 = 11.25) -> compare against torch's own pooling
+    ref = torch.nn.functional.adaptive_avg_pool2d(x, (64, 64))
+    torch.testing.assert_close(p, ref, rtol=1e-5, atol=1e-7)

@@ -1,0 +1,120 @@
+"""Host-side mirror of the reference interface (Filter heads/regressors, Agent, Value) against the
+golden vectors. Pixels are produced by the oracle here (CPU run); tests/test_gpu_*.py repeat the same
+comparisons with the HIP kernels."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from _engine import cpu_agent, cpu_value
+from adaptiveisp_amd.config import cfg
+from adaptiveisp_amd.isp import filters as F
+
+T = torch.from_numpy
+CLASSES = {"E": F.ExposureFilter, "G": F.GammaFilter, "CCM": F.CCMFilter, "Shr": F.SharpenFilter,
+           "NLM": F.DenoiseFilter, "T": F.ToneFilter, "Ct": F.ContrastFilter, "Sp": F.SaturationPlusFilter,
+           "BW": F.WNBFilter, "W": F.ImprovedWhiteBalanceFilter, "USM": F.SharpenUSMFilter,
+           "ShrV2": F.SharpenFilterV2, "C": F.ColorFilter}
+
+
+@pytest.mark.parametrize("name", sorted(CLASSES))
+def test_regressor_matches_reference(golden, name):
+    g = golden("filters")
+    f = CLASSES[name](cfg, predict=False)
+    with torch.no_grad():
+        p = f.filter_param_regressor(T(g[f"{name}.feat"])).reshape(2, -1).numpy()
+    assert np.array_equal(p, g[f"{name}.param"]), np.abs(p - g[f"{name}.param"]).max()
+
+
+def test_short_names_and_param_counts():
+    names = [c(cfg).get_short_name() for c in cfg.filters]
+    assert names == ["E", "G", "CCM", "Shr", "NLM", "T", "Ct", "S+", "BW", "W"]
+    assert [c(cfg).get_num_filter_parameters() for c in cfg.filters] == [1, 1, 9, 1, 1, 8, 1, 1, 1, 3]
+    assert all(c(cfg).get_num_mask_parameters() == 6 and not c(cfg).use_masking() for c in cfg.filters)
+
+
+def test_state_dict_keys_match_reference():
+    here = os.path.dirname(os.path.abspath(__file__))
+    ref = json.load(open(os.path.join(here, "golden", "state_dict_keys.json")))
+    ag, va = cpu_agent(cfg), cpu_value(cfg)
+    assert {k: list(v.shape) for k, v in ag.state_dict().items()} == ref["agent"]
+    assert {k: list(v.shape) for k, v in va.state_dict().items()} == ref["value"]
+    assert sum(p.numel() for p in ag.parameters()) == 7176609
+    assert sum(p.numel() for p in va.parameters()) == 1223841
+
+
+def test_cfg_values():
+    assert cfg.num_state_dim == 13 and cfg.z_dim == 163 and cfg.test_steps == 5
+    assert cfg.exploration == 0.05 and cfg.filter_usage_penalty == 1.0 and cfg.feature_extractor_dims == 4096
+
+
+@pytest.mark.parametrize("tag", ["s0", "s1"])
+def test_agent_eval_forward(golden, tag):
+    g = golden("agent")
+    ag = cpu_agent(cfg)
+    with torch.no_grad():
+        (x, ns, sur, pen), dbg, debugger = ag((T(g["x"]), T(g["z"]), T(g[tag])), float(g[f"{tag}.progress"]))
+    assert np.array_equal(dbg["selected_filter"].numpy(), g[f"{tag}.selected"])        # integer stage: exact
+    assert dbg["selected_filter"].dtype == torch.int64
+    assert np.array_equal(ns.numpy(), g[f"{tag}.new_states"])
+    np.testing.assert_allclose(dbg["pdf"].numpy(), g[f"{tag}.pdf0"], rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(sur.numpy(), g[f"{tag}.surrogate"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(pen.numpy(), g[f"{tag}.penalty"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(x.numpy(), g[f"{tag}.x"], rtol=1e-5, atol=2e-6)
+    assert set(dbg) == {"state", "selected_filter_id", "filter_debug_info", "pdf", "selected_filter"}
+    assert debugger.width == g["x"].shape[2]
+
+
+@pytest.mark.parametrize("k", range(10))
+def test_agent_teacher_forced(golden, k):
+    g = golden("agent")
+    ag = cpu_agent(cfg)
+    with torch.no_grad():
+        (x, ns, sur, pen), dbg, _ = ag((T(g["x"]), T(g["z"]), T(g["s0"])), 1.0, selected_filter_id=k)
+    np.testing.assert_allclose(dbg["filter_debug_info"][k]["filter_parameters"].reshape(-1).numpy(),
+                               g[f"forced{k}.param0"], rtol=1e-5, atol=1e-6)
+    assert np.array_equal(ns.numpy(), g[f"forced{k}.new_states"])
+    np.testing.assert_allclose(pen.numpy(), g[f"forced{k}.penalty"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(x.numpy(), g[f"forced{k}.x"], rtol=1e-5, atol=2e-6)
+
+
+def test_agent_high_res_and_trajectory(golden):
+    g = golden("agent")
+    ag = cpu_agent(cfg)
+    with torch.no_grad():
+        (x, ns, hr), _, _ = ag((T(g["x"]), T(g["z"]), T(g["s0"])), 1.0, high_res=T(g["hr.in"]), selected_filter_id=5)
+        np.testing.assert_allclose(x.numpy(), g["hr.x"], rtol=1e-5, atol=2e-6)
+        np.testing.assert_allclose(hr.numpy(), g["hr.out"], rtol=1e-5, atol=2e-6)
+        xt, st = T(g["x"]), T(g["s0"])
+        for step, k in enumerate([0, 2, 4, 3, 5]):
+            (xt, st, sur, pen), _, _ = ag((xt, T(g["z"]), st), 1.0, selected_filter_id=k)
+            assert np.array_equal(st.numpy(), g[f"traj{step}.states"])
+            np.testing.assert_allclose(pen.numpy(), g[f"traj{step}.penalty"], rtol=1e-5, atol=1e-6)
+            # errors compound along the trajectory through the re-predicted parameters
+            np.testing.assert_allclose(xt.numpy(), g[f"traj{step}.x"], rtol=1e-4, atol=2e-5)
+
+
+def test_value_forward(golden):
+    g = golden("agent")
+    va = cpu_value(cfg)
+    with torch.no_grad():
+        np.testing.assert_allclose(va(T(g["x"]), T(g["s0"])).numpy(), g["value.s0"], rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(va(T(g["x"]), T(g["s1"])).numpy(), g["value.s1"], rtol=1e-5, atol=1e-6)
+
+
+def test_pdf_sample_one_hot_exact(golden):
+    from adaptiveisp_amd.agent import one_hot, pdf_sample
+    g = golden("select")
+    idx = pdf_sample(T(g["pdf"]), T(g["u"]))
+    assert np.array_equal(idx.numpy(), g["idx"])
+    assert np.array_equal(one_hot(10, idx.to(torch.int64)).numpy(), g["one_hot"])
+
+
+def test_no_cpu_fallback():
+    """The product must not filter pixels on the CPU: CPU tensors are rejected loudly."""
+    from adaptiveisp_amd import _lib
+    f = F.ExposureFilter(cfg)
+    with pytest.raises(_lib.AdaispError):
+        f.process(torch.rand(1, 3, 8, 8), torch.zeros(1, 1))
