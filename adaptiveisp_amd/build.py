@@ -19,6 +19,10 @@ LIBS = {
                  "isp_api.hip"],
         headers=["isp_internal.h", "../../include/adaisp.h"],
         flags=ISP_FLAGS),
+    "libadayolo.so": dict(
+        sources=["yolo_conv.hip", "yolo_misc.hip", "yolo_api.hip"],
+        headers=["../../include/adayolo.h"],
+        flags=["-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]),
 }
 
 

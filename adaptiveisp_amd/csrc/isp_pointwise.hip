@@ -28,13 +28,28 @@ struct OpExposure {  // isp/filters.py:223-224   img * exp(p * ln2)
     __device__ __forceinline__ void apply(float& r, float& g, float& b) const { r *= s; g *= s; b *= s; }
 };
 
+// x^g for x >= 0.001 (normal, positive) and moderate g, ~2 ulp, on the hardware log2/exp2 units.
+// libm's powf costs ~360 VALU slots (it also serves negative bases, integer exponents, subnormals) and made
+// the gamma filter VALU-bound at 22 % of HBM; this form needs ~25. log2(x) is split into the v_log_f32
+// result `hi` plus a first-order correction `lo` recovered from 2^hi, and the rounding error of g*hi is
+// carried by an fma, so the absolute error of the exponent stays ~1e-7 even for |g*log2 x| ~ 30.
+__device__ __forceinline__ float pow_pos(float x, float g) {
+    const float hi = __builtin_amdgcn_logf(x);
+    const float t = __builtin_amdgcn_exp2f(hi);
+    const float lo = (x - t) * __builtin_amdgcn_rcpf(t) * 1.44269504088896341f;
+    const float yh = g * hi;
+    const float yl = fmaf(g, hi, -yh) + g * lo;
+    const float r = __builtin_amdgcn_exp2f(yh);
+    return fmaf(r, yl * 0.693147180559945309f, r);
+}
+
 struct OpGamma {  // isp/filters.py:244-245   pow(max(img, 0.001), gamma)
     float gm;
     __device__ void init(const float* p) { gm = p[0]; }
     __device__ __forceinline__ void apply(float& r, float& g, float& b) const {
-        r = powf(fmaxf(r, 0.001f), gm);
-        g = powf(fmaxf(g, 0.001f), gm);
-        b = powf(fmaxf(b, 0.001f), gm);
+        r = pow_pos(fmaxf(r, 0.001f), gm);
+        g = pow_pos(fmaxf(g, 0.001f), gm);
+        b = pow_pos(fmaxf(b, 0.001f), gm);
     }
 };
 

@@ -1,0 +1,93 @@
+// C-ABI of libadayolo.so (include/adayolo.h): argument checks + launches. No allocation, no sync.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/adayolo.h"
+
+namespace adayolo {
+struct ConvArgs {
+    const unsigned short* in; int in_cs;
+    const unsigned short* w; const float* bias;
+    const unsigned short* res; int res_cs;
+    unsigned short* out; int out_cs;
+    int B, H, W, Cin, Cout, Ho, Wo, ks, stride, pad, act;
+    int M;
+    int mtiles, ntiles;
+};
+hipError_t launch_conv(ConvArgs a, hipStream_t s);
+hipError_t launch_stem(const float* img, const float* w, const float* bias, void* out, int out_cs, int B, int H,
+                       int W, int Hp, int pad_top, float pad_value, hipStream_t s);
+hipError_t launch_upsample2x(const void* in, int in_cs, void* out, int out_cs, int B, int H, int W, int C,
+                             hipStream_t s);
+hipError_t launch_detect_decode(const void* raw, int raw_cs, float* pred, int pred_rows, int row_offset,
+                                const float* anchors_px, float det_stride, int B, int ny, int nx, int na, int no,
+                                hipStream_t s);
+}  // namespace adayolo
+
+using namespace adayolo;
+
+extern "C" {
+
+int adayolo_abi_version(void) { return ADAYOLO_ABI_VERSION; }
+
+const char* adayolo_strerror(int code) {
+    switch (code) {
+        case ADAYOLO_OK: return "ok";
+        case ADAYOLO_EINVAL: return "invalid argument (null pointer or non-positive size)";
+        case ADAYOLO_ESHAPE: return "shape not supported (channels/strides must be multiples of 8, ksize 1 or 3, stride 1 or 2)";
+        case ADAYOLO_ELAUNCH: return "kernel launch failed";
+        default: return "unknown error";
+    }
+}
+
+int adayolo_conv_fwd(const void* in, int in_cstride, const void* weight, const float* bias, const void* residual,
+                     int res_cstride, void* out, int out_cstride, int B, int H, int W, int Cin, int Cout, int ksize,
+                     int stride, int act, void* stream) {
+    if (!in || !weight || !bias || !out) return ADAYOLO_EINVAL;
+    if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return ADAYOLO_EINVAL;
+    if ((ksize != 1 && ksize != 3) || (stride != 1 && stride != 2)) return ADAYOLO_ESHAPE;
+    if (Cin % 8 || Cout % 8 || in_cstride % 8 || out_cstride % 8 || in_cstride < Cin || out_cstride < Cout)
+        return ADAYOLO_ESHAPE;
+    if (residual && (res_cstride % 8 || res_cstride < Cout)) return ADAYOLO_ESHAPE;
+    if (act != ADAYOLO_ACT_NONE && act != ADAYOLO_ACT_SILU) return ADAYOLO_EINVAL;
+    ConvArgs a;
+    a.in = static_cast<const unsigned short*>(in); a.in_cs = in_cstride;
+    a.w = static_cast<const unsigned short*>(weight); a.bias = bias;
+    a.res = static_cast<const unsigned short*>(residual); a.res_cs = res_cstride;
+    a.out = static_cast<unsigned short*>(out); a.out_cs = out_cstride;
+    a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
+    a.ks = ksize; a.stride = stride; a.pad = ksize / 2; a.act = act;
+    a.Ho = (H + 2 * a.pad - ksize) / stride + 1;
+    a.Wo = (W + 2 * a.pad - ksize) / stride + 1;
+    const long M = (long)B * a.Ho * a.Wo;
+    if (M > 0x7fffffffL || (long)B * H * W * in_cstride > 0x7fffffffffL) return ADAYOLO_ESHAPE;
+    a.M = (int)M; a.mtiles = a.ntiles = 0;
+    return launch_conv(a, static_cast<hipStream_t>(stream)) == hipSuccess ? ADAYOLO_OK : ADAYOLO_ELAUNCH;
+}
+
+int adayolo_stem_fwd(const float* img, const float* weight, const float* bias, void* out, int out_cstride, int B,
+                     int H, int W, int Hp, int pad_top, float pad_value, int Cout, void* stream) {
+    if (!img || !weight || !bias || !out) return ADAYOLO_EINVAL;
+    if (B <= 0 || H <= 0 || W <= 0 || Hp < H || pad_top < 0 || pad_top + H > Hp) return ADAYOLO_EINVAL;
+    if (Cout != 32 || out_cstride % 8 || out_cstride < Cout || B > 65535) return ADAYOLO_ESHAPE;
+    return launch_stem(img, weight, bias, out, out_cstride, B, H, W, Hp, pad_top, pad_value,
+                       static_cast<hipStream_t>(stream)) == hipSuccess ? ADAYOLO_OK : ADAYOLO_ELAUNCH;
+}
+
+int adayolo_upsample2x(const void* in, int in_cstride, void* out, int out_cstride, int B, int H, int W, int C,
+                       void* stream) {
+    if (!in || !out || B <= 0 || H <= 0 || W <= 0 || C <= 0) return ADAYOLO_EINVAL;
+    if (C % 8 || in_cstride % 8 || out_cstride % 8 || in_cstride < C || out_cstride < C) return ADAYOLO_ESHAPE;
+    return launch_upsample2x(in, in_cstride, out, out_cstride, B, H, W, C, static_cast<hipStream_t>(stream)) ==
+                   hipSuccess ? ADAYOLO_OK : ADAYOLO_ELAUNCH;
+}
+
+int adayolo_detect_decode(const void* raw, int raw_cstride, float* pred, int pred_rows, int row_offset,
+                          const float* anchors_px, float det_stride, int B, int ny, int nx, int na, int no,
+                          void* stream) {
+    if (!raw || !pred || !anchors_px || B <= 0 || ny <= 0 || nx <= 0 || na <= 0 || no < 5) return ADAYOLO_EINVAL;
+    if (raw_cstride < na * no || row_offset < 0 || row_offset + na * ny * nx > pred_rows) return ADAYOLO_ESHAPE;
+    return launch_detect_decode(raw, raw_cstride, pred, pred_rows, row_offset, anchors_px, det_stride, B, ny, nx, na,
+                                no, static_cast<hipStream_t>(stream)) == hipSuccess ? ADAYOLO_OK : ADAYOLO_ELAUNCH;
+}
+
+}  // extern "C"

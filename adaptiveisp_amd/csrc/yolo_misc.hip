@@ -1,0 +1,184 @@
+// Detector-side kernels that are not the generic conv: the fused ISP->detector stem, nearest 2x
+// up-sampling into a concat slice, and the Detect-head decode. gfx950 only.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/adayolo.h"
+
+namespace adayolo {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+
+__device__ __forceinline__ unsigned short f2bf(float f) {
+    unsigned u = __float_as_uint(f);
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+}
+__device__ __forceinline__ unsigned pack2(float lo, float hi) { return (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16); }
+__device__ __forceinline__ float bf2f(unsigned short h) { return __uint_as_float(((unsigned)h) << 16); }
+__device__ __forceinline__ float silu(float x) {
+    return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504088896341f * x));
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Stem: letterbox + Conv(3->32, k3 s1 p1) + SiLU, planar fp32 in, NHWC bf16 out.
+// K = 27 taps*channels padded to 32 = ONE v_mfma_f32_16x16x32_bf16 step. Weights (the MFMA A operand) sit
+// in registers for the whole kernel; the activation fragment of 16 neighbouring pixels is gathered from
+// an fp32 LDS tile. The MFMA row -> channel map is permuted (row 4g+i of tile t = channel 8g+4t+i) so that
+// each lane ends up with 8 CONSECUTIVE channels of its pixel and stores them as one 16-byte vector.
+// ---------------------------------------------------------------------------------------------------
+constexpr int S_TW = 64, S_TH = 16, S_LW = S_TW + 2, S_LH = S_TH + 2;
+
+__global__ __launch_bounds__(256) void k_stem(const float* __restrict__ img, const float* __restrict__ w,
+                                              const float* __restrict__ bias, unsigned short* __restrict__ out,
+                                              int out_cs, int H, int W, int Hp, int pad_top, float pad_value) {
+    __shared__ float tile[3 * S_LH * S_LW];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.z, x0 = blockIdx.x * S_TW, y0 = blockIdx.y * S_TH;
+    const long plane = (long)H * W;
+    const float* src = img + (long)b * 3 * plane;
+    for (int i = tid; i < 3 * S_LH * S_LW; i += 256) {
+        const int c = i / (S_LH * S_LW), r = i - c * (S_LH * S_LW);
+        const int ly = r / S_LW, lx = r - ly * S_LW;
+        const int gy = y0 - 1 + ly, gx = x0 - 1 + lx;
+        float v = 0.0f;                                   // conv zero padding outside the letterboxed frame
+        if (gy >= 0 && gy < Hp && gx >= 0 && gx < W) {
+            const int sy = gy - pad_top;
+            v = (sy >= 0 && sy < H) ? src[c * plane + (long)sy * W + gx] : pad_value;
+        }
+        tile[i] = v;
+    }
+    const int g = lane >> 4, p = lane & 15;
+    // weight fragments: tile t, MFMA row j = lane&15 -> channel 8*(j>>2) + 4t + (j&3); k = 8g + e
+    bf16x8 wf[2];
+    int off[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int k = 8 * g + e;
+        const int tap = k / 3, c = k - tap * 3, kh = tap / 3, kw = tap - kh * 3;
+        off[e] = (k < 27) ? (c * S_LH + kh) * S_LW + kw : 0;
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int ch = 8 * (p >> 2) + 4 * t + (p & 3);
+        unsigned short h[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int k = 8 * g + e;
+            h[e] = (k < 27) ? f2bf(w[ch * 27 + k]) : (unsigned short)0;
+        }
+        u32x4 pk = {(unsigned)h[0] | ((unsigned)h[1] << 16), (unsigned)h[2] | ((unsigned)h[3] << 16),
+                    (unsigned)h[4] | ((unsigned)h[5] << 16), (unsigned)h[6] | ((unsigned)h[7] << 16)};
+        wf[t] = __builtin_bit_cast(bf16x8, pk);
+    }
+    float bv[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) bv[i] = bias[8 * g + i];
+    __syncthreads();
+
+    // each wave: 4 rows x 64 cols = 16 groups of 16 pixels
+    for (int grp = 0; grp < 16; ++grp) {
+        const int ly = wave * 4 + (grp >> 2), lx = (grp & 3) * 16 + p;
+        const int gy = y0 + ly, gx = x0 + lx;
+        const float* t0 = tile + ly * S_LW + lx;
+        float a[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) a[e] = t0[off[e]];
+        u32x4 pk = {pack2(a[0], a[1]), pack2(a[2], a[3]), pack2(a[4], a[5]), pack2(a[6], a[7])};
+        const bf16x8 af = __builtin_bit_cast(bf16x8, pk);
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        const f32x4 d0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[0], af, z, 0, 0, 0);
+        const f32x4 d1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[1], af, z, 0, 0, 0);
+        if (gy < Hp && gx < W) {
+            float v[8];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { v[i] = silu(d0[i] + bv[i]); v[4 + i] = silu(d1[i] + bv[4 + i]); }
+            u32x4 o = {pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7])};
+            *reinterpret_cast<u32x4*>(out + (((long)b * Hp + gy) * W + gx) * out_cs + 8 * g) = o;
+        }
+    }
+}
+
+hipError_t launch_stem(const float* img, const float* w, const float* bias, void* out, int out_cs, int B, int H,
+                       int W, int Hp, int pad_top, float pad_value, hipStream_t s) {
+    dim3 grid((W + S_TW - 1) / S_TW, (Hp + S_TH - 1) / S_TH, B);
+    hipLaunchKernelGGL(k_stem, grid, dim3(256), 0, s, img, w, bias, static_cast<unsigned short*>(out), out_cs, H, W,
+                       Hp, pad_top, pad_value);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Nearest 2x up-sampling into a channel slice of the concat buffer (nn.Upsample + Concat).
+// One lane moves one 16-byte channel chunk of an input pixel to its 4 output pixels.
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_upsample2x(const unsigned short* __restrict__ in, int in_cs,
+                                                    unsigned short* __restrict__ out, int out_cs, int B, int H, int W,
+                                                    int C) {
+    const int cpp = C / 8;
+    const long total = (long)B * H * W * cpp;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int ch = (int)(i % cpp) * 8;
+        const long pix = i / cpp;
+        const int x = (int)(pix % W);
+        const long by = pix / W;             // b*H + y
+        const int y = (int)(by % H);
+        const long b = by / H;
+        const u32x4 v = *reinterpret_cast<const u32x4*>(in + pix * in_cs + ch);
+        unsigned short* o = out + ((b * 2 * H + 2 * y) * (2L * W) + 2 * x) * out_cs + ch;
+        *reinterpret_cast<u32x4*>(o) = v;
+        *reinterpret_cast<u32x4*>(o + out_cs) = v;
+        *reinterpret_cast<u32x4*>(o + 2L * W * out_cs) = v;
+        *reinterpret_cast<u32x4*>(o + (2L * W + 1) * out_cs) = v;
+    }
+}
+
+hipError_t launch_upsample2x(const void* in, int in_cs, void* out, int out_cs, int B, int H, int W, int C,
+                             hipStream_t s) {
+    const long total = (long)B * H * W * (C / 8);
+    long blocks = (total + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(k_upsample2x, dim3((unsigned)blocks), dim3(256), 0, s, static_cast<const unsigned short*>(in),
+                       in_cs, static_cast<unsigned short*>(out), out_cs, B, H, W, C);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Detect decode (eval branch of Detect.forward, yolov3/models/yolo.py:56-76).
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_detect_decode(const unsigned short* __restrict__ raw, int raw_cs,
+                                                       float* __restrict__ pred, int pred_rows, int row_offset,
+                                                       const float* __restrict__ anchors_px, float det_stride, int B,
+                                                       int ny, int nx, int na, int no) {
+    const long total = (long)B * na * ny * nx * no;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int j = (int)(i % no);
+        long c = i / no;
+        const int x = (int)(c % nx); c /= nx;
+        const int y = (int)(c % ny); c /= ny;
+        const int an = (int)(c % na);
+        const long b = c / na;
+        const float t = bf2f(raw[((b * ny + y) * nx + x) * raw_cs + an * no + j]);
+        const float s = 1.0f / (1.0f + expf(-t));
+        float v = s;
+        if (j == 0) v = (s * 2.0f + ((float)x - 0.5f)) * det_stride;
+        else if (j == 1) v = (s * 2.0f + ((float)y - 0.5f)) * det_stride;
+        else if (j == 2) v = (s * 2.0f) * (s * 2.0f) * anchors_px[2 * an];
+        else if (j == 3) v = (s * 2.0f) * (s * 2.0f) * anchors_px[2 * an + 1];
+        pred[(b * pred_rows + row_offset + ((long)an * ny + y) * nx + x) * no + j] = v;
+    }
+}
+
+hipError_t launch_detect_decode(const void* raw, int raw_cs, float* pred, int pred_rows, int row_offset,
+                                const float* anchors_px, float det_stride, int B, int ny, int nx, int na, int no,
+                                hipStream_t s) {
+    const long total = (long)B * na * ny * nx * no;
+    long blocks = (total + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(k_detect_decode, dim3((unsigned)blocks), dim3(256), 0, s,
+                       static_cast<const unsigned short*>(raw), raw_cs, pred, pred_rows, row_offset, anchors_px,
+                       det_stride, B, ny, nx, na, no);
+    return hipGetLastError();
+}
+
+}  // namespace adayolo

@@ -1,0 +1,50 @@
+"""ctypes binding of csrc/libadayolo.so (C-ABI in include/adayolo.h). No eager/CPU fallback."""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB_PATH = os.path.join(_HERE, "csrc", "libadayolo.so")
+ABI_VERSION = 1
+ACT_NONE, ACT_SILU = 0, 1
+EXPORTS = ("adayolo_conv_fwd", "adayolo_stem_fwd", "adayolo_upsample2x", "adayolo_detect_decode", "adayolo_strerror",
+           "adayolo_abi_version")
+_lib = None
+
+
+class AdayoloError(RuntimeError):
+    pass
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise AdayoloError(f"{LIB_PATH} not found: run __graft_entry__.build() (hipcc --offload-arch=gfx950); "
+                           "the detector has no eager fallback")
+    L = ctypes.CDLL(LIB_PATH)
+    vp, ci, cf = ctypes.c_void_p, ctypes.c_int, ctypes.c_float
+    L.adayolo_conv_fwd.argtypes = [vp, ci, vp, vp, vp, ci, vp, ci, ci, ci, ci, ci, ci, ci, ci, ci, vp]
+    L.adayolo_stem_fwd.argtypes = [vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, cf, ci, vp]
+    L.adayolo_upsample2x.argtypes = [vp, ci, vp, ci, ci, ci, ci, ci, vp]
+    L.adayolo_detect_decode.argtypes = [vp, ci, vp, ci, ci, vp, cf, ci, ci, ci, ci, ci, vp]
+    L.adayolo_strerror.argtypes = [ci]
+    L.adayolo_strerror.restype = ctypes.c_char_p
+    for n in ("adayolo_conv_fwd", "adayolo_stem_fwd", "adayolo_upsample2x", "adayolo_detect_decode",
+              "adayolo_abi_version"):
+        getattr(L, n).restype = ci
+    if L.adayolo_abi_version() != ABI_VERSION:
+        raise AdayoloError("libadayolo.so ABI mismatch: rebuild")
+    _lib = L
+    return L
+
+
+def check(rc, what):
+    if rc != 0:
+        raise AdayoloError(f"{what} failed: {load().adayolo_strerror(rc).decode()} ({rc})")
+
+
+def stream_ptr():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)

@@ -1,0 +1,207 @@
+"""HIP/MFMA execution engine for the YOLOv3 reward-model forward.
+
+Built once per (model, batch, resolution): folds every BatchNorm into its conv, lays the weights out as
+bf16 [Cout][KH][KW][Cin], allocates every activation as an NHWC bf16 tensor and records a flat launch
+plan of C-ABI calls (include/adayolo.h). What the reference does with ~250 ATen launches per forward
+(conv, BN, SiLU, add, upsample, cat, permute, sigmoid...) becomes ~80 launches, each conv carrying its
+bias + SiLU + residual epilogue:
+
+  * stem: reads the ISP output directly (planar fp32), letterboxes to a multiple of 32 rows and applies
+    Conv(3->32)+SiLU in one kernel — no separate pad / layout / dtype pass;
+  * Concat is free: the two producers write straight into channel slices of the concatenated tensor
+    (the convs take channel strides), Upsample is a scatter into its slice;
+  * Detect: 1x1 conv to 255(+1 pad) channels, then one decode kernel writes the [B, N, 85] fp32 prediction.
+
+There is no eager fallback: without libadayolo.so / a HIP device this raises.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from .model import Bottleneck, Concat, Conv, Detect, DetectionModel
+
+LETTERBOX_VALUE = 114.0 / 255.0     # yolov3/utils/augmentations.py:111 (color=(114,114,114)) on a [0,1] image
+
+
+class _View:
+    """A channel slice [coff, coff+C) of an NHWC bf16 buffer [B,H,W,CS]."""
+
+    def __init__(self, buf, coff, C):
+        self.buf, self.coff, self.C = buf, coff, C
+        self.H, self.W, self.cs = buf.shape[1], buf.shape[2], buf.shape[3]
+
+    @property
+    def ptr(self):
+        return self.buf.data_ptr() + 2 * self.coff
+
+    def tensor(self):
+        return self.buf[..., self.coff:self.coff + self.C]
+
+
+def _pack_conv(w, b, pad_cout_to=None):
+    """[Cout,Cin,k,k] fp32 -> bf16 [Cout,k,k,Cin] contiguous (+ fp32 bias); optional zero rows up to pad_cout_to."""
+    w = w.detach().float().permute(0, 2, 3, 1).contiguous()
+    b = b.detach().float().contiguous()
+    if pad_cout_to is not None and w.shape[0] < pad_cout_to:
+        extra = pad_cout_to - w.shape[0]
+        w = torch.cat([w, w.new_zeros((extra,) + tuple(w.shape[1:]))], 0)
+        b = torch.cat([b, b.new_zeros(extra)], 0)
+    return w.to(torch.bfloat16).contiguous(), b
+
+
+class YoloEngine:
+    def __init__(self, model: DetectionModel, batch, height, width, device="cuda:0"):
+        if width % 32:
+            raise ValueError(f"image width {width} must be a multiple of 32 (reference: check_img_size)")
+        self.L = _lib.load()
+        self.dev = torch.device(device)
+        if self.dev.type != "cuda":
+            raise _lib.AdayoloError("YoloEngine needs a HIP device; there is no CPU path")
+        self.B, self.H, self.W = int(batch), int(height), int(width)
+        self.Hp = (self.H + 31) // 32 * 32
+        self.pad_top = (self.Hp - self.H) // 2
+        det = model.model[-1]
+        self.na, self.no, self.nc = det.na, det.no, det.nc
+        self._keep = []          # tensors referenced by raw pointers in the plan
+        self.plan = []
+        self._build(model)
+
+    # ------------------------------------------------------------------------------------------
+    def _new(self, H, W, C):
+        t = torch.empty((self.B, H, W, C), dtype=torch.bfloat16, device=self.dev)
+        self._keep.append(t)
+        return t
+
+    def _conv_op(self, src, conv_w, conv_b, dst, k, s, act, res=None, cout=None):
+        w, b = conv_w.to(self.dev), conv_b.to(self.dev)
+        self._keep += [w, b]
+        cout = cout if cout is not None else w.shape[0]
+        args = (ctypes.c_void_p(src.ptr), src.cs, ctypes.c_void_p(w.data_ptr()), ctypes.c_void_p(b.data_ptr()),
+                ctypes.c_void_p(res.ptr) if res is not None else None, res.cs if res is not None else 0,
+                ctypes.c_void_p(dst.ptr), dst.cs, self.B, src.H, src.W, src.C, cout, k, s, act)
+        self.plan.append(("conv", self.L.adayolo_conv_fwd, args))
+        flops = 2.0 * self.B * dst.H * dst.W * cout * k * k * src.C
+        self.flops += flops
+
+    def _build(self, model):
+        self.flops = 0.0
+        layers = list(model.model)
+        # pass 1: shapes (C,H,W) of every layer output
+        shp = []
+        for i, m in enumerate(layers):
+            prev = (3, self.Hp, self.W) if i == 0 else (shp[_src(i, m.f)] if isinstance(m.f, int) else None)
+            if isinstance(m, Conv):
+                s = m.conv.stride[0]
+                shp.append((m.conv.out_channels, (prev[1] - 1) // s + 1, (prev[2] - 1) // s + 1))
+            elif isinstance(m, (Bottleneck, torch.nn.Sequential)):
+                last = m if isinstance(m, Bottleneck) else m[-1]
+                shp.append((last.cv2.conv.out_channels, prev[1], prev[2]))
+            elif isinstance(m, torch.nn.Upsample):
+                shp.append((prev[0], prev[1] * 2, prev[2] * 2))
+            elif isinstance(m, Concat):
+                srcs = [shp[_src(i, j)] for j in m.f]
+                shp.append((sum(s[0] for s in srcs), srcs[0][1], srcs[0][2]))
+            elif isinstance(m, Detect):
+                shp.append(None)
+        # pass 2: output views; concat sources write into slices of the concat tensor
+        view = [None] * len(layers)
+        for i, m in enumerate(layers):
+            if isinstance(m, Concat):
+                C, H, W = shp[i]
+                buf = self._new(H, W, C)
+                view[i] = _View(buf, 0, C)
+                off = 0
+                for j in m.f:
+                    src = _src(i, j)
+                    view[src] = _View(buf, off, shp[src][0])
+                    off += shp[src][0]
+        for i, m in enumerate(layers):
+            if view[i] is None and shp[i] is not None:
+                C, H, W = shp[i]
+                view[i] = _View(self._new(H, W, C), 0, C)
+        # pass 3: launch plan
+        for i, m in enumerate(layers):
+            src = view[_src(i, m.f)] if (i > 0 and isinstance(m.f, int)) else None
+            if i == 0:
+                w, b = m.folded()
+                w = w.detach().float().permute(0, 2, 3, 1).contiguous().to(self.dev)      # [32][3][3][3] fp32
+                b = b.detach().float().contiguous().to(self.dev)
+                self._keep += [w, b]
+                self._stem = (w, b, view[0])
+                self.plan.append(("stem", None, None))
+                self.flops += 2.0 * self.B * self.Hp * self.W * 32 * 27
+            elif isinstance(m, Conv):
+                w, b = _pack_conv(*m.folded())
+                self._conv_op(src, w, b, view[i], m.conv.kernel_size[0], m.conv.stride[0], _lib.ACT_SILU)
+            elif isinstance(m, (Bottleneck, torch.nn.Sequential)):
+                blocks = [m] if isinstance(m, Bottleneck) else list(m)
+                cur = src
+                for bi, blk in enumerate(blocks):
+                    hidden = _View(self._new(cur.H, cur.W, blk.cv1.conv.out_channels), 0, blk.cv1.conv.out_channels)
+                    out = view[i] if bi == len(blocks) - 1 else \
+                        _View(self._new(cur.H, cur.W, blk.cv2.conv.out_channels), 0, blk.cv2.conv.out_channels)
+                    w1, b1 = _pack_conv(*blk.cv1.folded())
+                    w2, b2 = _pack_conv(*blk.cv2.folded())
+                    self._conv_op(cur, w1, b1, hidden, 1, 1, _lib.ACT_SILU)
+                    self._conv_op(hidden, w2, b2, out, 3, 1, _lib.ACT_SILU, res=cur if blk.add else None)
+                    cur = out
+            elif isinstance(m, torch.nn.Upsample):
+                args = (ctypes.c_void_p(src.ptr), src.cs, ctypes.c_void_p(view[i].ptr), view[i].cs, self.B, src.H,
+                        src.W, src.C)
+                self.plan.append(("up", self.L.adayolo_upsample2x, args))
+            elif isinstance(m, Detect):
+                ins = [view[j] for j in m.f]
+                self.rows = sum(self.na * v.H * v.W for v in ins)
+                self.pred = torch.empty((self.B, self.rows, self.no), dtype=torch.float32, device=self.dev)
+                self.raw = []
+                row = 0
+                cpad = (self.na * self.no + 7) // 8 * 8
+                for li, v in enumerate(ins):
+                    raw = _View(self._new(v.H, v.W, cpad), 0, cpad)
+                    w, b = _pack_conv(m.m[li].weight, m.m[li].bias, pad_cout_to=cpad)
+                    self._conv_op(v, w, b, raw, 1, 1, _lib.ACT_NONE, cout=cpad)
+                    anc = (m.anchors[li].float() * float(m.stride[li])).contiguous().to(self.dev)
+                    self._keep.append(anc)
+                    args = (ctypes.c_void_p(raw.ptr), raw.cs, ctypes.c_void_p(self.pred.data_ptr()), self.rows, row,
+                            ctypes.c_void_p(anc.data_ptr()), float(m.stride[li]), self.B, v.H, v.W, self.na, self.no)
+                    self.plan.append(("decode", self.L.adayolo_detect_decode, args))
+                    self.raw.append(raw)
+                    row += self.na * v.H * v.W
+        self.views = view
+
+    # ------------------------------------------------------------------------------------------
+    def forward(self, img):
+        """img: planar fp32 [B,3,H,W] in [0,1] on the engine's device -> pred fp32 [B, N, 85] (eval decode)."""
+        if img.shape != (self.B, 3, self.H, self.W) or img.dtype != torch.float32 or img.device != self.dev:
+            raise ValueError(f"expected fp32 {(self.B, 3, self.H, self.W)} on {self.dev}, got {img.dtype} "
+                             f"{tuple(img.shape)} on {img.device}")
+        img = img.contiguous()
+        with torch.cuda.device(self.dev):
+            st = _lib.stream_ptr()
+            for kind, fn, args in self.plan:
+                if kind == "stem":
+                    w, b, out = self._stem
+                    rc = self.L.adayolo_stem_fwd(ctypes.c_void_p(img.data_ptr()), ctypes.c_void_p(w.data_ptr()),
+                                                 ctypes.c_void_p(b.data_ptr()), ctypes.c_void_p(out.ptr), out.cs,
+                                                 self.B, self.H, self.W, self.Hp, self.pad_top, LETTERBOX_VALUE, 32, st)
+                else:
+                    rc = fn(*args, st)
+                if rc != 0:
+                    _lib.check(rc, f"adayolo {kind}")
+        return self.pred
+
+    __call__ = forward
+
+    def raw_maps(self):
+        """Training-style outputs [B, na, ny, nx, no] (fp32 copies of the raw head maps)."""
+        outs = []
+        for v in self.raw:
+            t = v.buf[..., : self.na * self.no].float()
+            outs.append(t.view(self.B, v.H, v.W, self.na, self.no).permute(0, 3, 1, 2, 4).contiguous())
+        return outs
+
+
+def _src(i, f):
+    """Absolute index of the layer that feeds layer i through the (possibly relative) reference `from` field."""
+    return i + f if f < 0 else f

@@ -1,0 +1,81 @@
+/*
+ * adayolo.h — C-ABI of the MI355X-native YOLOv3 reward-model forward (libadayolo.so).
+ *
+ * Replaces, for the detector half of the hot path, the reference's PyTorch modules
+ *   Conv       = SiLU(BN(conv2d(x)))            yolov3/models/common.py:45-59   (BN folded: forward_fuse :58-59,
+ *                                                yolov3/utils/torch_utils.py:248-269)
+ *   Bottleneck = x + cv2(cv1(x))                 yolov3/models/common.py:110-120
+ *   nn.Upsample(2,'nearest') + Concat            yolov3/models/yolov3.yaml:34-36,41-43, common.py:305-312
+ *   Detect (eval decode)                         yolov3/models/yolo.py:56-76
+ * The reference has no FFI here either; these entry points are what a binding of those modules calls.
+ *
+ * Conventions: DEVICE pointers, caller-owned. Activations are NHWC bf16 ("pixel-major"): element
+ * (b,y,x,c) of a tensor with channel stride `cs` lives at ((b*H + y)*W + x)*cs + c — `cs` may exceed the
+ * channel count so that a conv can read or write a channel slice of a wider (concatenated) tensor.
+ * Weights are bf16 [Cout][KH][KW][Cin] (BN folded in), bias fp32 [Cout]. Channel counts and strides are
+ * multiples of 8 (16-byte vectors). All calls enqueue on `stream`, never allocate or synchronise.
+ * Return 0 on success, negative on error (adayolo_strerror).
+ */
+#ifndef ADAYOLO_H_
+#define ADAYOLO_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ADAYOLO_ABI_VERSION 1
+
+#define ADAYOLO_ACT_NONE 0
+#define ADAYOLO_ACT_SILU 1
+
+#define ADAYOLO_OK       0
+#define ADAYOLO_EINVAL  -1
+#define ADAYOLO_ESHAPE  -2
+#define ADAYOLO_ELAUNCH -3
+
+/*
+ * out[b,ho,wo,co] = act( bias[co] + sum_{kh,kw,ci} in[b, ho*stride-pad+kh, wo*stride-pad+kw, ci] * w[co,kh,kw,ci] )
+ *                   (+ residual[b,ho,wo,co] if residual != NULL, added AFTER the activation: Bottleneck shortcut)
+ * Implicit GEMM on the bf16 matrix cores (v_mfma_f32_16x16x32_bf16), fp32 accumulate, fused epilogue.
+ * ksize in {1,3}; pad = ksize/2; stride in {1,2}. Ho = (H + 2*pad - ksize)/stride + 1 (same for Wo).
+ */
+int adayolo_conv_fwd(const void* in, int in_cstride,
+                     const void* weight, const float* bias,
+                     const void* residual, int res_cstride,
+                     void* out, int out_cstride,
+                     int B, int H, int W, int Cin, int Cout,
+                     int ksize, int stride, int act, void* stream);
+
+/*
+ * Detector stem fused with the ISP->detector hand-over: reads the ISP output as planar fp32
+ * [B,3,H,W] (values in [0,1]), letterboxes it vertically to Hp rows (pad_top rows of `pad_value` above,
+ * the rest below: yolov3/utils/augmentations.py:111-141 uses 114/255), and applies the first
+ * Conv(3->Cout, k3 s1) + SiLU, writing NHWC bf16 [B,Hp,W,Cout]. weight is fp32 [Cout][3][3][3]
+ * (co,kh,kw,ci), bias fp32.
+ */
+int adayolo_stem_fwd(const float* img, const float* weight, const float* bias, void* out, int out_cstride,
+                     int B, int H, int W, int Hp, int pad_top, float pad_value, int Cout, void* stream);
+
+/* Nearest 2x up-sampling of in[B,H,W,C] into a channel slice of out[B,2H,2W,*] (Upsample + Concat). */
+int adayolo_upsample2x(const void* in, int in_cstride, void* out, int out_cstride,
+                       int B, int H, int W, int C, void* stream);
+
+/*
+ * Detect head decode (eval): raw[b,y,x, a*no + j] (NHWC bf16, channel stride raw_cstride, na*no valid
+ * channels) -> pred[b, row_offset + (a*ny + y)*nx + x, j] fp32 with
+ *   s = sigmoid(raw); xy = (2 s - 0.5 + grid) * det_stride; wh = (2 s)^2 * anchor_px; others = s.
+ * anchors_px: fp32 [na][2] (pixel units). pred has `pred_rows` rows of `no` floats per image.
+ */
+int adayolo_detect_decode(const void* raw, int raw_cstride, float* pred, int pred_rows, int row_offset,
+                          const float* anchors_px, float det_stride,
+                          int B, int ny, int nx, int na, int no, void* stream);
+
+const char* adayolo_strerror(int code);
+int adayolo_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ADAYOLO_H_ */

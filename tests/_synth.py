@@ -7,7 +7,7 @@ import numpy as np
 import torch
 
 
-def synth_tensor(key, shape, dtype, seed=0):
+def synth_tensor(key, shape, dtype, seed=0, gain=1.4):
     rng = np.random.default_rng([seed, zlib.crc32(key.encode())])
     shape = tuple(shape)
     if key.endswith("num_batches_tracked"):
@@ -18,7 +18,7 @@ def synth_tensor(key, shape, dtype, seed=0):
         a = rng.normal(0.0, 0.1, shape)
     elif len(shape) >= 2:                      # conv / linear weight
         fan_in = int(np.prod(shape[1:]))
-        a = rng.normal(0.0, 1.0, shape) * (1.4 / np.sqrt(fan_in))
+        a = rng.normal(0.0, 1.0, shape) * (gain / np.sqrt(fan_in))
     elif key.endswith("weight"):               # batch-norm scale
         a = rng.uniform(0.8, 1.2, shape)
     else:                                      # biases
@@ -26,8 +26,15 @@ def synth_tensor(key, shape, dtype, seed=0):
     return torch.from_numpy(np.asarray(a, dtype=np.float32)).to(dtype)
 
 
-def synth_state_dict(module, seed=0):
-    return {k: synth_tensor(k, v.shape, v.dtype, seed) for k, v in module.state_dict().items()}
+def synth_state_dict(module, seed=0, gain=1.4):
+    return {k: synth_tensor(k, v.shape, v.dtype, seed, gain) for k, v in module.state_dict().items()}
+
+
+def synth_yolo_state_dict(model, seed=2):
+    """Detector weights: unit gain keeps the logits O(1) through the 75 conv layers; real anchors kept."""
+    sd = synth_state_dict(model, seed=seed, gain=1.0)
+    sd["model.28.anchors"] = model.state_dict()["model.28.anchors"].clone()
+    return sd
 
 
 def test_image(B, H, W, seed, special=True):

@@ -19,7 +19,7 @@ import torch
 sys.dont_write_bytecode = True
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(HERE))
-from _synth import synth_state_dict, test_image  # noqa: E402
+from _synth import synth_state_dict, synth_yolo_state_dict, test_image  # noqa: E402
 
 
 def _stub(name, **attrs):
@@ -44,6 +44,59 @@ def import_reference(root="/root/reference"):
     import agent
     import value
     return filters, cfg, agent, value
+
+
+class _AnyObj:
+    def __init__(self, *a, **k): pass
+    def __call__(self, *a, **k): return _AnyObj()
+    def __getattr__(self, n):
+        if n.startswith("__"):
+            raise AttributeError(n)
+        return _AnyObj()
+    def __mro_entries__(self, bases): return (object,)
+
+
+class _AnyModule(types.ModuleType):
+    def __getattr__(self, name):
+        if name.startswith("__"):
+            raise AttributeError(name)
+        return _AnyObj()
+
+
+def import_reference_yolo(root="/root/reference/yolov3"):
+    """The detector subtree imports plotting / dataset / export helpers at module scope; none of them is
+    on the forward path, so absent packages become permissive stubs."""
+    for n in ["cv2", "seaborn", "thop", "ultralytics", "ultralytics.utils", "ultralytics.utils.plotting",
+              "ultralytics.utils.checks", "torchvision", "torchvision.ops", "torchvision.datasets",
+              "torchvision.transforms", "torchvision.transforms.functional", "IPython", "IPython.display"]:
+        m = _AnyModule(n)
+        m.__path__ = []
+        sys.modules[n] = m
+    for n in [k for k in sys.modules if k == "utils" or k.startswith("utils.") or k == "models" or k.startswith("models.")]:
+        del sys.modules[n]
+    sys.path.insert(0, root)
+    from models.yolo import Model
+    return Model
+
+
+def gen_yolo():
+    import io, contextlib, json
+    Model = import_reference_yolo()
+    with contextlib.redirect_stdout(io.StringIO()), contextlib.redirect_stderr(io.StringIO()):
+        m = Model("/root/reference/yolov3/models/yolov3.yaml", ch=3, nc=80)
+    m.load_state_dict(synth_yolo_state_dict(m, seed=2))
+    m.eval()
+    x = test_image(1, 64, 96, seed=51, special=False)
+    with torch.no_grad():
+        pred, raws = m(torch.from_numpy(x))
+    out = {"x": x, "pred": pred.numpy()}
+    for i, r in enumerate(raws):
+        out[f"raw{i}"] = r.numpy()
+    np.savez_compressed(os.path.join(HERE, "yolo.npz"), **out)
+    p = os.path.join(HERE, "state_dict_keys.json")
+    keys = json.load(open(p))
+    keys["yolo"] = {k: list(v.shape) for k, v in m.state_dict().items()}
+    json.dump(keys, open(p, "w"), indent=0)
 
 
 def main():
@@ -171,6 +224,7 @@ def main():
     out["one_hot"] = agent_mod.one_hot(10, idx.to(torch.int64)).numpy()
     np.savez_compressed(os.path.join(HERE, "select.npz"), **out)
 
+    gen_yolo()
     tot = sum(os.path.getsize(os.path.join(HERE, f)) for f in os.listdir(HERE) if f.endswith(".npz"))
     print("fixtures written, total bytes:", tot)
 

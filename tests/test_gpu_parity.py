@@ -147,7 +147,7 @@ def test_fullsize_identities():
     eye = torch.eye(3, device=dev()).reshape(1, 9).repeat(B, 1)
     assert torch.equal(_lib.process(OPS["CCM"], x, eye * 2.0), x)              # rows are re-normalised
     assert torch.equal(_lib.process(OPS["E"], x, one * 0.0), x)
-    assert torch.equal(_lib.process(OPS["G"], x.clamp_min(0.001), one), x.clamp_min(0.001))
+    torch.testing.assert_close(_lib.process(OPS["G"], x, one), x.clamp_min(0.001), rtol=1e-6, atol=0)   # gamma 1
     assert torch.equal(_lib.process(OPS["BW"], x, one * 0.0), x)
     assert torch.equal(_lib.process(OPS["Sp"], x, one * 0.0), x)
     assert torch.equal(_lib.process(OPS["Shr"], x, one), x)                      # factor 1 keeps the image

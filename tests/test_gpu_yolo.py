@@ -1,0 +1,138 @@
+"""Detector kernels (implicit-GEMM conv on bf16 MFMA, fused stem, upsample, decode) against plain PyTorch
+fp32 on the same bf16-rounded operands, and the whole engine against the reference's golden output."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _conv_hip(x_nhwc, w, b, k, s, act, res=None, out=None, cout=None):
+    from adaptiveisp_amd.yolo import _lib
+    L = _lib.load()
+    B, H, W, _ = x_nhwc.shape
+    cin = w.shape[-1]
+    cout = cout or w.shape[0]
+    Ho, Wo = (H + 2 * (k // 2) - k) // s + 1, (W + 2 * (k // 2) - k) // s + 1
+    if out is None:
+        out = torch.zeros(B, Ho, Wo, cout, dtype=torch.bfloat16, device=DEV)
+    rc = L.adayolo_conv_fwd(ctypes.c_void_p(x_nhwc.data_ptr()), x_nhwc.stride(2), ctypes.c_void_p(w.data_ptr()),
+                            ctypes.c_void_p(b.data_ptr()), ctypes.c_void_p(res.data_ptr()) if res is not None else None,
+                            res.stride(2) if res is not None else 0, ctypes.c_void_p(out.data_ptr()), out.stride(2),
+                            B, H, W, cin, cout, k, s, act, _lib.stream_ptr())
+    _lib.check(rc, "conv")
+    torch.cuda.synchronize()
+    return out
+
+
+CASES = [  # B, H, W, Cin, Cout, k, s, residual
+    (2, 16, 24, 32, 64, 3, 2, False), (1, 23, 40, 64, 32, 1, 1, False), (2, 12, 20, 32, 64, 3, 1, True),
+    (1, 19, 33, 128, 256, 3, 1, True), (3, 9, 11, 768, 256, 1, 1, False), (1, 46, 80, 256, 128, 1, 1, False),
+    (1, 8, 12, 1024, 256, 1, 1, False), (2, 7, 5, 8, 32, 3, 1, False), (1, 30, 30, 64, 128, 3, 2, False),
+    (1, 5, 6, 512, 1024, 3, 1, True),
+]
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_conv_vs_torch(case):
+    B, H, W, Cin, Cout, k, s, use_res = case
+    g = torch.Generator(device="cpu").manual_seed(hash(case) % 2 ** 31)
+    x = (torch.randn(B, H, W, Cin, generator=g)).to(torch.bfloat16).to(DEV)
+    w = (torch.randn(Cout, k, k, Cin, generator=g) / (k * k * Cin) ** 0.5).to(torch.bfloat16).to(DEV)
+    b = torch.randn(Cout, generator=g).to(DEV)
+    Ho, Wo = (H - 1) // s + 1, (W - 1) // s + 1
+    res = torch.randn(B, Ho, Wo, Cout, generator=g).to(torch.bfloat16).to(DEV) if use_res else None
+    for act in (0, 1):
+        out = _conv_hip(x, w, b, k, s, act, res)
+        ref = F.conv2d(x.float().permute(0, 3, 1, 2), w.float().permute(0, 3, 1, 2), b, stride=s, padding=k // 2)
+        if act:
+            ref = F.silu(ref)
+        ref = ref.permute(0, 2, 3, 1)
+        if use_res:
+            ref = ref.to(torch.bfloat16).float() + res.float()
+        err = (out.float() - ref).abs().max().item()
+        assert err <= 2e-2 * max(1.0, ref.abs().max().item()), f"{case} act={act}: {err}"
+
+
+def test_conv_channel_slices():
+    """Reading and writing channel slices of wider tensors (how Concat is made free)."""
+    g = torch.Generator(device="cpu").manual_seed(5)
+    wide_in = torch.randn(1, 10, 14, 96, generator=g).to(torch.bfloat16).to(DEV)
+    wide_out = torch.full((1, 10, 14, 160), 7.0, dtype=torch.bfloat16, device=DEV)
+    w = (torch.randn(64, 3, 3, 32, generator=g) / 17).to(torch.bfloat16).to(DEV)
+    b = torch.zeros(64, device=DEV)
+    xin, xout = wide_in[..., 32:64], wide_out[..., 64:128]
+    _conv_hip(xin, w, b, 3, 1, 1, out=xout)
+    ref = F.silu(F.conv2d(xin.float().permute(0, 3, 1, 2), w.float().permute(0, 3, 1, 2), b, padding=1)).permute(0, 2, 3, 1)
+    assert (xout.float() - ref).abs().max().item() < 2e-2
+    assert (wide_out[..., :64] == 7).all() and (wide_out[..., 128:] == 7).all()       # neighbours untouched
+
+
+def test_stem_upsample_decode():
+    from adaptiveisp_amd.yolo import _lib
+    L = _lib.load()
+    g = torch.Generator(device="cpu").manual_seed(6)
+    B, H, W, Hp, top = 2, 40, 96, 64, 12
+    img = torch.rand(B, 3, H, W, generator=g).to(DEV)
+    w = (torch.randn(32, 3, 3, 3, generator=g) / 5).to(DEV)          # (co,kh,kw,ci)
+    b = torch.randn(32, generator=g).to(DEV)
+    out = torch.zeros(B, Hp, W, 32, dtype=torch.bfloat16, device=DEV)
+    _lib.check(L.adayolo_stem_fwd(ctypes.c_void_p(img.data_ptr()), ctypes.c_void_p(w.data_ptr()),
+                                  ctypes.c_void_p(b.data_ptr()), ctypes.c_void_p(out.data_ptr()), 32, B, H, W, Hp, top,
+                                  114 / 255, 32, _lib.stream_ptr()), "stem")
+    boxed = torch.full((B, 3, Hp, W), 114 / 255, device=DEV)
+    boxed[:, :, top:top + H] = img
+    ref = F.silu(F.conv2d(boxed.to(torch.bfloat16).float(), w.to(torch.bfloat16).float().permute(0, 3, 1, 2), b,
+                          padding=1)).permute(0, 2, 3, 1)
+    assert (out.float() - ref).abs().max().item() < 2e-2 * max(1.0, ref.abs().max().item())
+    # upsample into a slice
+    x = torch.randn(B, 5, 7, 16, generator=g).to(torch.bfloat16).to(DEV)
+    dst = torch.zeros(B, 10, 14, 40, dtype=torch.bfloat16, device=DEV)
+    _lib.check(L.adayolo_upsample2x(ctypes.c_void_p(x.data_ptr()), 16, ctypes.c_void_p(dst[..., 8:].data_ptr()), 40, B, 5,
+                                    7, 16, _lib.stream_ptr()), "up")
+    ref = x.repeat_interleave(2, 1).repeat_interleave(2, 2)
+    assert torch.equal(dst[..., 8:24], ref) and not dst[..., :8].any() and not dst[..., 24:].any()
+    # decode
+    ny, nx, na, no = 4, 6, 3, 85
+    raw = torch.randn(B, ny, nx, 256, generator=g).to(torch.bfloat16).to(DEV)
+    anc = torch.tensor([[10., 13.], [16., 30.], [33., 23.]], device=DEV)
+    pred = torch.zeros(B, 100, no, device=DEV)
+    _lib.check(L.adayolo_detect_decode(ctypes.c_void_p(raw.data_ptr()), 256, ctypes.c_void_p(pred.data_ptr()), 100, 20,
+                                       ctypes.c_void_p(anc.data_ptr()), 8.0, B, ny, nx, na, no, _lib.stream_ptr()), "dec")
+    t = raw[..., :255].float().view(B, ny, nx, na, no).permute(0, 3, 1, 2, 4).sigmoid()
+    yv, xv = torch.meshgrid(torch.arange(ny, device=DEV).float(), torch.arange(nx, device=DEV).float(), indexing="ij")
+    grid = torch.stack((xv, yv), 2).view(1, 1, ny, nx, 2) - 0.5
+    ref = torch.cat(((t[..., :2] * 2 + grid) * 8.0, (t[..., 2:4] * 2) ** 2 * anc.view(1, na, 1, 1, 2), t[..., 4:]), -1)
+    torch.testing.assert_close(pred[:, 20:20 + na * ny * nx], ref.reshape(B, -1, no), rtol=1e-5, atol=1e-5)
+    assert not pred[:, :20].any() and not pred[:, 20 + na * ny * nx:].any()
+
+
+@pytest.mark.parametrize("shape", [(1, 64, 96), (2, 80, 96)])
+def test_engine_vs_reference_model(golden, shape):
+    from _synth import synth_yolo_state_dict, test_image
+    from adaptiveisp_amd.yolo import YoloEngine, yolov3
+    B, H, W = shape
+    m = yolov3().eval()
+    m.load_state_dict(synth_yolo_state_dict(m))
+    if shape == (1, 64, 96):
+        x = torch.from_numpy(golden("yolo")["x"])
+    else:
+        x = torch.from_numpy(test_image(B, H, W, seed=77, special=False))
+    eng = YoloEngine(m, B, H, W, device=DEV)
+    pred = eng(x.to(DEV))
+    torch.cuda.synchronize()
+    boxed = torch.full((B, 3, eng.Hp, W), 114 / 255)
+    boxed[:, :, eng.pad_top:eng.pad_top + H] = x
+    with torch.no_grad():
+        ref_pred, ref_raw = m(boxed)
+    if shape == (1, 64, 96):
+        np.testing.assert_allclose(ref_pred.numpy(), golden("yolo")["pred"], rtol=1e-5, atol=1e-6)   # the reference itself
+    for r, rr in zip(eng.raw_maps(), ref_raw):
+        scale = rr.abs().max().item()
+        assert (r.cpu() - rr).abs().max().item() <= 3e-2 * scale, "raw head maps (bf16 engine vs fp32 reference)"
+    rel = ((pred.cpu() - ref_pred).abs() / (ref_pred.abs() + 1.0)).max().item()
+    assert rel < 2e-2, rel
