@@ -15,9 +15,10 @@ OP_ZERO, OP_EXPOSURE, OP_GAMMA, OP_CCM, OP_SHARPEN, OP_NLM, OP_TONE = -1, 0, 1, 
 OP_CONTRAST, OP_SATPLUS, OP_WNB, OP_WB, OP_USM, OP_SHARPEN_V2, OP_COLOR = 6, 7, 8, 9, 10, 11, 12
 MAX_PARAMS = 24
 CLIP01 = 1
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 EXPORTS = ("adaisp_forward", "adaisp_process", "adaisp_backward_params", "adaisp_pool64", "adaisp_num_params",
+           "adaisp_policy_conv", "adaisp_policy_fc1", "adaisp_policy_finish",
            "adaisp_strerror", "adaisp_abi_version")
 
 _lib = None

@@ -16,12 +16,12 @@ ISP_FLAGS = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math"
 LIBS = {
     "libadaisp.so": dict(
         sources=["isp_pointwise.hip", "isp_conv.hip", "isp_nlm.hip", "isp_pool.hip", "isp_backward.hip",
-                 "isp_api.hip"],
+                 "isp_policy.hip", "isp_api.hip"],
         headers=["isp_internal.h", "../../include/adaisp.h"],
         flags=ISP_FLAGS),
     "libadayolo.so": dict(
-        sources=["yolo_conv.hip", "yolo_misc.hip", "yolo_api.hip"],
-        headers=["../../include/adayolo.h"],
+        sources=["yolo_conv.hip", "yolo_conv_dma.hip", "yolo_misc.hip", "yolo_api.hip"],
+        headers=["yolo_internal.h", "../../include/adayolo.h"],
         flags=["-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]),
 }
 

@@ -110,4 +110,32 @@ int adaisp_backward_params(const float* img, const float* grad_out, const int32_
                : ADAISP_ELAUNCH;
 }
 
+int adaisp_policy_conv(const float* in, const float* states, int n_state, const float* w, const float* bias, float* out,
+                       int G, int B, int Cin, int Hin, int Cout, void* stream) {
+    if (!in || !w || !bias || !out || G <= 0 || B <= 0 || Cin <= 0 || Hin <= 1 || Cout <= 0) return ADAISP_EINVAL;
+    if (Cout % 8 || Hin % 2 || G > 65535 || (states && (Cin < 3 || n_state != Cin - 3))) return ADAISP_ESHAPE;
+    return launch_policy_conv(in, states, n_state, w, bias, out, G, B, Cin, Hin, Cout,
+                              static_cast<hipStream_t>(stream)) == hipSuccess ? ADAISP_OK : ADAISP_ELAUNCH;
+}
+
+int adaisp_policy_fc1(const float* feats, const int32_t* head_src, const float* w1, const float* b1, float* hidden,
+                      int B, int D, int NH, int HID, void* stream) {
+    if (!feats || !head_src || !w1 || !b1 || !hidden || B <= 0 || D <= 0 || NH <= 0 || HID <= 0) return ADAISP_EINVAL;
+    if (D % 4) return ADAISP_ESHAPE;
+    return launch_policy_fc1(feats, head_src, w1, b1, hidden, B, D, NH, HID, static_cast<hipStream_t>(stream)) ==
+                   hipSuccess ? ADAISP_OK : ADAISP_ELAUNCH;
+}
+
+int adaisp_policy_finish(const adaisp_policy_finish_args* a, int B, void* stream) {
+    if (!a || B <= 0) return ADAISP_EINVAL;
+    if (!a->hidden || !a->w_filter || !a->b_filter || !a->row_filter || !a->row_slot || !a->w_sel || !a->b_sel ||
+        !a->noise || !a->states || !a->params_all || !a->packed || !a->op_ids || !a->selected || !a->pdf_out ||
+        !a->surrogate || !a->new_states || !a->penalty)
+        return ADAISP_EINVAL;
+    if (a->num_filters <= 0 || a->num_filters > ADAISP_POLICY_MAX_FILTERS || a->param_width <= 0 ||
+        a->param_width > ADAISP_MAX_PARAMS || a->hid <= 0 || a->num_rows <= 0 || B > 65535)
+        return ADAISP_ESHAPE;
+    return launch_policy_finish(*a, B, static_cast<hipStream_t>(stream)) == hipSuccess ? ADAISP_OK : ADAISP_ELAUNCH;
+}
+
 }  // extern "C"

@@ -38,6 +38,12 @@ hipError_t launch_backward_params(const float* img, const float* grad_out, const
                                   const float* params, int pstride, float* grad_params,
                                   int B, int H, int W, unsigned flags, hipStream_t s);
 
+hipError_t launch_policy_conv(const float* in, const float* states, int n_state, const float* w, const float* bias,
+                              float* out, int G, int B, int Cin, int Hin, int Cout, hipStream_t s);
+hipError_t launch_policy_fc1(const float* feats, const int32_t* head_src, const float* w1, const float* b1,
+                             float* hidden, int B, int D, int NH, int HID, hipStream_t s);
+hipError_t launch_policy_finish(const adaisp_policy_finish_args& a, int B, hipStream_t s);
+
 // Output clamp of Filter.forward (isp/filters.py:125). With `clip` false the bounds are +-inf.
 struct Clip {
     float lo, hi;

@@ -1,0 +1,256 @@
+// Fused eval path of the policy step (Agent.forward, agent.py:88-285) for gfx950.
+//
+// In the reference one RL step of the policy is ~250 tiny ATen launches per batch (two 4-layer CNN trunks
+// with BatchNorm, 10 filters x (fc1, LeakyReLU, fc_filter, fc_mask, regressor), selector head, softmax,
+// sampling, one-hot, state update, penalties). At 64x64 inputs that is pure launch latency. Here:
+//
+//   k_trunk_conv  x4  Conv2d(k4,s2,p1) with the BatchNorm folded in + LeakyReLU(0.2), fp32. Both trunks
+//                     (parameter features / action selection) run in one launch (blockIdx.z). The first
+//                     layer assembles its input on the fly: 3 pooled image planes + the state vector as
+//                     constant planes (enrich_image_input, util.py:58-63) — no concat tensor.
+//                     Weights are wave-uniform (scalar loads), each lane owns one output pixel x 8 channels.
+//   k_fc1         x1  the eleven 4096->128 hidden layers (10 filter heads + selector), one wave per neuron,
+//                     weights streamed once for the whole batch.
+//   k_finish      x1  per image: fc_filter of every head + its regressor (tanh_range / exp / sigmoid / WB
+//                     normalisation), selector fc2 + softmax + exploration mix + entropy, pdf_sample / argmax /
+//                     forced id, one-hot, surrogate, state update, penalty, and the packed parameter row + op
+//                     code that adaisp_forward consumes. Integer stages follow agent.py:12-23,138-149,234-259.
+//
+// All arithmetic is fp32 with fmaf accumulation (the reference's fp32 GEMM/conv libraries use other
+// summation orders; parity is to 1e-5, selection is exact on the golden vectors).
+#include "isp_internal.h"
+
+namespace adaisp {
+namespace {
+
+__device__ __forceinline__ float lrelu02(float v) { return v > 0.0f ? v : 0.2f * v; }
+
+// ---- trunk conv: out[g][b][co][oy][ox] = lrelu(bias + sum_{ci,kh,kw} in[.., 2oy-1+kh, 2ox-1+kw] * w[g][co][ci][kh][kw])
+constexpr int CO_PER = 8;
+
+__global__ __launch_bounds__(256) void k_trunk_conv(const float* __restrict__ in, const float* __restrict__ states,
+                                                    int n_state, const float* __restrict__ w,
+                                                    const float* __restrict__ bias, float* __restrict__ out, int B,
+                                                    int Cin, int Hin, int Cout) {
+    const int Ho = Hin >> 1;
+    const int g = blockIdx.z, co0 = blockIdx.y * CO_PER;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    const int npix = B * Ho * Ho;
+    const bool live = idx < npix;
+    const int pid = live ? idx : 0;
+    const int b = pid / (Ho * Ho), r = pid - b * Ho * Ho, oy = r / Ho, ox = r - oy * Ho;
+    const float* wg = w + ((long)g * Cout + co0) * Cin * 16;
+    float acc[CO_PER];
+#pragma unroll
+    for (int c = 0; c < CO_PER; ++c) acc[c] = bias[g * Cout + co0 + c];
+    // validity of the 4x4 window taps (zero padding 1)
+    bool vy[4], vx[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        vy[t] = (2 * oy - 1 + t) >= 0 && (2 * oy - 1 + t) < Hin;
+        vx[t] = (2 * ox - 1 + t) >= 0 && (2 * ox - 1 + t) < Hin;
+    }
+    const int n_img = states ? 3 : Cin;                       // channels that come from a tensor
+    const float* ib = states ? in + (long)b * 3 * Hin * Hin   // first layer: shared pooled image [B,3,H,H]
+                             : in + ((long)g * B + b) * Cin * Hin * Hin;
+    for (int ci = 0; ci < Cin; ++ci) {
+        float v[16];
+        if (ci < n_img) {
+            const float* p = ib + (long)ci * Hin * Hin + (2 * oy - 1) * Hin + (2 * ox - 1);
+#pragma unroll
+            for (int kh = 0; kh < 4; ++kh)
+#pragma unroll
+                for (int kw = 0; kw < 4; ++kw) v[kh * 4 + kw] = (vy[kh] && vx[kw]) ? p[kh * Hin + kw] : 0.0f;
+        } else {
+            const float s = states[b * n_state + (ci - 3)];  // constant plane, still zero outside the frame
+#pragma unroll
+            for (int kh = 0; kh < 4; ++kh)
+#pragma unroll
+                for (int kw = 0; kw < 4; ++kw) v[kh * 4 + kw] = (vy[kh] && vx[kw]) ? s : 0.0f;
+        }
+        const float* wc = wg + ci * 16;
+#pragma unroll
+        for (int c = 0; c < CO_PER; ++c)
+#pragma unroll
+            for (int t = 0; t < 16; ++t) acc[c] = fmaf(v[t], wc[(long)c * Cin * 16 + t], acc[c]);
+    }
+    if (live) {
+        float* o = out + (((long)g * B + b) * Cout + co0) * Ho * Ho + oy * Ho + ox;
+#pragma unroll
+        for (int c = 0; c < CO_PER; ++c) o[(long)c * Ho * Ho] = lrelu02(acc[c]);
+    }
+}
+
+// ---- fc1 of every head: hidden[b][h][j] = lrelu(b1[h][j] + feats[src(h)][b][:] . w1[h][j][:]) ------------
+constexpr int FC_MAXB = 8;
+
+__global__ __launch_bounds__(256) void k_fc1(const float* __restrict__ feats, const int32_t* __restrict__ head_src,
+                                             const float* __restrict__ w1, const float* __restrict__ b1,
+                                             float* __restrict__ hidden, int B, int D, int NH, int HID) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int neuron = blockIdx.x * 4 + wave;                 // over NH*HID
+    if (neuron >= NH * HID) return;
+    const int h = neuron / HID;
+    const float4* wr = reinterpret_cast<const float4*>(w1 + (long)neuron * D);
+    const float* fb = feats + (long)head_src[h] * B * D;
+    for (int b0 = 0; b0 < B; b0 += FC_MAXB) {
+        const int nb = min(FC_MAXB, B - b0);
+        float acc[FC_MAXB];
+#pragma unroll
+        for (int i = 0; i < FC_MAXB; ++i) acc[i] = 0.0f;
+        for (int k = lane; k < D / 4; k += 64) {
+            const float4 wv = wr[k];
+#pragma unroll
+            for (int i = 0; i < FC_MAXB; ++i) {
+                if (i < nb) {
+                    const float4 f = reinterpret_cast<const float4*>(fb + (long)(b0 + i) * D)[k];
+                    acc[i] = fmaf(wv.x, f.x, fmaf(wv.y, f.y, fmaf(wv.z, f.z, fmaf(wv.w, f.w, acc[i]))));
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < FC_MAXB; ++i) {
+            float v = acc[i];
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+            if (lane == 0 && i < nb) hidden[((long)(b0 + i) * NH + h) * HID + neuron - h * HID] = lrelu02(v + b1[neuron]);
+        }
+    }
+}
+
+// ---- finish ------------------------------------------------------------------------------------------
+__device__ __forceinline__ float tanh01f(float x) { return tanhf(x) * 0.5f + 0.5f; }
+
+__global__ __launch_bounds__(64) void k_finish(adaisp_policy_finish_args a) {
+    const int b = blockIdx.x, t = threadIdx.x;
+    const int F = a.num_filters, HID = a.hid, PW = a.param_width;
+    __shared__ float raw[ADAISP_POLICY_MAX_FILTERS * ADAISP_MAX_PARAMS];   // fc_filter outputs
+    __shared__ float logit[ADAISP_POLICY_MAX_FILTERS];
+    __shared__ float pdf[ADAISP_POLICY_MAX_FILTERS];
+    __shared__ int sel_sh;
+    const float* hb = a.hidden + (long)b * (F + 1) * HID;
+
+    // fc_filter rows of every head (row -> filter via a.row_filter) and the selector's fc2
+    for (int r = t; r < a.num_rows + F; r += 64) {
+        const bool is_sel = r >= a.num_rows;
+        const int rr = is_sel ? r - a.num_rows : r;
+        const int f = is_sel ? F : a.row_filter[rr];
+        const float* wrow = is_sel ? a.w_sel + (long)rr * HID : a.w_filter + (long)rr * HID;
+        const float* h = hb + (long)f * HID;
+        float acc = 0.0f;
+        for (int k = 0; k < HID; ++k) acc = fmaf(wrow[k], h[k], acc);
+        acc += is_sel ? a.b_sel[rr] : a.b_filter[rr];
+        if (is_sel) logit[rr] = acc;
+        else raw[f * ADAISP_MAX_PARAMS + a.row_slot[rr]] = acc;
+    }
+    __syncthreads();
+
+    // regressors (isp/filters.py: filter_param_regressor of each class) -> params_all[b][f][slot]
+    for (int r = t; r < a.num_rows; r += 64) {
+        const int f = a.row_filter[r], s = a.row_slot[r];
+        const adaisp_regressor rg = a.reg[f];
+        const float x = raw[f * ADAISP_MAX_PARAMS + s];
+        float v;
+        switch (rg.kind) {
+            case ADAISP_REG_TANH_RANGE: v = tanh01f(x + rg.bias) * rg.scale + rg.lo; break;
+            case ADAISP_REG_EXP_TANH_RANGE: v = expf(tanh01f(x + rg.bias) * rg.scale + rg.lo); break;
+            case ADAISP_REG_SIGMOID: v = 1.0f / (1.0f + expf(-x)); break;
+            case ADAISP_REG_TANH: v = tanhf(x); break;
+            default: {  // ADAISP_REG_WB: exp(tanh_range(-.5,.5)(x * [0,1,1])) / (1e-5 + lum of the three gains)
+                float gsc[3];
+                for (int c = 0; c < 3; ++c) {
+                    const float xc = raw[f * ADAISP_MAX_PARAMS + c] * (c == 0 ? 0.0f : 1.0f);
+                    gsc[c] = expf(tanh01f(xc + rg.bias) * rg.scale + rg.lo);
+                }
+                const float lum = ((1e-5f + 0.27f * gsc[0]) + 0.67f * gsc[1]) + 0.06f * gsc[2];
+                v = gsc[s] * (1.0f / lum);
+            } break;
+        }
+        a.params_all[((long)b * F + f) * PW + s] = v;
+    }
+
+    // selector: softmax + 1e-37, exploration mix, renormalise, entropy, sample / argmax / forced (agent.py:126-149)
+    if (t == 0) {
+        float mx = logit[0];
+        for (int k = 1; k < F; ++k) mx = fmaxf(mx, logit[k]);
+        float sum = 0.0f;
+        for (int k = 0; k < F; ++k) { pdf[k] = expf(logit[k] - mx); sum += pdf[k]; }
+        float tot = 0.0f;
+        for (int k = 0; k < F; ++k) {
+            float p = pdf[k] / sum + 1e-37f;
+            p = p * a.one_minus_exploration + a.exploration_over_f;
+            pdf[k] = p;
+            tot += p;
+        }
+        tot += 1e-30f;
+        float ent = 0.0f;
+        for (int k = 0; k < F; ++k) { pdf[k] = pdf[k] / tot; ent += -pdf[k] * logf(pdf[k]); }
+        // pdf_sample: pdf / (sum + 1e-36); index = #{k : cdf_exclusive_k < u} - 1
+        float s2 = 0.0f;
+        for (int k = 0; k < F; ++k) s2 += pdf[k];
+        s2 += 1e-36f;
+        const float u = a.noise[(long)b * a.noise_stride];
+        int cnt = 0, amax = 0;
+        float run = 0.0f;
+        for (int k = 0; k < F; ++k) {
+            const float pk = pdf[k] / s2;
+            run += pk;
+            if (run - pk < u) ++cnt;
+            if (pdf[k] > pdf[amax]) amax = k;
+        }
+        const int sel = a.forced_id >= 0 ? a.forced_id : (a.train_mode ? cnt - 1 : amax);
+        sel_sh = sel;
+        a.selected[b] = (long long)sel;
+        a.op_ids[b] = (sel >= 0 && sel < F) ? a.reg[sel].op : ADAISP_OP_ZERO;
+        for (int k = 0; k < F; ++k) a.pdf_out[(long)b * F + k] = pdf[k];
+        a.surrogate[b] = (sel >= 0 && sel < F) ? logf(pdf[sel] + 1e-10f) : 0.0f;
+        // state update + penalty (agent.py:234-280); mean(clip(x-1,0)^2) is 0 because x is clipped to [0,1]
+        const int S = 3 + F;
+        const float* st = a.states + (long)b * S;
+        float* ns = a.new_states + (long)b * S;
+        const float last = fabsf(st[2] + 1.0f - a.test_steps) < 1e-4f ? 1.0f : 0.0f;
+        ns[0] = last; ns[1] = last; ns[2] = st[2] + 1.0f;
+        float usage_pen = 0.0f;
+        for (int k = 0; k < F; ++k) {
+            const float oh = (k == sel) ? 1.0f : 0.0f;
+            usage_pen += st[3 + k] * oh;
+            ns[3 + k] = fmaxf(st[3 + k], oh);
+        }
+        const float entropy_pen = a.entropy_coef * (-ent + a.log_num_filters);
+        const float early = (1.0f - last) * last * a.early_stop_penalty;
+        float runtime_pen = 0.0f;
+        if (a.runtime && sel >= 0 && sel < F) runtime_pen = a.runtime_lambda * a.runtime[sel];
+        a.penalty[b] = 0.0f + entropy_pen + usage_pen * a.filter_usage_penalty + early + runtime_pen;
+    }
+    __syncthreads();
+    // packed parameter row of the selected filter (zeros for the all-zero one-hot)
+    const int sel = sel_sh;
+    for (int s = t; s < PW; s += 64) {
+        float v = 0.0f;
+        if (sel >= 0 && sel < F && s < a.reg[sel].n) v = a.params_all[((long)b * F + sel) * PW + s];
+        a.packed[(long)b * PW + s] = v;
+    }
+}
+
+}  // namespace
+
+hipError_t launch_policy_conv(const float* in, const float* states, int n_state, const float* w, const float* bias,
+                              float* out, int G, int B, int Cin, int Hin, int Cout, hipStream_t s) {
+    const int Ho = Hin / 2;
+    dim3 grid((B * Ho * Ho + 255) / 256, Cout / CO_PER, G);
+    hipLaunchKernelGGL(k_trunk_conv, grid, dim3(256), 0, s, in, states, n_state, w, bias, out, B, Cin, Hin, Cout);
+    return hipGetLastError();
+}
+
+hipError_t launch_policy_fc1(const float* feats, const int32_t* head_src, const float* w1, const float* b1,
+                             float* hidden, int B, int D, int NH, int HID, hipStream_t s) {
+    hipLaunchKernelGGL(k_fc1, dim3((NH * HID + 3) / 4), dim3(256), 0, s, feats, head_src, w1, b1, hidden, B, D, NH, HID);
+    return hipGetLastError();
+}
+
+hipError_t launch_policy_finish(const adaisp_policy_finish_args& a, int B, hipStream_t s) {
+    hipLaunchKernelGGL(k_finish, dim3(B), dim3(64), 0, s, a);
+    return hipGetLastError();
+}
+
+}  // namespace adaisp

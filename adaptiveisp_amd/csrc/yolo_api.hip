@@ -1,27 +1,5 @@
 // C-ABI of libadayolo.so (include/adayolo.h): argument checks + launches. No allocation, no sync.
-#include <hip/hip_runtime.h>
-#include <stdint.h>
-#include "../../include/adayolo.h"
-
-namespace adayolo {
-struct ConvArgs {
-    const unsigned short* in; int in_cs;
-    const unsigned short* w; const float* bias;
-    const unsigned short* res; int res_cs;
-    unsigned short* out; int out_cs;
-    int B, H, W, Cin, Cout, Ho, Wo, ks, stride, pad, act;
-    int M;
-    int mtiles, ntiles;
-};
-hipError_t launch_conv(ConvArgs a, hipStream_t s);
-hipError_t launch_stem(const float* img, const float* w, const float* bias, void* out, int out_cs, int B, int H,
-                       int W, int Hp, int pad_top, float pad_value, hipStream_t s);
-hipError_t launch_upsample2x(const void* in, int in_cs, void* out, int out_cs, int B, int H, int W, int C,
-                             hipStream_t s);
-hipError_t launch_detect_decode(const void* raw, int raw_cs, float* pred, int pred_rows, int row_offset,
-                                const float* anchors_px, float det_stride, int B, int ny, int nx, int na, int no,
-                                hipStream_t s);
-}  // namespace adayolo
+#include "yolo_internal.h"
 
 using namespace adayolo;
 
@@ -39,9 +17,11 @@ const char* adayolo_strerror(int code) {
     }
 }
 
-int adayolo_conv_fwd(const void* in, int in_cstride, const void* weight, const float* bias, const void* residual,
-                     int res_cstride, void* out, int out_cstride, int B, int H, int W, int Cin, int Cout, int ksize,
-                     int stride, int act, void* stream) {
+#define ADAYOLO_DEFAULT_VARIANT 2
+
+int adayolo_conv_fwd_variant(const void* in, int in_cstride, const void* weight, const float* bias,
+                             const void* residual, int res_cstride, void* out, int out_cstride, int B, int H, int W,
+                             int Cin, int Cout, int ksize, int stride, int act, int variant, void* stream) {
     if (!in || !weight || !bias || !out) return ADAYOLO_EINVAL;
     if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return ADAYOLO_EINVAL;
     if ((ksize != 1 && ksize != 3) || (stride != 1 && stride != 2)) return ADAYOLO_ESHAPE;
@@ -61,7 +41,16 @@ int adayolo_conv_fwd(const void* in, int in_cstride, const void* weight, const f
     const long M = (long)B * a.Ho * a.Wo;
     if (M > 0x7fffffffL || (long)B * H * W * in_cstride > 0x7fffffffffL) return ADAYOLO_ESHAPE;
     a.M = (int)M; a.mtiles = a.ntiles = 0;
-    return launch_conv(a, static_cast<hipStream_t>(stream)) == hipSuccess ? ADAYOLO_OK : ADAYOLO_ELAUNCH;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const hipError_t e = (variant == 1) ? launch_conv(a, s) : launch_conv_dma(a, s, variant ? variant : ADAYOLO_DEFAULT_VARIANT);
+    return e == hipSuccess ? ADAYOLO_OK : ADAYOLO_ELAUNCH;
+}
+
+int adayolo_conv_fwd(const void* in, int in_cstride, const void* weight, const float* bias, const void* residual,
+                     int res_cstride, void* out, int out_cstride, int B, int H, int W, int Cin, int Cout, int ksize,
+                     int stride, int act, void* stream) {
+    return adayolo_conv_fwd_variant(in, in_cstride, weight, bias, residual, res_cstride, out, out_cstride, B, H, W,
+                                    Cin, Cout, ksize, stride, act, 0, stream);
 }
 
 int adayolo_stem_fwd(const float* img, const float* weight, const float* bias, void* out, int out_cstride, int B,

@@ -16,9 +16,7 @@
 //
 // Reference semantics: Conv.forward_fuse = SiLU(conv2d(x) + b), yolov3/models/common.py:58-59;
 // Bottleneck shortcut x + cv2(cv1(x)), common.py:119-120.
-#include <hip/hip_runtime.h>
-#include <stdint.h>
-#include "../../include/adayolo.h"
+#include "yolo_internal.h"
 
 namespace adayolo {
 
@@ -43,16 +41,6 @@ __device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
 __device__ __forceinline__ float silu(float x) {
     return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504088896341f * x));
 }
-
-struct ConvArgs {
-    const unsigned short* in; int in_cs;
-    const unsigned short* w; const float* bias;
-    const unsigned short* res; int res_cs;
-    unsigned short* out; int out_cs;
-    int B, H, W, Cin, Cout, Ho, Wo, ks, stride, pad, act;
-    int M;            // B*Ho*Wo
-    int mtiles, ntiles;
-};
 
 // Bijective XCD remap: consecutive logical ids share an XCD (observed placement: block b -> XCD b % 8).
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {

@@ -1,0 +1,29 @@
+// Shared between the translation units of libadayolo.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/adayolo.h"
+
+namespace adayolo {
+
+struct ConvArgs {
+    const unsigned short* in; int in_cs;
+    const unsigned short* w; const float* bias;
+    const unsigned short* res; int res_cs;
+    unsigned short* out; int out_cs;
+    int B, H, W, Cin, Cout, Ho, Wo, ks, stride, pad, act;
+    int M;            // B*Ho*Wo
+    int mtiles, ntiles;
+};
+
+hipError_t launch_conv(ConvArgs a, hipStream_t s);                    // register-staged (yolo_conv.hip)
+hipError_t launch_conv_dma(ConvArgs a, hipStream_t s, int variant);   // LDS-DMA ring (yolo_conv_dma.hip)
+hipError_t launch_stem(const float* img, const float* w, const float* bias, void* out, int out_cs, int B, int H,
+                       int W, int Hp, int pad_top, float pad_value, hipStream_t s);
+hipError_t launch_upsample2x(const void* in, int in_cs, void* out, int out_cs, int B, int H, int W, int C,
+                             hipStream_t s);
+hipError_t launch_detect_decode(const void* raw, int raw_cs, float* pred, int pred_rows, int row_offset,
+                                const float* anchors_px, float det_stride, int B, int ny, int nx, int na, int no,
+                                hipStream_t s);
+
+}  // namespace adayolo

@@ -1,8 +1,6 @@
 // Detector-side kernels that are not the generic conv: the fused ISP->detector stem, nearest 2x
 // up-sampling into a concat slice, and the Detect-head decode. gfx950 only.
-#include <hip/hip_runtime.h>
-#include <stdint.h>
-#include "../../include/adayolo.h"
+#include "yolo_internal.h"
 
 namespace adayolo {
 

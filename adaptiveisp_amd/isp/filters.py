@@ -91,6 +91,17 @@ class Filter(nn.Module):
     def filter_param_regressor(self, features):
         raise AssertionError("filter_param_regressor must be implemented by the filter class")
 
+    # (kind, lo, hi, initial) of the regressor for the fused policy kernel (kinds: include/adaisp.h); None = no fused form
+    _regressor = None
+
+    def regressor_spec(self):
+        """(op, n, kind, lo, scale, bias) consumed by adaisp_policy_finish; mirrors filter_param_regressor."""
+        if self._regressor is None:
+            raise NotImplementedError(f"{type(self).__name__} has no fused regressor")
+        kind, lo, hi, initial = self._regressor(self.cfg) if callable(self._regressor) else self._regressor
+        bias = 0.0 if initial is None else math.atanh(2 * (initial - lo) / (hi - lo) - 1)
+        return int(self.op_code), int(self.get_num_filter_parameters()), kind, float(lo), float(hi - lo), float(bias)
+
     # -- pixels ----------------------------------------------------------------------------------
     def process(self, img, param):
         """Whole-image filter, no mask, no clip: one HIP launch (adaisp_process / adaisp_forward)."""
@@ -156,6 +167,7 @@ class Filter(nn.Module):
 
 class ExposureFilter(Filter):
     op_code = _lib.OP_EXPOSURE
+    _regressor = staticmethod(lambda cfg: (0, -cfg.exposure_range, cfg.exposure_range, 0))
 
     def __init__(self, cfg, predict=False):
         super().__init__(cfg, "E", 1, predict)
@@ -167,6 +179,7 @@ class ExposureFilter(Filter):
 
 class GammaFilter(Filter):
     op_code = _lib.OP_GAMMA
+    _regressor = staticmethod(lambda cfg: (1, -math.log(cfg.gamma_range), math.log(cfg.gamma_range), None))
 
     def __init__(self, cfg, predict=False):
         super().__init__(cfg, "G", 1, predict)
@@ -178,21 +191,24 @@ class GammaFilter(Filter):
 
 class ImprovedWhiteBalanceFilter(Filter):
     op_code = _lib.OP_WB
+    _regressor = (4, -0.5, 0.5, None)
 
     def __init__(self, cfg, predict=False):
         super().__init__(cfg, "W", 3, predict)
         self.num_filter_parameters = self.channels
+        # R gain pinned to 1; non-persistent so the state dict keeps the reference's keys (and no H2D copy per call)
+        self.register_buffer("_keep", torch.tensor([[0.0, 1.0, 1.0]], dtype=torch.float32), persistent=False)
 
     def filter_param_regressor(self, features):
         log_wb_range = 0.5
-        keep = torch.tensor([[0.0, 1.0, 1.0]], dtype=torch.float32, device=features.device)  # R gain pinned
-        scaling = torch.exp(tanh_range(-log_wb_range, log_wb_range)(features * keep))
+        scaling = torch.exp(tanh_range(-log_wb_range, log_wb_range)(features * self._keep.to(features.device)))
         lum = 1e-5 + 0.27 * scaling[:, 0] + 0.67 * scaling[:, 1] + 0.06 * scaling[:, 2]
         return scaling * (1.0 / lum)[:, None]
 
 
 class ColorFilter(Filter):
     op_code = _lib.OP_COLOR
+    _regressor = staticmethod(lambda cfg: (0, cfg.color_curve_range[0], cfg.color_curve_range[1], 1))
 
     def __init__(self, cfg, predict=False):
         super().__init__(cfg, "C", 3 * cfg.curve_steps, predict)
@@ -205,6 +221,7 @@ class ColorFilter(Filter):
 
 class ToneFilter(Filter):
     op_code = _lib.OP_TONE
+    _regressor = staticmethod(lambda cfg: (0, cfg.tone_curve_range[0], cfg.tone_curve_range[1], None))
 
     def __init__(self, cfg, predict=False):
         super().__init__(cfg, "T", cfg.curve_steps, predict)
@@ -223,6 +240,7 @@ class ToneFilterV2(ToneFilter):
 
 class ContrastFilter(Filter):
     op_code = _lib.OP_CONTRAST
+    _regressor = (3, 0.0, 1.0, None)
 
     def __init__(self, cfg, predict=False):
         super().__init__(cfg, "Ct", 1, predict)
@@ -233,6 +251,7 @@ class ContrastFilter(Filter):
 
 class WNBFilter(Filter):
     op_code = _lib.OP_WNB
+    _regressor = (2, 0.0, 1.0, None)
 
     def __init__(self, cfg, predict=False):
         super().__init__(cfg, "BW", 1, predict)
@@ -243,6 +262,7 @@ class WNBFilter(Filter):
 
 class SaturationPlusFilter(Filter):
     op_code = _lib.OP_SATPLUS
+    _regressor = (2, 0.0, 1.0, None)
 
     def __init__(self, cfg, predict=False):
         super().__init__(cfg, "S+", 1, predict)
@@ -254,6 +274,7 @@ class SaturationPlusFilter(Filter):
 class DenoiseFilter(Filter):
     """Non-local means, gray weights, 11x11 search / 5x5 patch (reference isp/filters.py:571-586)."""
     op_code = _lib.OP_NLM
+    _regressor = (2, 0.0, 1.0, None)
 
     def __init__(self, cfg, predict=False):
         super().__init__(cfg, "NLM", 1, predict)
@@ -266,6 +287,7 @@ class DenoiseFilter(Filter):
 
 class SharpenUSMFilter(Filter):
     op_code = _lib.OP_USM
+    _regressor = staticmethod(lambda cfg: (0, cfg.usm_sharpen_range[0], cfg.usm_sharpen_range[1], None))
 
     def __init__(self, cfg, predict=False):
         super().__init__(cfg, "USM", 2, predict)
@@ -276,6 +298,7 @@ class SharpenUSMFilter(Filter):
 
 class SharpenFilter(Filter):
     op_code = _lib.OP_SHARPEN
+    _regressor = staticmethod(lambda cfg: (0, cfg.sharpen_range[0], cfg.sharpen_range[1], None))
 
     def __init__(self, cfg, predict=False):
         super().__init__(cfg, "Shr", 1, predict)
@@ -304,6 +327,7 @@ color_correction_matrix = _fused_only("color_correction_matrix")
 class CCMFilter(Filter):
     """3x3 colour-correction matrix; the kernel divides every row by its sum (reference isp/filters.py:694-708)."""
     op_code = _lib.OP_CCM
+    _regressor = staticmethod(lambda cfg: (0, cfg.ccm_range[0], cfg.ccm_range[1], None))
 
     def __init__(self, cfg, predict=False):
         super().__init__(cfg, "CCM", 9, predict)

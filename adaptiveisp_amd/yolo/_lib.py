@@ -8,7 +8,7 @@ _HERE = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB_PATH = os.path.join(_HERE, "csrc", "libadayolo.so")
 ABI_VERSION = 1
 ACT_NONE, ACT_SILU = 0, 1
-EXPORTS = ("adayolo_conv_fwd", "adayolo_stem_fwd", "adayolo_upsample2x", "adayolo_detect_decode", "adayolo_strerror",
+EXPORTS = ("adayolo_conv_fwd", "adayolo_conv_fwd_variant", "adayolo_stem_fwd", "adayolo_upsample2x", "adayolo_detect_decode", "adayolo_strerror",
            "adayolo_abi_version")
 _lib = None
 
@@ -27,6 +27,8 @@ def load():
     L = ctypes.CDLL(LIB_PATH)
     vp, ci, cf = ctypes.c_void_p, ctypes.c_int, ctypes.c_float
     L.adayolo_conv_fwd.argtypes = [vp, ci, vp, vp, vp, ci, vp, ci, ci, ci, ci, ci, ci, ci, ci, ci, vp]
+    L.adayolo_conv_fwd_variant.argtypes = [vp, ci, vp, vp, vp, ci, vp, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, vp]
+    L.adayolo_conv_fwd_variant.restype = ci
     L.adayolo_stem_fwd.argtypes = [vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, cf, ci, vp]
     L.adayolo_upsample2x.argtypes = [vp, ci, vp, ci, ci, ci, ci, ci, vp]
     L.adayolo_detect_decode.argtypes = [vp, ci, vp, ci, ci, vp, cf, ci, ci, ci, ci, ci, vp]

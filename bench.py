@@ -1,0 +1,268 @@
+#!/usr/bin/env python3
+"""Headline benchmark: ISP + YOLOv3 forward images/sec @1280x720, batch 8 per GPU (BASELINE.json configs[1]).
+
+One "step" = one batch through the whole hot path with inputs resident in HBM:
+    5 RL steps of the ISP (64x64 pooling -> policy/parameter heads -> selected filter kernel), teacher-forced
+    schedule S_mixed = [E, CCM, NLM, Shr, T] so the kernel work is deterministic,
+    then the YOLOv3 forward (letterbox 720->736 fused into the stem, bf16 MFMA convs, eval decode).
+N GPUs = N independent replicas (one process per GPU, no data-path collective): scaling "weak".
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Prints ONE JSON line (rank 0). Extra objects: `roofline` (dominant kernel: the 128x128 implicit-GEMM conv,
+timed per launch with HIP events on the launch stream), `isp` (per-step ISP kernel times vs the HBM roof)
+and `cpu_baseline` (the CPU oracle + plain torch-CPU detector on a bounded sample, host cores of this box).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+SCHEDULES = {"mixed": [0, 2, 4, 3, 5], "point": [0, 9, 2, 5, 1], "heavy": [4, 3]}
+NAMES = ["E", "G", "CCM", "Shr", "NLM", "T", "Ct", "S+", "BW", "W"]
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 peak
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=8)
+    ap.add_argument("--height", type=int, default=720)
+    ap.add_argument("--width", type=int, default=1280)
+    ap.add_argument("--schedule", default="mixed", choices=sorted(SCHEDULES))
+    ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
+    ap.add_argument("--miopen", action="store_true",
+                    help="let MIOpen run the 64x64 policy convs (default: ATen native kernels, which are capturable)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-detail", action="store_true", help="skip the per-kernel roofline passes")
+    return ap.parse_args()
+
+
+def build_workload(a, dev):
+    from adaptiveisp_amd.agent import Agent
+    from adaptiveisp_amd.config import cfg
+    from adaptiveisp_amd.yolo import YoloEngine, yolov3
+    torch.manual_seed(0)
+    agent = Agent(cfg, shape=(6 + len(cfg.filters), 64, 64), device=dev).to(dev).eval()
+    torch.manual_seed(1)
+    det = yolov3().eval()
+    engine = YoloEngine(det, a.batch, a.height, a.width, device=dev)
+    g = torch.Generator(device="cpu").manual_seed(1234 + 1)
+    x0 = (torch.rand(a.batch, 3, a.height, a.width, generator=g) ** 2.2 * 0.5).to(dev)
+    z = torch.rand(a.batch, cfg.z_dim, generator=g).to(dev)
+    s0 = torch.zeros(a.batch, cfg.num_state_dim, device=dev)
+    sched = SCHEDULES[a.schedule]
+
+    def step():
+        x, st = x0, s0
+        with torch.no_grad():
+            for k in sched:
+                (x, st, _, _), _, _ = agent((x, z, st), 1.0, selected_filter_id=k)
+            return engine(x)
+
+    return step, engine, agent, x0, sched
+
+
+def time_isp_kernels(x0, sched, iters=10):
+    """Per-op ISP kernel time (HIP events on the launch stream), algorithmic 24 B/px."""
+    from adaptiveisp_amd import _lib
+    B, _, H, W = x0.shape
+    npar = {0: 1, 1: 1, 2: 9, 3: 1, 4: 1, 5: 8, 6: 1, 7: 1, 8: 1, 9: 3}
+    out = torch.empty_like(x0)
+    res = {}
+    for op in sorted(set(sched)):
+        p = torch.rand(B, npar[op], device=x0.device) * 0.8 + 0.6
+        n = 3 if op == 4 else iters
+        _lib.process(op, x0, p, clip=True, out=out)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(n):
+            _lib.process(op, x0, p, clip=True, out=out)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / n
+        gbs = 24.0 * B * H * W / (ms * 1e-3) / 1e9
+        res[NAMES[op]] = {"ms": round(ms, 4), "GBps": round(gbs, 1), "frac_hbm": round(gbs / HBM_PEAK_GBS, 3)}
+    return res
+
+
+def time_dominant_conv(engine, x, reps=3):
+    """Average launch duration of the dominant kernel (k_conv_igemm<128,128,2,2>) over every launch of it in
+    one detector forward, measured with an event pair around each launch on the launch stream."""
+    from adaptiveisp_amd.yolo import _lib as ylib
+    import ctypes
+    st = ylib.stream_ptr()
+    sel = []
+    for kind, fn, args in engine.plan:
+        if kind != "conv":
+            continue
+        B, H, W, cin, cout, k, s = args[8], args[9], args[10], args[11], args[12], args[13], args[14]
+        Ho, Wo = (H - 1) // s + 1, (W - 1) // s + 1
+        M = B * Ho * Wo
+        if cout > 64 and ((M + 127) // 128) * ((cout + 127) // 128) >= 512:
+            sel.append((fn, args, 2.0 * M * cout * k * k * cin))
+    engine(x)
+    torch.cuda.synchronize()
+    tot_ms, tot_fl, n = 0.0, 0.0, 0
+    for _ in range(reps):
+        for fn, args, fl in sel:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            fn(*args, st)
+            e1.record()
+            e1.synchronize()
+            tot_ms += e0.elapsed_time(e1)
+            tot_fl += fl
+            n += 1
+    # whole detector forward, for the end-to-end TFLOP/s
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        engine(x)
+    e1.record()
+    torch.cuda.synchronize()
+    det_ms = e0.elapsed_time(e1) / reps
+    return {"launches_per_forward": len(sel), "avg_launch_ms": tot_ms / max(n, 1),
+            "tflops": tot_fl / (tot_ms * 1e-3) / 1e12 if tot_ms else 0.0,
+            "flops_per_launch": tot_fl / max(n, 1), "detector_ms": det_ms,
+            "detector_tflops": engine.flops / (det_ms * 1e-3) / 1e12}
+
+
+def cpu_baseline(a, sched):
+    """The CPU oracle (oracle/isp_oracle.c, OpenMP on all host cores) for the 5 ISP steps + plain torch-CPU fp32
+    for the detector, on ONE image of the batch (bounded sample); images/sec."""
+    import numpy as np
+    import oracle
+    from adaptiveisp_amd.yolo import yolov3
+    oracle.build()
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    rng = np.random.default_rng(1235)
+    x = (rng.random((1, 3, a.height, a.width)) ** 2.2 * 0.5).astype(np.float32)
+    npar = {0: 1, 1: 1, 2: 9, 3: 1, 4: 1, 5: 8, 6: 1, 7: 1, 8: 1, 9: 3}
+    t0 = time.perf_counter()
+    cur = x
+    for op in sched:
+        oracle.pool64(cur)
+        p = (rng.random((1, npar[op])) * 0.8 + 0.6).astype(np.float32)
+        cur = oracle.forward(cur, op, p, clip=True)
+    t_isp = time.perf_counter() - t0
+    torch.manual_seed(1)
+    det = yolov3().eval()
+    Hp = (a.height + 31) // 32 * 32
+    boxed = torch.full((1, 3, Hp, a.width), 114 / 255)
+    boxed[:, :, (Hp - a.height) // 2:(Hp - a.height) // 2 + a.height] = torch.from_numpy(cur)
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        det(boxed)
+        t_det = time.perf_counter() - t0
+    return {"value": round(1.0 / (t_isp + t_det), 4), "unit": "images/sec", "cores": cores, "kind": "port",
+            "sample": f"1 image of the batch @{a.width}x{a.height}: 5 ISP steps {[NAMES[k] for k in sched]} with the C "
+                      f"oracle ({t_isp:.2f} s) + YOLOv3 fp32 torch-CPU forward ({t_det:.2f} s)",
+            "isp_s": round(t_isp, 3), "detector_s": round(t_det, 3)}
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (the product has no CPU path)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    # The policy trunks are tiny 64x64 convs; MIOpen's solvers allocate inside the call, which a hipGraph
+    # capture forbids. ATen's native conv/batch-norm kernels compute the same fp32 result and are capturable.
+    torch.backends.cudnn.enabled = bool(a.miopen)
+    step, engine, agent, x0, sched = build_workload(a, dev)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    run = step
+    graphed = False
+    step()                                   # eager warm-up: lazy module init, MIOpen/rocBLAS plans
+    torch.cuda.synchronize()
+    if not a.no_graph:
+        try:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                step()
+            torch.cuda.current_stream().wait_stream(side)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                step()
+            run, graphed = graph.replay, True
+        except Exception as e:          # stays on the HIP kernels either way; only the launch mechanism differs
+            print(f"[bench] hipGraph capture unavailable ({type(e).__name__}: {e}); launching eagerly", file=sys.stderr)
+            torch.cuda.synchronize()
+            run = step
+    for _ in range(a.warmup):
+        run()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        run()
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    value = world * a.batch * a.steps / dt
+
+    line = {
+        "metric": "ISP+YOLO forward images/sec @1280x720 bs8", "value": round(value, 2), "unit": "images/sec",
+        "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": f"batch {a.batch} x {a.width}x{a.height} fp32 RGB, 5-step ISP schedule "
+                               f"{[NAMES[k] for k in sched]} (teacher-forced, policy/heads evaluated every step) + YOLOv3 "
+                               f"forward @{a.width}x{engine.Hp} bf16 (random-init weights)",
+                   "per_gpu_batch": a.batch, "global_batch": a.batch * world, "parallelism": f"replicas x{world}",
+                   "launch": "hipGraph replay" if graphed else "eager"},
+    }
+    if rank == 0 and not a.no_detail:
+        d = time_dominant_conv(engine, x0)
+        line["roofline"] = {"bound": "mfma", "kernel": "k_conv_igemm<128,128,2,2>",
+                            "achieved": round(d["tflops"], 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                            "frac": round(d["tflops"] / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None,
+                            "avg_launch_ms": round(d["avg_launch_ms"], 4), "launches_per_step": d["launches_per_forward"],
+                            "flops_per_launch": d["flops_per_launch"]}
+        line["detector"] = {"ms": round(d["detector_ms"], 3), "tflops": round(d["detector_tflops"], 1),
+                            "gflop_per_image": round(engine.flops / a.batch / 1e9, 1)}
+        line["isp"] = {"bound": "hbm", "peak_GBps": HBM_PEAK_GBS, "bytes_per_px": 24,
+                       "kernels": time_isp_kernels(x0, sched)}
+    if rank == 0 and not a.no_cpu_baseline and world == 1:
+        try:
+            line["cpu_baseline"] = cpu_baseline(a, sched)
+        except Exception as e:
+            line["cpu_baseline"] = {"error": f"{type(e).__name__}: {e}"}
+    if rank == 0:
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define ADAISP_ABI_VERSION 2
+#define ADAISP_ABI_VERSION 3
 
 /* Kernel op codes. 0..9 follow the reference's default filter order (config.py:19-22). */
 enum adaisp_op {
@@ -93,6 +93,76 @@ int adaisp_backward_params(const float* img, const float* grad_out,
 
 /* AdaptiveAvgPool2d((64,64)) of a [B,3,H,W] image: agent.py:85,97, value.py:61,63. */
 int adaisp_pool64(const float* img, float* pooled, int B, int H, int W, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * Fused eval path of one policy step (Agent.forward in eval mode, agent.py:88-285; FeatureExtractor
+ * agent.py:26-60; Filter.extract_parameters / filter_param_regressor isp/filters.py:65-73 and per class).
+ * Weights are the module parameters with BatchNorm folded into the convs (eval statistics), fp32.
+ * --------------------------------------------------------------------------------------------------------- */
+#define ADAISP_POLICY_MAX_FILTERS 16
+
+enum adaisp_regressor_kind {
+    ADAISP_REG_TANH_RANGE     = 0, /* tanh01(x + bias) * scale + lo          (E, CCM, Shr, T, USM, C) */
+    ADAISP_REG_EXP_TANH_RANGE = 1, /* exp(tanh01(x + bias) * scale + lo)     (G)                      */
+    ADAISP_REG_SIGMOID        = 2, /* 1 / (1 + exp(-x))                      (NLM, S+, BW)            */
+    ADAISP_REG_TANH           = 3, /* tanh(x)                                (Ct)                     */
+    ADAISP_REG_WB             = 4  /* exp(tanh_range(x*[0,1,1])) / luminance (W), isp/filters.py:258-269 */
+};
+
+typedef struct adaisp_regressor {
+    int32_t op;      /* kernel op code of the filter (enum adaisp_op)  */
+    int32_t n;       /* number of regressed parameters                 */
+    int32_t kind;    /* enum adaisp_regressor_kind                     */
+    float lo, scale, bias;
+} adaisp_regressor;
+
+typedef struct adaisp_policy_finish_args {
+    /* inputs */
+    const float* hidden;       /* [B][F+1][hid]  LeakyReLU(fc1) of the F filter heads, then the selector's   */
+    const float* w_filter;     /* [rows][hid]    fc_filter weights of all heads, stacked in filter order       */
+    const float* b_filter;     /* [rows]                                                                        */
+    const int32_t* row_filter; /* [rows]         filter index of each stacked row                               */
+    const int32_t* row_slot;   /* [rows]         parameter slot of each stacked row inside its filter           */
+    const float* w_sel;        /* [F][hid]       selector fc2                                                   */
+    const float* b_sel;        /* [F]                                                                           */
+    const float* noise;        /* [B][noise_stride]  z; column 0 is the selection noise (agent.py:92)           */
+    const float* states;       /* [B][3+F]                                                                      */
+    const float* runtime;      /* [F] or NULL (cfg.filter_runtime_penalty off)                                  */
+    /* outputs */
+    float* params_all;         /* [B][F][param_width] regressed parameters of every filter                      */
+    float* packed;             /* [B][param_width]    row of the selected filter (input of adaisp_forward)      */
+    int32_t* op_ids;           /* [B]                 op code of the selected filter (-1: all-zero one-hot)     */
+    long long* selected;       /* [B]                 selected filter id (int64 like the reference)             */
+    float* pdf_out;            /* [B][F]                                                                        */
+    float* surrogate;          /* [B]                                                                           */
+    float* new_states;         /* [B][3+F]                                                                      */
+    float* penalty;            /* [B]                                                                           */
+    /* scalars */
+    int32_t num_filters, num_rows, hid, param_width, noise_stride;
+    int32_t train_mode;        /* 1: pdf_sample, 0: argmax                                                      */
+    int32_t forced_id;         /* >= 0: teacher-forced selected_filter_id                                       */
+    float one_minus_exploration, exploration_over_f;
+    float entropy_coef;        /* (1 - progress) * cfg.exploration_penalty                                      */
+    float log_num_filters, test_steps, filter_usage_penalty, early_stop_penalty, runtime_lambda;
+    adaisp_regressor reg[ADAISP_POLICY_MAX_FILTERS];
+} adaisp_policy_finish_args;
+
+/*
+ * One folded trunk layer: out = LeakyReLU_0.2(conv2d(in, w, k4 s2 p1) + bias), G independent trunks per launch.
+ *   in  [G][B][Cin][Hin][Hin], w [G][Cout][Cin][4][4], bias [G][Cout], out [G][B][Cout][Hin/2][Hin/2].
+ * First layer: pass states != NULL; `in` is then the 64x64-pooled image [B,3,Hin,Hin] shared by all trunks and
+ * input channels 3..Cin-1 are the per-image constants states[b][c-3] (enrich_image_input, util.py:58-63).
+ * Cout must be a multiple of 8.
+ */
+int adaisp_policy_conv(const float* in, const float* states, int n_state, const float* w, const float* bias,
+                       float* out, int G, int B, int Cin, int Hin, int Cout, void* stream);
+
+/* hidden[b][h][j] = LeakyReLU_0.2(b1[h][j] + feats[head_src[h]][b][:] . w1[h][j][:]);  feats [G][B][D], D % 4 == 0 */
+int adaisp_policy_fc1(const float* feats, const int32_t* head_src, const float* w1, const float* b1, float* hidden,
+                      int B, int D, int NH, int HID, void* stream);
+
+/* Everything after the hidden layers (see struct). `args` is a HOST struct holding DEVICE pointers. */
+int adaisp_policy_finish(const adaisp_policy_finish_args* args, int B, void* stream);
 
 /* Number of regressed parameters an op reads per image (0 for ADAISP_OP_ZERO, -1 if unknown). */
 int adaisp_num_params(int op);

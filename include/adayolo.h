@@ -49,6 +49,17 @@ int adayolo_conv_fwd(const void* in, int in_cstride,
                      int ksize, int stride, int act, void* stream);
 
 /*
+ * Same as adayolo_conv_fwd with an explicit kernel variant (tuning / A-B measurements; results are identical):
+ * 0 = library default, 1 = register-staged tile loads, 2/3/4 = LDS-DMA ring with 2/3/4 stages.
+ */
+int adayolo_conv_fwd_variant(const void* in, int in_cstride,
+                             const void* weight, const float* bias,
+                             const void* residual, int res_cstride,
+                             void* out, int out_cstride,
+                             int B, int H, int W, int Cin, int Cout,
+                             int ksize, int stride, int act, int variant, void* stream);
+
+/*
  * Detector stem fused with the ISP->detector hand-over: reads the ISP output as planar fp32
  * [B,3,H,W] (values in [0,1]), letterboxes it vertically to Hp rows (pad_top rows of `pad_value` above,
  * the rest below: yolov3/utils/augmentations.py:111-141 uses 114/255), and applies the first

@@ -82,3 +82,49 @@ def test_filter_module_api(golden):
         low, high, dbg = f.forward(img, specified_parameter=p, high_res=img)
         np.testing.assert_allclose(low.cpu().numpy(), g[f"{name}.forward"], rtol=1e-5, atol=2e-6)
         assert torch.equal(low, high) and set(dbg) == {"filter_parameters", "mask"}
+
+
+@pytest.mark.parametrize("tag", ["s0", "s1"])
+def test_fused_eval_path_matches_torch_path(golden, tag):
+    """The 7-launch fused policy step (policy_fast.py) against the PyTorch head path and the golden vectors."""
+    g = golden("agent")
+    ag, cfg, dev = _agent()
+    inp = (T(g["x"]).to(dev), T(g["z"]).to(dev), T(g[tag]).to(dev))
+    prog = float(g[f"{tag}.progress"])
+    with torch.no_grad():
+        ag.use_fast_eval = True
+        (xf, nsf, surf, penf), dbgf, _ = ag(inp, prog)
+        assert ag._fast is not None                                   # the fused path really ran
+        ag.use_fast_eval = False
+        (xt, nst, surt, pent), dbgt, _ = ag(inp, prog)
+    assert torch.equal(dbgf["selected_filter"], dbgt["selected_filter"]) and dbgf["selected_filter"].dtype == torch.int64
+    assert np.array_equal(dbgf["selected_filter"].cpu().numpy(), g[f"{tag}.selected"])
+    assert torch.equal(nsf, nst) and np.array_equal(nsf.cpu().numpy(), g[f"{tag}.new_states"])
+    torch.testing.assert_close(dbgf["pdf"], dbgt["pdf"], rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(dbgf["pdf"].cpu().numpy(), g[f"{tag}.pdf0"], rtol=1e-3, atol=1e-5)
+    torch.testing.assert_close(surf, surt, rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(penf, pent, rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(penf.cpu().numpy(), g[f"{tag}.penalty"], rtol=1e-4, atol=1e-5)
+    for a, b in zip(dbgf["filter_debug_info"], dbgt["filter_debug_info"]):
+        assert a["filter_parameters"].shape == b["filter_parameters"].shape
+        torch.testing.assert_close(a["filter_parameters"], b["filter_parameters"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(xf.cpu().numpy(), g[f"{tag}.x"], rtol=2e-4, atol=2e-5)
+
+
+def test_fused_eval_forced_and_highres(golden):
+    g = golden("agent")
+    ag, cfg, dev = _agent()
+    inp = (T(g["x"]).to(dev), T(g["z"]).to(dev), T(g["s0"]).to(dev))
+    with torch.no_grad():
+        for k in range(10):
+            (x, ns, sur, pen), dbg, _ = ag(inp, 1.0, selected_filter_id=k)
+            assert np.array_equal(ns.cpu().numpy(), g[f"forced{k}.new_states"])
+            np.testing.assert_allclose(pen.cpu().numpy(), g[f"forced{k}.penalty"], rtol=1e-4, atol=1e-5)
+            np.testing.assert_allclose(x.cpu().numpy(), g[f"forced{k}.x"], rtol=2e-4, atol=2e-5)
+        (x, ns, hr), _, _ = ag(inp, 1.0, high_res=T(g["hr.in"]).to(dev), selected_filter_id=5)
+        np.testing.assert_allclose(hr.cpu().numpy(), g["hr.out"], rtol=2e-4, atol=2e-5)
+        # weights are re-snapshotted after an in-place update
+        with torch.no_grad():
+            ag.fc2.bias.add_(torch.tensor([0, 0, 0, 0, 0, 0, 0, 0, 50.0, 0], device=dev))
+        (_, _, _, _), dbg, _ = ag(inp, 1.0)
+        assert (dbg["selected_filter"] == 8).all()

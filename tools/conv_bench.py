@@ -1,0 +1,68 @@
+#!/usr/bin/env python3
+"""A/B of the implicit-GEMM conv variants on the YOLOv3 layer shapes (bs8, 1280x736). TFLOP/s per shape."""
+import ctypes
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from adaptiveisp_amd.yolo import _lib  # noqa: E402
+
+DEV = "cuda:0"
+# (H, W, Cin, Cout, k, s, count in the network)
+SHAPES = [
+    (736, 1280, 32, 64, 3, 2, 1), (368, 640, 64, 32, 1, 1, 1), (368, 640, 32, 64, 3, 1, 1),
+    (368, 640, 64, 128, 3, 2, 1), (184, 320, 128, 64, 1, 1, 2), (184, 320, 64, 128, 3, 1, 2),
+    (184, 320, 128, 256, 3, 2, 1), (92, 160, 256, 128, 1, 1, 10), (92, 160, 128, 256, 3, 1, 11),
+    (92, 160, 256, 512, 3, 2, 1), (46, 80, 512, 256, 1, 1, 10), (46, 80, 256, 512, 3, 1, 11),
+    (46, 80, 512, 1024, 3, 2, 1), (23, 40, 1024, 512, 1, 1, 7), (23, 40, 512, 1024, 3, 1, 7),
+    (46, 80, 768, 256, 1, 1, 1), (92, 160, 384, 128, 1, 1, 1), (92, 160, 256, 256, 1, 1, 1),
+]
+
+
+def run(L, x, w, b, out, B, H, W, cin, cout, k, s, variant, iters):
+    args = (ctypes.c_void_p(x.data_ptr()), cin, ctypes.c_void_p(w.data_ptr()), ctypes.c_void_p(b.data_ptr()), None, 0,
+            ctypes.c_void_p(out.data_ptr()), cout, B, H, W, cin, cout, k, s, 1, variant)
+    st = _lib.stream_ptr()
+    for _ in range(2):
+        _lib.check(L.adayolo_conv_fwd_variant(*args, st), "conv")
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        L.adayolo_conv_fwd_variant(*args, st)
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+def main():
+    variants = [int(v) for v in (sys.argv[1] if len(sys.argv) > 1 else "1,2,3,4").split(",")]
+    B = 8
+    L = _lib.load()
+    tot = {v: 0.0 for v in variants}
+    totfl = 0.0
+    print(f"{'shape':38s} " + " ".join(f"v{v:>2d} TF/s   ms " for v in variants))
+    for (H, W, cin, cout, k, s, cnt) in SHAPES:
+        g = torch.Generator(device="cpu").manual_seed(H + cin)
+        x = torch.randn(B, H, W, cin, generator=g).to(torch.bfloat16).to(DEV)
+        w = (torch.randn(cout, k, k, cin, generator=g) / (k * k * cin) ** 0.5).to(torch.bfloat16).to(DEV)
+        b = torch.randn(cout, generator=g).to(DEV)
+        Ho, Wo = (H - 1) // s + 1, (W - 1) // s + 1
+        fl = 2.0 * B * Ho * Wo * cout * k * k * cin
+        outs, row = {}, []
+        for v in variants:
+            out = torch.zeros(B, Ho, Wo, cout, dtype=torch.bfloat16, device=DEV)
+            ms = run(L, x, w, b, out, B, H, W, cin, cout, k, s, v, 10)
+            outs[v] = out
+            tot[v] += ms * cnt
+            row.append(f"{fl / ms / 1e9:7.1f} {ms:6.3f}")
+        totfl += fl * cnt
+        same = all(torch.equal(outs[variants[0]], outs[v]) for v in variants[1:])
+        print(f"{H}x{W} {cin:4d}->{cout:4d} k{k} s{s} x{cnt:<2d}          " + "  ".join(row) + ("" if same else "  MISMATCH"))
+    print("network conv total (ms), TF/s: " + "  ".join(f"v{v}: {tot[v]:.3f} ms {totfl / tot[v] / 1e9:.1f}" for v in variants))
+
+
+if __name__ == "__main__":
+    main()
