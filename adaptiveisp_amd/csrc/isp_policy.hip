@@ -26,15 +26,22 @@ namespace {
 __device__ __forceinline__ float lrelu02(float v) { return v > 0.0f ? v : 0.2f * v; }
 
 // ---- trunk conv: out[g][b][co][oy][ox] = lrelu(bias + sum_{ci,kh,kw} in[.., 2oy-1+kh, 2ox-1+kw] * w[g][co][ci][kh][kw])
+// Workgroup = KS waves: 64 output pixels x 8 output channels, the input channels split into KS slices (one
+// wave per slice, so the slice's weights stay wave-uniform scalar loads); partial sums meet in LDS.
+// The deep layers have few pixels (4x4 maps) and long reductions (K = 2048): without the split they run
+// on a handful of waves, each grinding a 16k-FMA serial chain.
 constexpr int CO_PER = 8;
+constexpr int PX_PER = 64;
 
-__global__ __launch_bounds__(256) void k_trunk_conv(const float* __restrict__ in, const float* __restrict__ states,
-                                                    int n_state, const float* __restrict__ w,
-                                                    const float* __restrict__ bias, float* __restrict__ out, int B,
-                                                    int Cin, int Hin, int Cout) {
+__global__ __launch_bounds__(1024) void k_trunk_conv(const float* __restrict__ in, const float* __restrict__ states,
+                                                     int n_state, const float* __restrict__ w,
+                                                     const float* __restrict__ bias, float* __restrict__ out, int B,
+                                                     int Cin, int Hin, int Cout, int KS) {
+    extern __shared__ float part[];                             // [KS][CO_PER][PX_PER]
     const int Ho = Hin >> 1;
     const int g = blockIdx.z, co0 = blockIdx.y * CO_PER;
-    const int idx = blockIdx.x * 256 + threadIdx.x;
+    const int lane = threadIdx.x & 63, ks = threadIdx.x >> 6;
+    const int idx = blockIdx.x * PX_PER + lane;
     const int npix = B * Ho * Ho;
     const bool live = idx < npix;
     const int pid = live ? idx : 0;
@@ -42,18 +49,19 @@ __global__ __launch_bounds__(256) void k_trunk_conv(const float* __restrict__ in
     const float* wg = w + ((long)g * Cout + co0) * Cin * 16;
     float acc[CO_PER];
 #pragma unroll
-    for (int c = 0; c < CO_PER; ++c) acc[c] = bias[g * Cout + co0 + c];
-    // validity of the 4x4 window taps (zero padding 1)
-    bool vy[4], vx[4];
+    for (int c = 0; c < CO_PER; ++c) acc[c] = 0.0f;
+    bool vy[4], vx[4];                                          // zero padding 1
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
         vy[t] = (2 * oy - 1 + t) >= 0 && (2 * oy - 1 + t) < Hin;
         vx[t] = (2 * ox - 1 + t) >= 0 && (2 * ox - 1 + t) < Hin;
     }
-    const int n_img = states ? 3 : Cin;                       // channels that come from a tensor
-    const float* ib = states ? in + (long)b * 3 * Hin * Hin   // first layer: shared pooled image [B,3,H,H]
+    const int n_img = states ? 3 : Cin;                         // channels that come from a tensor
+    const float* ib = states ? in + (long)b * 3 * Hin * Hin     // first layer: shared pooled image [B,3,H,H]
                              : in + ((long)g * B + b) * Cin * Hin * Hin;
-    for (int ci = 0; ci < Cin; ++ci) {
+    const int cps = (Cin + KS - 1) / KS;                        // channels per slice
+    const int c_lo = ks * cps, c_hi = min(Cin, c_lo + cps);
+    for (int ci = c_lo; ci < c_hi; ++ci) {
         float v[16];
         if (ci < n_img) {
             const float* p = ib + (long)ci * Hin * Hin + (2 * oy - 1) * Hin + (2 * ox - 1);
@@ -62,7 +70,7 @@ __global__ __launch_bounds__(256) void k_trunk_conv(const float* __restrict__ in
 #pragma unroll
                 for (int kw = 0; kw < 4; ++kw) v[kh * 4 + kw] = (vy[kh] && vx[kw]) ? p[kh * Hin + kw] : 0.0f;
         } else {
-            const float s = states[b * n_state + (ci - 3)];  // constant plane, still zero outside the frame
+            const float s = states[b * n_state + (ci - 3)];     // constant plane, still zero outside the frame
 #pragma unroll
             for (int kh = 0; kh < 4; ++kh)
 #pragma unroll
@@ -74,10 +82,14 @@ __global__ __launch_bounds__(256) void k_trunk_conv(const float* __restrict__ in
 #pragma unroll
             for (int t = 0; t < 16; ++t) acc[c] = fmaf(v[t], wc[(long)c * Cin * 16 + t], acc[c]);
     }
-    if (live) {
-        float* o = out + (((long)g * B + b) * Cout + co0) * Ho * Ho + oy * Ho + ox;
 #pragma unroll
-        for (int c = 0; c < CO_PER; ++c) o[(long)c * Ho * Ho] = lrelu02(acc[c]);
+    for (int c = 0; c < CO_PER; ++c) part[(ks * CO_PER + c) * PX_PER + lane] = acc[c];
+    __syncthreads();
+    // wave c of the first CO_PER waves finishes channel c (KS < CO_PER: the remaining channels loop)
+    for (int c = ks; c < CO_PER; c += KS) {
+        float v = bias[g * Cout + co0 + c];
+        for (int k = 0; k < KS; ++k) v += part[(k * CO_PER + c) * PX_PER + lane];
+        if (live) out[(((long)g * B + b) * Cout + co0 + c) * Ho * Ho + oy * Ho + ox] = lrelu02(v);
     }
 }
 
@@ -98,6 +110,7 @@ __global__ __launch_bounds__(256) void k_fc1(const float* __restrict__ feats, co
         float acc[FC_MAXB];
 #pragma unroll
         for (int i = 0; i < FC_MAXB; ++i) acc[i] = 0.0f;
+#pragma unroll 4
         for (int k = lane; k < D / 4; k += 64) {
             const float4 wv = wr[k];
 #pragma unroll
@@ -121,7 +134,7 @@ __global__ __launch_bounds__(256) void k_fc1(const float* __restrict__ feats, co
 // ---- finish ------------------------------------------------------------------------------------------
 __device__ __forceinline__ float tanh01f(float x) { return tanhf(x) * 0.5f + 0.5f; }
 
-__global__ __launch_bounds__(64) void k_finish(adaisp_policy_finish_args a) {
+__global__ __launch_bounds__(256) void k_finish(adaisp_policy_finish_args a) {
     const int b = blockIdx.x, t = threadIdx.x;
     const int F = a.num_filters, HID = a.hid, PW = a.param_width;
     __shared__ float raw[ADAISP_POLICY_MAX_FILTERS * ADAISP_MAX_PARAMS];   // fc_filter outputs
@@ -130,23 +143,31 @@ __global__ __launch_bounds__(64) void k_finish(adaisp_policy_finish_args a) {
     __shared__ int sel_sh;
     const float* hb = a.hidden + (long)b * (F + 1) * HID;
 
-    // fc_filter rows of every head (row -> filter via a.row_filter) and the selector's fc2
-    for (int r = t; r < a.num_rows + F; r += 64) {
-        const bool is_sel = r >= a.num_rows;
-        const int rr = is_sel ? r - a.num_rows : r;
-        const int f = is_sel ? F : a.row_filter[rr];
-        const float* wrow = is_sel ? a.w_sel + (long)rr * HID : a.w_filter + (long)rr * HID;
-        const float* h = hb + (long)f * HID;
-        float acc = 0.0f;
-        for (int k = 0; k < HID; ++k) acc = fmaf(wrow[k], h[k], acc);
-        acc += is_sel ? a.b_sel[rr] : a.b_filter[rr];
-        if (is_sel) logit[rr] = acc;
-        else raw[f * ADAISP_MAX_PARAMS + a.row_slot[rr]] = acc;
+    // fc_filter rows of every head (row -> filter via a.row_filter) and the selector's fc2: one wave per row,
+    // lanes stride the hidden dimension, shuffle reduction
+    {
+        const int lane = t & 63, wv = t >> 6;
+        for (int r = wv; r < a.num_rows + F; r += 4) {
+            const bool is_sel = r >= a.num_rows;
+            const int rr = is_sel ? r - a.num_rows : r;
+            const int f = is_sel ? F : a.row_filter[rr];
+            const float* wrow = is_sel ? a.w_sel + (long)rr * HID : a.w_filter + (long)rr * HID;
+            const float* h = hb + (long)f * HID;
+            float acc = 0.0f;
+            for (int k = lane; k < HID; k += 64) acc = fmaf(wrow[k], h[k], acc);
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+            if (lane == 0) {
+                acc += is_sel ? a.b_sel[rr] : a.b_filter[rr];
+                if (is_sel) logit[rr] = acc;
+                else raw[f * ADAISP_MAX_PARAMS + a.row_slot[rr]] = acc;
+            }
+        }
     }
     __syncthreads();
 
     // regressors (isp/filters.py: filter_param_regressor of each class) -> params_all[b][f][slot]
-    for (int r = t; r < a.num_rows; r += 64) {
+    for (int r = t; r < a.num_rows; r += 256) {
         const int f = a.row_filter[r], s = a.row_slot[r];
         const adaisp_regressor rg = a.reg[f];
         const float x = raw[f * ADAISP_MAX_PARAMS + s];
@@ -225,7 +246,7 @@ __global__ __launch_bounds__(64) void k_finish(adaisp_policy_finish_args a) {
     __syncthreads();
     // packed parameter row of the selected filter (zeros for the all-zero one-hot)
     const int sel = sel_sh;
-    for (int s = t; s < PW; s += 64) {
+    for (int s = t; s < PW; s += 256) {
         float v = 0.0f;
         if (sel >= 0 && sel < F && s < a.reg[sel].n) v = a.params_all[((long)b * F + sel) * PW + s];
         a.packed[(long)b * PW + s] = v;
@@ -237,8 +258,13 @@ __global__ __launch_bounds__(64) void k_finish(adaisp_policy_finish_args a) {
 hipError_t launch_policy_conv(const float* in, const float* states, int n_state, const float* w, const float* bias,
                               float* out, int G, int B, int Cin, int Hin, int Cout, hipStream_t s) {
     const int Ho = Hin / 2;
-    dim3 grid((B * Ho * Ho + 255) / 256, Cout / CO_PER, G);
-    hipLaunchKernelGGL(k_trunk_conv, grid, dim3(256), 0, s, in, states, n_state, w, bias, out, B, Cin, Hin, Cout);
+    int KS = Cin / 8;                                   // ~8 input channels per wave
+    if (KS < 1) KS = 1;
+    if (KS > 16) KS = 16;
+    dim3 grid((B * Ho * Ho + PX_PER - 1) / PX_PER, Cout / CO_PER, G);
+    const size_t smem = (size_t)KS * CO_PER * PX_PER * sizeof(float);
+    hipLaunchKernelGGL(k_trunk_conv, grid, dim3(64 * KS), smem, s, in, states, n_state, w, bias, out, B, Cin, Hin, Cout,
+                       KS);
     return hipGetLastError();
 }
 
@@ -249,7 +275,7 @@ hipError_t launch_policy_fc1(const float* feats, const int32_t* head_src, const 
 }
 
 hipError_t launch_policy_finish(const adaisp_policy_finish_args& a, int B, hipStream_t s) {
-    hipLaunchKernelGGL(k_finish, dim3(B), dim3(64), 0, s, a);
+    hipLaunchKernelGGL(k_finish, dim3(B), dim3(256), 0, s, a);
     return hipGetLastError();
 }
 
