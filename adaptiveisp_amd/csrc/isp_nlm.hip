@@ -37,9 +37,14 @@ __device__ __forceinline__ int wrap(int v, int n) {
     return v < 0 ? v + n : v;
 }
 
+// GRAD = false: forward (writes `out`). GRAD = true: d/dh of the forward, contracted with grad_out and summed over
+// the image: with w_s = exp(-d_s/hh), d w_s/dh = w_s d_s / hh^2 (h > 0), so
+//   d out_c/dh = (A_c - out_c * Bsum) / den,  A_c = sum_s x_sc w_s d_s / hh^2,  Bsum = sum_s w_s d_s / hh^2.
+template <bool GRAD>
 __global__ __launch_bounds__(kThreads) void k_nlm(const float* __restrict__ img, float* __restrict__ out,
                                                   const int32_t* __restrict__ ids, int uniform_op,
-                                                  const float* __restrict__ params, int pstride, int H, int W) {
+                                                  const float* __restrict__ params, int pstride, int H, int W,
+                                                  const float* __restrict__ grad_out, float* __restrict__ grad_params) {
     __shared__ float ylds[YROWS * YP];
     __shared__ float clds[3 * CROWS * CP];
 
@@ -81,8 +86,14 @@ __global__ __launch_bounds__(kThreads) void k_nlm(const float* __restrict__ img,
             yc[bi][k] = ylds[(rb + HY - PR + k) * YP + tx + HY - (bi - PR)];
 
     float num[3][RPT], den[RPT];
+    float ga[GRAD ? 3 : 1][GRAD ? RPT : 1], gb[GRAD ? RPT : 1];
 #pragma unroll
     for (int r = 0; r < RPT; ++r) { num[0][r] = num[1][r] = num[2][r] = 0.0f; den[r] = 0.0f; }
+    if (GRAD) {
+#pragma unroll
+        for (int r = 0; r < RPT; ++r) { ga[0][r] = ga[1][r] = ga[2][r] = 0.0f; gb[r] = 0.0f; }
+    }
+    const float inv_hh2 = 1.0f / (hh * hh);
 
     for (int dx = -SR; dx <= SR; ++dx) {           // x_shift outer   (denoise.py:104)
         for (int dy = -SR; dy <= SR; ++dy) {       // y_shift inner   (denoise.py:105)
@@ -109,26 +120,59 @@ __global__ __launch_bounds__(kThreads) void k_nlm(const float* __restrict__ img,
             for (int r = 0; r < RPT; ++r) {
                 const float dist = __fsqrt_rn(fmaxf(D[r], 0.0f));
                 const float wgt = expf(-dist / hh);
-                num[0][r] += cs[(0 * CROWS + r) * CP] * wgt;
-                num[1][r] += cs[(1 * CROWS + r) * CP] * wgt;
-                num[2][r] += cs[(2 * CROWS + r) * CP] * wgt;
+                const float c0 = cs[(0 * CROWS + r) * CP], c1 = cs[(1 * CROWS + r) * CP], c2 = cs[(2 * CROWS + r) * CP];
+                num[0][r] += c0 * wgt;
+                num[1][r] += c1 * wgt;
+                num[2][r] += c2 * wgt;
                 den[r] += wgt;
+                if (GRAD) {
+                    const float dw = wgt * dist * inv_hh2;
+                    ga[0][r] = fmaf(c0, dw, ga[0][r]);
+                    ga[1][r] = fmaf(c1, dw, ga[1][r]);
+                    ga[2][r] = fmaf(c2, dw, ga[2][r]);
+                    gb[r] += dw;
+                }
             }
         }
     }
 
     const int gx = x0 + tx;
-    if (gx < W) {
+    if (!GRAD) {
+        if (gx < W) {
 #pragma unroll
-        for (int r = 0; r < RPT; ++r) {
-            const int gy = y0 + rb + r;
-            if (gy < H) {
-                const long g = (long)gy * W + gx;
-                o[g] = clamp01(num[0][r] / den[r]);
-                o[g + plane] = clamp01(num[1][r] / den[r]);
-                o[g + 2 * plane] = clamp01(num[2][r] / den[r]);
+            for (int r = 0; r < RPT; ++r) {
+                const int gy = y0 + rb + r;
+                if (gy < H) {
+                    const long g = (long)gy * W + gx;
+                    o[g] = clamp01(num[0][r] / den[r]);
+                    o[g + plane] = clamp01(num[1][r] / den[r]);
+                    o[g + 2 * plane] = clamp01(num[2][r] / den[r]);
+                }
             }
         }
+    } else {
+        float acc = 0.0f;
+        const float* go = grad_out + (long)b * 3 * plane;
+        if (gx < W && params[(long)b * pstride] > 0.0f) {          // relu(h): no gradient for h <= 0
+#pragma unroll
+            for (int r = 0; r < RPT; ++r) {
+                const int gy = y0 + rb + r;
+                if (gy < H) {
+                    const long g = (long)gy * W + gx;
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        const float oc = num[c][r] / den[r];
+                        if (oc >= 0.0f && oc <= 1.0f) acc += go[g + c * plane] * (ga[c][r] - oc * gb[r]) / den[r];
+                    }
+                }
+            }
+        }
+        __shared__ float red[4];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+        if ((tid & 63) == 0) red[tid >> 6] = acc;
+        __syncthreads();
+        if (tid == 0) atomicAdd(grad_params + (long)b * pstride, (red[0] + red[1]) + (red[2] + red[3]));
     }
 }
 
@@ -136,8 +180,16 @@ __global__ __launch_bounds__(kThreads) void k_nlm(const float* __restrict__ img,
 
 hipError_t launch_nlm(const Batch& a, hipStream_t s) {
     dim3 grid((a.W + TW - 1) / TW, (a.H + TH - 1) / TH, a.B);
-    hipLaunchKernelGGL(k_nlm, grid, dim3(kThreads), 0, s, a.img, a.out, a.ids, a.uniform_op, a.params, a.pstride,
-                       a.H, a.W);
+    hipLaunchKernelGGL(k_nlm<false>, grid, dim3(kThreads), 0, s, a.img, a.out, a.ids, a.uniform_op, a.params, a.pstride,
+                       a.H, a.W, static_cast<const float*>(nullptr), static_cast<float*>(nullptr));
+    return hipGetLastError();
+}
+
+hipError_t launch_nlm_backward(const float* img, const float* grad_out, const int32_t* ids, const float* params,
+                               int pstride, float* grad_params, int B, int H, int W, hipStream_t s) {
+    dim3 grid((W + TW - 1) / TW, (H + TH - 1) / TH, B);
+    hipLaunchKernelGGL(k_nlm<true>, grid, dim3(kThreads), 0, s, img, static_cast<float*>(nullptr), ids, 0, params,
+                       pstride, H, W, grad_out, grad_params);
     return hipGetLastError();
 }
 

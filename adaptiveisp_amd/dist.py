@@ -1,0 +1,102 @@
+"""Data-parallel glue for the RL training step: one process per GPU, `torch.distributed` (backend "nccl" = RCCL
+over xGMI on the MI355X node, "gloo" on CPU for tests).
+
+The reference trains on one GPU (train.py:45 WORLD_SIZE = 1). Sharding is by replay records: every rank draws its own
+batch, runs the whole hot path locally, and the ONLY collective per iteration is an all-reduce (mean) of the agent
+and value gradients — issued after backward() and BEFORE the 1e-5 grad-norm clip so the clip sees the global
+gradient (train.py:341-349). Gradients are flattened into one bucket per model (28.7 MB + 4.9 MB fp32): a few large
+transfers suit the point-to-point xGMI links better than hundreds of small ones.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend=None):
+    """Initialise the default process group from RANK / WORLD_SIZE / MASTER_* (torchrun). Returns (rank, world, device)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    use_gpu = torch.cuda.is_available()
+    device = torch.device("cuda", local) if use_gpu else torch.device("cpu")
+    if use_gpu:
+        torch.cuda.set_device(device)
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group(backend or ("nccl" if use_gpu else "gloo"), rank=rank, world_size=world)
+    return rank, world, device
+
+
+def broadcast_parameters(modules, src=0):
+    """Make every rank start from rank `src`'s weights and buffers (one flat broadcast per module)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return
+    for m in modules:
+        tensors = [t.data for t in list(m.parameters()) + list(m.buffers()) if t.is_floating_point()]
+        if not tensors:
+            continue
+        flat = torch.cat([t.reshape(-1) for t in tensors])
+        dist.broadcast(flat, src)
+        off = 0
+        for t in tensors:
+            n = t.numel()
+            t.copy_(flat[off:off + n].view_as(t))
+            off += n
+
+
+class GradBucket:
+    """Flat fp32 view of a module's gradients; `all_reduce_mean()` averages them across ranks in one collective."""
+
+    def __init__(self, module):
+        self.params = [p for p in module.parameters() if p.requires_grad]
+        self.numel = sum(p.numel() for p in self.params)
+        self.flat = None
+
+    def all_reduce_mean(self, async_op=False):
+        dev = self.params[0].device
+        if self.flat is None or self.flat.device != dev:
+            self.flat = torch.zeros(self.numel, dtype=torch.float32, device=dev)
+        off = 0
+        for p in self.params:
+            n = p.numel()
+            if p.grad is None:
+                self.flat[off:off + n].zero_()
+            else:
+                self.flat[off:off + n].copy_(p.grad.reshape(-1))
+            off += n
+        work = None
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            work = dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, async_op=async_op)
+            if not async_op:
+                self.flat.div_(dist.get_world_size())
+        return work
+
+    def finish(self, work=None):
+        """Complete an async all-reduce (if any) and scatter the averaged bucket back into .grad."""
+        if work is not None:
+            work.wait()
+            self.flat.div_(dist.get_world_size())
+        off = 0
+        for p in self.params:
+            n = p.numel()
+            if p.grad is None:
+                p.grad = self.flat[off:off + n].view_as(p).clone()
+            else:
+                p.grad.copy_(self.flat[off:off + n].view_as(p))
+            off += n
+
+
+def synced_step(models, optimizers, buckets, max_grad_norm=1e-5):
+    """After loss.backward(): all-reduce(mean) the gradients of every model (overlapped), clip, step.
+    Mirrors train.py:341-351 with the collective inserted before the clip."""
+    works = [b.all_reduce_mean(async_op=dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1)
+             for b in buckets]
+    for b, w in zip(buckets, works):
+        b.finish(w)
+    for m in models:
+        torch.nn.utils.clip_grad_norm_(m.parameters(), max_grad_norm)
+    for o in optimizers:
+        o.step()
+        o.zero_grad(set_to_none=False)

@@ -41,8 +41,6 @@ def parse():
     ap.add_argument("--width", type=int, default=1280)
     ap.add_argument("--schedule", default="mixed", choices=sorted(SCHEDULES))
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
-    ap.add_argument("--miopen", action="store_true",
-                    help="let MIOpen run the 64x64 policy convs (default: ATen native kernels, which are capturable)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-detail", action="store_true", help="skip the per-kernel roofline passes")
     return ap.parse_args()
@@ -188,9 +186,6 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    # The policy trunks are tiny 64x64 convs; MIOpen's solvers allocate inside the call, which a hipGraph
-    # capture forbids. ATen's native conv/batch-norm kernels compute the same fp32 result and are capturable.
-    torch.backends.cudnn.enabled = bool(a.miopen)
     step, engine, agent, x0, sched = build_workload(a, dev)
 
     def barrier():

@@ -135,6 +135,27 @@ def main():
             out[f"{key}.forward"] = fwd.numpy()
     np.savez_compressed(os.path.join(HERE, "filters.npz"), **out)
 
+    # ---------------------------------------------------------------- A2. parameter gradients (autograd of the reference)
+    gout = {}
+    G = np.random.default_rng(6).normal(0.0, 1.0, img.shape).astype(np.float32)
+    gout["grad_out"] = G
+    for name, cls in classes:
+        key = name.replace("+", "p")
+        f = cls(cfg, predict=False)
+        param = T(out[f"{key}.param"]).clone()
+        if name in ("T", "C"):
+            param = f.filter_param_regressor(T(out[f"{key}.feat"])).detach()
+        param.requires_grad_(True)
+        for mode in ("process", "forward"):
+            if param.grad is not None:
+                param.grad = None
+            y = f.process(T(img), param)
+            if mode == "forward":
+                y = torch.clip(y, 0.0, 1.0)
+            (y * T(G)).sum().backward()
+            gout[f"{key}.{mode}"] = param.grad.reshape(2, -1).numpy().copy()
+    np.savez_compressed(os.path.join(HERE, "filters_grad.npz"), **gout)
+
     # ---------------------------------------------------------------- B. NLM wrap-around cases
     out = {}
     nlm = filters.DenoiseFilter(cfg, predict=False)

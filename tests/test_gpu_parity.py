@@ -189,3 +189,37 @@ def test_fullsize_pool_checksum():
     # 1280 = 64*20 columns tile exactly; rows overlap (720/64 = 11.25) -> compare against torch's own pooling
     ref = torch.nn.functional.adaptive_avg_pool2d(x, (64, 64))
     torch.testing.assert_close(p, ref, rtol=1e-5, atol=1e-7)
+
+
+# ---- parameter gradients (adaisp_backward_params) vs the reference's autograd ----------------------------
+
+@pytest.mark.parametrize("name", sorted(OPS))
+@pytest.mark.parametrize("mode", ["process", "forward"])
+def test_param_gradients_match_reference_autograd(golden, name, mode):
+    from adaptiveisp_amd import _lib
+    g, gg = golden("filters"), golden("filters_grad")
+    img = torch.from_numpy(g["img"]).to(dev())
+    p = torch.from_numpy(g[f"{name}.param"]).to(dev())
+    ids = torch.full((2,), OPS[name], dtype=torch.int32, device=dev())
+    grad = _lib.backward_params(img, torch.from_numpy(gg["grad_out"]).to(dev()), ids, p, clip=(mode == "forward"))
+    ref = gg[f"{name}.{mode}"]
+    # sums of ~3k signed terms in a different order than autograd's reductions: compare to the gradient scale
+    np.testing.assert_allclose(grad.cpu().numpy()[:, :ref.shape[1]], ref, rtol=2e-4, atol=2e-4 * max(1.0, np.abs(ref).max()))
+
+
+def test_autograd_through_filter_modules(golden):
+    """Filter.forward on a parameter that requires grad: autograd reaches the heads through the HIP backward."""
+    from adaptiveisp_amd.config import cfg
+    from adaptiveisp_amd.isp import filters as F
+    g, gg = golden("filters"), golden("filters_grad")
+    img = torch.from_numpy(g["img"]).to(dev())
+    G = torch.from_numpy(gg["grad_out"]).to(dev())
+    for name, cls in (("CCM", F.CCMFilter), ("T", F.ToneFilter), ("NLM", F.DenoiseFilter), ("W", F.ImprovedWhiteBalanceFilter)):
+        f = cls(cfg, predict=False)
+        feat = torch.from_numpy(g[f"{name}.feat"]).to(dev()).requires_grad_(True)
+        low, _, _ = f.forward(img, specified_parameter=f.filter_param_regressor(feat))
+        (low * G).sum().backward()
+        assert feat.grad is not None and torch.isfinite(feat.grad).all() and feat.grad.abs().sum() > 0
+    with pytest.raises(NotImplementedError):
+        x = img.clone().requires_grad_(True)
+        F.ExposureFilter(cfg).forward(x, specified_parameter=torch.zeros(2, 1, device=dev()))[0].sum().backward()
