@@ -42,7 +42,8 @@ int adayolo_conv_fwd_variant(const void* in, int in_cstride, const void* weight,
     if (M > 0x7fffffffL || (long)B * H * W * in_cstride > 0x7fffffffffL) return ADAYOLO_ESHAPE;
     a.M = (int)M; a.mtiles = a.ntiles = 0;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const hipError_t e = (variant == 1) ? launch_conv(a, s) : launch_conv_dma(a, s, variant ? variant : ADAYOLO_DEFAULT_VARIANT);
+    if (variant == 0) variant = ADAYOLO_DEFAULT_VARIANT;
+    const hipError_t e = (variant == 1) ? launch_conv(a, s) : (variant >= 5) ? launch_conv_dma2(a, s, variant) : launch_conv_dma(a, s, variant);
     return e == hipSuccess ? ADAYOLO_OK : ADAYOLO_ELAUNCH;
 }
 

@@ -77,10 +77,10 @@ class YoloEngine:
         w, b = conv_w.to(self.dev), conv_b.to(self.dev)
         self._keep += [w, b]
         cout = cout if cout is not None else w.shape[0]
-        args = (ctypes.c_void_p(src.ptr), src.cs, ctypes.c_void_p(w.data_ptr()), ctypes.c_void_p(b.data_ptr()),
+        args = [ctypes.c_void_p(src.ptr), src.cs, ctypes.c_void_p(w.data_ptr()), ctypes.c_void_p(b.data_ptr()),
                 ctypes.c_void_p(res.ptr) if res is not None else None, res.cs if res is not None else 0,
-                ctypes.c_void_p(dst.ptr), dst.cs, self.B, src.H, src.W, src.C, cout, k, s, act)
-        self.plan.append(("conv", self.L.adayolo_conv_fwd, args))
+                ctypes.c_void_p(dst.ptr), dst.cs, self.B, src.H, src.W, src.C, cout, k, s, act, 0]   # last: variant
+        self.plan.append(("conv", self.L.adayolo_conv_fwd_variant, args))
         flops = 2.0 * self.B * dst.H * dst.W * cout * k * k * src.C
         self.flops += flops
 
@@ -169,6 +169,38 @@ class YoloEngine:
                     self.raw.append(raw)
                     row += self.na * v.H * v.W
         self.views = view
+
+    # ------------------------------------------------------------------------------------------
+    TUNE_CANDIDATES = (2, 5, 12, 13, 18, 19)
+
+    def autotune(self, reps=3):
+        """Pick the fastest conv kernel variant per layer by timing it on this engine's own buffers (all variants
+        compute the same result; see include/adayolo.h). Like a vendor library's 'find' step, done once."""
+        st = _lib.stream_ptr()
+        chosen = {}
+        with torch.cuda.device(self.dev):
+            for kind, fn, args in self.plan:
+                if kind != "conv":
+                    continue
+                key = tuple(args[8:16])                      # B,H,W,Cin,Cout,k,s,act
+                if key not in chosen:
+                    best = (None, float("inf"))
+                    for v in self.TUNE_CANDIDATES:
+                        args[16] = v
+                        fn(*args, st)
+                        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                        e0.record()
+                        for _ in range(reps):
+                            fn(*args, st)
+                        e1.record()
+                        e1.synchronize()
+                        t = e0.elapsed_time(e1)
+                        if t < best[1]:
+                            best = (v, t)
+                    chosen[key] = best[0]
+                args[16] = chosen[key]
+        self.tuned = chosen
+        return chosen
 
     # ------------------------------------------------------------------------------------------
     def forward(self, img):

@@ -29,6 +29,10 @@ SCHEDULES = {"mixed": [0, 2, 4, 3, 5], "point": [0, 9, 2, 5, 1], "heavy": [4, 3]
 NAMES = ["E", "G", "CCM", "Shr", "NLM", "T", "Ct", "S+", "BW", "W"]
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 peak
+CONV_KERNEL_NAMES = {1: "k_conv_igemm<128,128,2,2>", 2: "dma::k_conv_igemm_dma<128,128,2,2,2>",
+                     5: "dma2::k_conv_igemm_dma32<128,128,2,2,2,0,64>", 12: "dma2::k_conv_igemm_dma32<256,128,4,2,2,0,64>",
+                     13: "dma2::k_conv_igemm_dma32<256,256,4,2,2,0,64>", 18: "dma2::k_conv_igemm_dma32<128,128,2,2,4,0,32>",
+                     19: "dma2::k_conv_igemm_dma32<128,256,2,4,3,0,32>"}
 
 
 def parse():
@@ -55,6 +59,7 @@ def build_workload(a, dev):
     torch.manual_seed(1)
     det = yolov3().eval()
     engine = YoloEngine(det, a.batch, a.height, a.width, device=dev)
+    engine.autotune()
     g = torch.Generator(device="cpu").manual_seed(1234 + 1)
     x0 = (torch.rand(a.batch, 3, a.height, a.width, generator=g) ** 2.2 * 0.5).to(dev)
     z = torch.rand(a.batch, cfg.z_dim, generator=g).to(dev)
@@ -101,6 +106,13 @@ def time_dominant_conv(engine, x, reps=3):
     from adaptiveisp_amd.yolo import _lib as ylib
     import ctypes
     st = ylib.stream_ptr()
+    # dominant kernel = the conv variant that carries the most flops in this forward
+    by_variant = {}
+    for kind, fn, args in engine.plan:
+        if kind == "conv":
+            Ho, Wo = (args[9] - 1) // args[14] + 1, (args[10] - 1) // args[14] + 1
+            by_variant[args[16]] = by_variant.get(args[16], 0.0) + 2.0 * args[8] * Ho * Wo * args[12] * args[13] ** 2 * args[11]
+    dominant = max(by_variant, key=by_variant.get)
     sel = []
     for kind, fn, args in engine.plan:
         if kind != "conv":
@@ -108,7 +120,7 @@ def time_dominant_conv(engine, x, reps=3):
         B, H, W, cin, cout, k, s = args[8], args[9], args[10], args[11], args[12], args[13], args[14]
         Ho, Wo = (H - 1) // s + 1, (W - 1) // s + 1
         M = B * Ho * Wo
-        if cout > 64 and ((M + 127) // 128) * ((cout + 127) // 128) >= 512:
+        if args[16] == dominant:
             sel.append((fn, args, 2.0 * M * cout * k * k * cin))
     engine(x)
     torch.cuda.synchronize()
@@ -131,7 +143,7 @@ def time_dominant_conv(engine, x, reps=3):
     e1.record()
     torch.cuda.synchronize()
     det_ms = e0.elapsed_time(e1) / reps
-    return {"launches_per_forward": len(sel), "avg_launch_ms": tot_ms / max(n, 1),
+    return {"variant": dominant, "launches_per_forward": len(sel), "avg_launch_ms": tot_ms / max(n, 1),
             "tflops": tot_fl / (tot_ms * 1e-3) / 1e12 if tot_ms else 0.0,
             "flops_per_launch": tot_fl / max(n, 1), "detector_ms": det_ms,
             "detector_tflops": engine.flops / (det_ms * 1e-3) / 1e12}
@@ -238,7 +250,7 @@ def main():
     }
     if rank == 0 and not a.no_detail:
         d = time_dominant_conv(engine, x0)
-        line["roofline"] = {"bound": "mfma", "kernel": "k_conv_igemm<128,128,2,2>",
+        line["roofline"] = {"bound": "mfma", "kernel": CONV_KERNEL_NAMES.get(d["variant"], f"conv variant {d['variant']}"),
                             "achieved": round(d["tflops"], 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                             "frac": round(d["tflops"] / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None,
                             "avg_launch_ms": round(d["avg_launch_ms"], 4), "launches_per_step": d["launches_per_forward"],

@@ -50,7 +50,8 @@ int adayolo_conv_fwd(const void* in, int in_cstride,
 
 /*
  * Same as adayolo_conv_fwd with an explicit kernel variant (tuning / A-B measurements; results are identical):
- * 0 = library default, 1 = register-staged tile loads, 2/3/4 = LDS-DMA ring with 2/3/4 stages.
+ * 0 = library default, 1 = register-staged tile loads, 2/3/4 = LDS-DMA ring with 2/3/4 stages (16x16x32 MFMA),
+ * 5/6 = lean-address LDS-DMA ring with 2/3 stages (32x32x16 MFMA).
  */
 int adayolo_conv_fwd_variant(const void* in, int in_cstride,
                              const void* weight, const float* bias,
