@@ -15,6 +15,7 @@ OP_ZERO, OP_EXPOSURE, OP_GAMMA, OP_CCM, OP_SHARPEN, OP_NLM, OP_TONE = -1, 0, 1, 
 OP_CONTRAST, OP_SATPLUS, OP_WNB, OP_WB, OP_USM, OP_SHARPEN_V2, OP_COLOR = 6, 7, 8, 9, 10, 11, 12
 MAX_PARAMS = 24
 CLIP01 = 1
+NLM_EXACT = 2      # NLM patch sums in the reference's running-sum order (slower); default is the separable kernel
 ABI_VERSION = 3
 
 EXPORTS = ("adaisp_forward", "adaisp_process", "adaisp_backward_params", "adaisp_pool64", "adaisp_num_params",
@@ -79,7 +80,7 @@ def _img_shape(img):
     return int(img.shape[0]), int(img.shape[2]), int(img.shape[3])
 
 
-def process(op, img, params, clip=False, out=None):
+def process(op, img, params, clip=False, out=None, nlm_exact=False):
     """adaisp_process: one host-known op for the whole batch. params [B,n] (regressed)."""
     L = load()
     img = _dev_f32(img, "img")
@@ -89,12 +90,12 @@ def process(op, img, params, clip=False, out=None):
         out = torch.empty_like(img)
     with torch.cuda.device(img.device):
         rc = L.adaisp_process(int(op), img.data_ptr(), out.data_ptr(), params.data_ptr(), params.shape[1], B, H, W,
-                              CLIP01 if clip else 0, _stream())
+                              (CLIP01 if clip else 0) | (NLM_EXACT if nlm_exact else 0), _stream())
     _check(rc, "adaisp_process")
     return out
 
 
-def forward(img, op_ids, params, clip=True, pooled=None, out=None):
+def forward(img, op_ids, params, clip=True, pooled=None, out=None, nlm_exact=False):
     """adaisp_forward: image b is filtered by op_ids[b] (int32, device). params [B,stride]."""
     L = load()
     img = _dev_f32(img, "img")
@@ -108,7 +109,7 @@ def forward(img, op_ids, params, clip=True, pooled=None, out=None):
     with torch.cuda.device(img.device):
         rc = L.adaisp_forward(img.data_ptr(), out.data_ptr(), pooled.data_ptr() if pooled is not None else None,
                               op_ids.data_ptr(), params.data_ptr(), params.shape[1], B, H, W,
-                              CLIP01 if clip else 0, _stream())
+                              (CLIP01 if clip else 0) | (NLM_EXACT if nlm_exact else 0), _stream())
     _check(rc, "adaisp_forward")
     return out
 

@@ -246,7 +246,7 @@ __global__ __launch_bounds__(kThreads) void k_bwd_conv(const float* __restrict__
 }  // namespace
 
 hipError_t launch_nlm_backward(const float* img, const float* grad_out, const int32_t* ids, const float* params,
-                               int pstride, float* grad_params, int B, int H, int W, hipStream_t s);
+                               int pstride, float* grad_params, int B, int H, int W, unsigned flags, hipStream_t s);
 
 hipError_t launch_backward_params(const float* img, const float* grad_out, const int32_t* ids, const float* params,
                                   int pstride, float* grad_params, int B, int H, int W, unsigned flags, hipStream_t s) {
@@ -263,7 +263,7 @@ hipError_t launch_backward_params(const float* img, const float* grad_out, const
                            grad_params, H, W);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
-    return launch_nlm_backward(img, grad_out, ids, params, pstride, grad_params, B, H, W, s);
+    return launch_nlm_backward(img, grad_out, ids, params, pstride, grad_params, B, H, W, flags, s);
 }
 
 }  // namespace adaisp

@@ -15,8 +15,11 @@
 //   * weights/accumulators (3 colour sums + 1 weight sum per pixel) never leave registers; shifts are
 //     visited x-shift outer / y-shift inner like the reference, so num/den round the same way.
 //
-// No barriers inside the 121-shift loop. Compute-bound on the fp32 VALU (≈3.3 kflop/px + 363
-// sqrt/div/exp per px), not on HBM (24 B/px).
+//   * consecutive y-shifts (dy, dy+1) are processed as packed fp32 pairs (v_pk_add_f32 / v_pk_mul_f32), which halves
+//     the instruction count of the patch sums; the weight is exp2(v_sqrt(D) * c) on the hardware units.
+//
+// No barriers inside the 121-shift loop. Compute-bound on the fp32 VALU (≈3.3 kflop/px + 242
+// transcendentals per px), not on HBM (24 B/px).
 #include "isp_internal.h"
 
 namespace adaisp {
@@ -31,6 +34,23 @@ constexpr int YROWS = TH + 2 * HY;            // 46
 constexpr int CP = TW + 2 * SR;               // 74
 constexpr int CROWS = TH + 2 * SR;            // 42
 constexpr int NK = RPT + 2 * PR;              // 12 rows of squared differences per column
+constexpr int kYBytes = ((YROWS * YP * 8 + 15) / 16) * 16;
+constexpr int kSmemBytes = kYBytes + 3 * CROWS * CP * 4;
+
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+// (a.lo - b.lo, a.lo - b.hi) and (a.hi - b.lo, a.hi - b.hi): packed subtract with one half of `a` broadcast
+// through the VOP3P operand selects (no v_mov to build the splat).
+__device__ __forceinline__ v2f pk_sub_bcast_lo(v2f a, v2f b) {
+    v2f d;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel_hi:[0,1] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+__device__ __forceinline__ v2f pk_sub_bcast_hi(v2f a, v2f b) {
+    v2f d;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
 
 __device__ __forceinline__ int wrap(int v, int n) {
     v %= n;
@@ -45,8 +65,11 @@ __global__ __launch_bounds__(kThreads) void k_nlm(const float* __restrict__ img,
                                                   const int32_t* __restrict__ ids, int uniform_op,
                                                   const float* __restrict__ params, int pstride, int H, int W,
                                                   const float* __restrict__ grad_out, float* __restrict__ grad_params) {
-    __shared__ float ylds[YROWS * YP];
-    __shared__ float clds[3 * CROWS * CP];
+    // LDS (dynamic, 66 KB): luminance as (y[row], y[row-1]) pairs so that the operands of two consecutive y-shifts
+    // are ONE aligned ds_read_b64, then the three clamped colour planes
+    extern __shared__ __attribute__((aligned(16))) unsigned char nlm_smem[];
+    v2f* ylds2 = reinterpret_cast<v2f*>(nlm_smem);                           // [YROWS][YP]
+    float* clds = reinterpret_cast<float*>(nlm_smem + kYBytes);              // [3][CROWS][CP]
 
     const int b = blockIdx.z;
     const int op = ids ? ids[b] : uniform_op;
@@ -63,7 +86,9 @@ __global__ __launch_bounds__(kThreads) void k_nlm(const float* __restrict__ img,
         const int gy = wrap(y0 + ly - HY, H), gx = wrap(x0 + lx - HY, W);
         const long g = (long)gy * W + gx;
         const float r = clamp01(in[g]), gg = clamp01(in[g + plane]), bb = clamp01(in[g + 2 * plane]);
-        ylds[q] = (0.299f * r + 0.587f * gg) + 0.114f * bb;     // denoise.py:17
+        const float yv = (0.299f * r + 0.587f * gg) + 0.114f * bb;     // denoise.py:17
+        reinterpret_cast<float*>(ylds2)[2 * q] = yv;                       // .x of row ly
+        if (ly + 1 < YROWS) reinterpret_cast<float*>(ylds2)[2 * (q + YP) + 1] = yv;   // .y of row ly+1
         const int cy = ly - PR, cx = lx - PR;
         if (cy >= 0 && cy < CROWS && cx >= 0 && cx < CP) {
             clds[(0 * CROWS + cy) * CP + cx] = r;
@@ -77,13 +102,15 @@ __global__ __launch_bounds__(kThreads) void k_nlm(const float* __restrict__ img,
     const int rb = ty * RPT;                       // first output row of this lane inside the tile
     const float hh = fmaxf(params[(long)b * pstride], 0.0f) + 1e-8f;   // relu(h) + EPS, denoise.py:113
 
-    // centre luminances: 5 patch columns x 12 rows, fixed for all 121 shifts
-    float yc[2 * PR + 1][NK];
+    // centre luminances: 5 patch columns x 12 rows, fixed for all 121 shifts; kept as register pairs (rows 2j, 2j+1)
+    v2f ycp[2 * PR + 1][NK / 2];
 #pragma unroll
     for (int bi = 0; bi < 2 * PR + 1; ++bi)        // bi = bx + PR
 #pragma unroll
-        for (int k = 0; k < NK; ++k)
-            yc[bi][k] = ylds[(rb + HY - PR + k) * YP + tx + HY - (bi - PR)];
+        for (int j = 0; j < NK / 2; ++j) {
+            const v2f* q = ylds2 + (rb + HY - PR + 2 * j) * YP + tx + HY - (bi - PR);
+            ycp[bi][j] = v2f{q[0].x, q[YP].x};
+        }
 
     float num[3][RPT], den[RPT];
     float ga[GRAD ? 3 : 1][GRAD ? RPT : 1], gb[GRAD ? RPT : 1];
@@ -95,44 +122,79 @@ __global__ __launch_bounds__(kThreads) void k_nlm(const float* __restrict__ img,
     }
     const float inv_hh2 = 1.0f / (hh * hh);
 
+    // exp(-dist/hh) = exp2(dist * nc): one multiply + the hardware exp2 (the relative error |x|*2^-24 only matters
+    // for weights far too small to contribute); v_sqrt_f32 is within 1 ulp.
+    const float nc = -1.44269504088896341f / hh;
+
+    // One shift: patch distance for the 8 pixels in the reference's summation order, then the weighted sums.
+    auto accumulate = [&](int r, float Dr, const float* cs) {
+        const float dist = __builtin_amdgcn_sqrtf(fmaxf(Dr, 0.0f));
+        const float wgt = __builtin_amdgcn_exp2f(dist * nc);
+        const float c0 = cs[(0 * CROWS + r) * CP], c1 = cs[(1 * CROWS + r) * CP], c2 = cs[(2 * CROWS + r) * CP];
+        num[0][r] += c0 * wgt;
+        num[1][r] += c1 * wgt;
+        num[2][r] += c2 * wgt;
+        den[r] += wgt;
+        if (GRAD) {
+            const float dw = wgt * dist * inv_hh2;
+            ga[0][r] = fmaf(c0, dw, ga[0][r]);
+            ga[1][r] = fmaf(c1, dw, ga[1][r]);
+            ga[2][r] = fmaf(c2, dw, ga[2][r]);
+            gb[r] += dw;
+        }
+    };
+
     for (int dx = -SR; dx <= SR; ++dx) {           // x_shift outer   (denoise.py:104)
-        for (int dy = -SR; dy <= SR; ++dy) {       // y_shift inner   (denoise.py:105)
-            // shifted value at (i,j) is the source at (i-dy, j-dx)
-            const float* ys = ylds + (rb + HY - PR - dy) * YP + tx + HY - dx;
+        // y shifts are visited in ascending order like the reference (denoise.py:105); two consecutive shifts
+        // (dy, dy+1) share every centre luminance, so their squared differences and patch sums run as packed
+        // fp32 pairs (v_pk_add/mul_f32: two IEEE results per instruction, same rounding as the scalar ops).
+        for (int dy = -SR; dy + 1 <= SR; dy += 2) {
+            const v2f* ys = ylds2 + (rb + HY - PR - dy) * YP + tx + HY - dx;      // .x: rows for shift dy, .y: one row up (dy+1)
+            v2f D2[RPT];
+#pragma unroll
+            for (int r = 0; r < RPT; ++r) D2[r] = v2f{0.0f, 0.0f};
+#pragma unroll
+            for (int bi = 0; bi < 2 * PR + 1; ++bi) {      // patch column bx = bi - PR, outer (denoise.py:60)
+                v2f sq2[NK];
+#pragma unroll
+                for (int k = 0; k < NK; ++k) {
+                    const v2f sh = ys[k * YP - (bi - PR)];                // (shift dy, shift dy+1) in one ds_read_b64
+                    const v2f d = (k & 1) ? pk_sub_bcast_hi(ycp[bi][k >> 1], sh) : pk_sub_bcast_lo(ycp[bi][k >> 1], sh);
+                    sq2[k] = d * d;
+                }
+#pragma unroll
+                for (int byi = 0; byi < 2 * PR + 1; ++byi)  // patch row by = byi - PR, inner (denoise.py:61)
+#pragma unroll
+                    for (int r = 0; r < RPT; ++r) D2[r] += sq2[r + PR - (byi - PR)];
+            }
+            const float* cs0 = clds + (rb + SR - dy) * CP + tx + SR - dx;
+#pragma unroll
+            for (int r = 0; r < RPT; ++r) accumulate(r, D2[r].x, cs0);
+#pragma unroll
+            for (int r = 0; r < RPT; ++r) accumulate(r, D2[r].y, cs0 - CP);
+        }
+        {   // the eleventh shift (dy = +SR) has no partner
+            const int dy = SR;
+            const v2f* ys = ylds2 + (rb + HY - PR - dy) * YP + tx + HY - dx;
             float D[RPT];
 #pragma unroll
             for (int r = 0; r < RPT; ++r) D[r] = 0.0f;
 #pragma unroll
-            for (int bi = 0; bi < 2 * PR + 1; ++bi) {      // patch column bx = bi - PR, outer (denoise.py:60)
+            for (int bi = 0; bi < 2 * PR + 1; ++bi) {
                 float sq[NK];
 #pragma unroll
                 for (int k = 0; k < NK; ++k) {
-                    const float d = yc[bi][k] - ys[k * YP - (bi - PR)];
+                    const float d = ycp[bi][k >> 1][k & 1] - ys[k * YP - (bi - PR)].x;
                     sq[k] = d * d;
                 }
 #pragma unroll
-                for (int byi = 0; byi < 2 * PR + 1; ++byi)  // patch row by = byi - PR, inner (denoise.py:61)
+                for (int byi = 0; byi < 2 * PR + 1; ++byi)
 #pragma unroll
                     for (int r = 0; r < RPT; ++r) D[r] += sq[r + PR - (byi - PR)];
             }
             const float* cs = clds + (rb + SR - dy) * CP + tx + SR - dx;
 #pragma unroll
-            for (int r = 0; r < RPT; ++r) {
-                const float dist = __fsqrt_rn(fmaxf(D[r], 0.0f));
-                const float wgt = expf(-dist / hh);
-                const float c0 = cs[(0 * CROWS + r) * CP], c1 = cs[(1 * CROWS + r) * CP], c2 = cs[(2 * CROWS + r) * CP];
-                num[0][r] += c0 * wgt;
-                num[1][r] += c1 * wgt;
-                num[2][r] += c2 * wgt;
-                den[r] += wgt;
-                if (GRAD) {
-                    const float dw = wgt * dist * inv_hh2;
-                    ga[0][r] = fmaf(c0, dw, ga[0][r]);
-                    ga[1][r] = fmaf(c1, dw, ga[1][r]);
-                    ga[2][r] = fmaf(c2, dw, ga[2][r]);
-                    gb[r] += dw;
-                }
-            }
+            for (int r = 0; r < RPT; ++r) accumulate(r, D[r], cs);
         }
     }
 
@@ -176,19 +238,216 @@ __global__ __launch_bounds__(kThreads) void k_nlm(const float* __restrict__ img,
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------
+// Separable variant (default). The 5x5 patch sum is a column sum (5 rows, in-lane, in the reference's patch-row
+// order) followed by a row sum over the 5 neighbouring columns, which live in the neighbouring LANES: they are
+// fetched with DPP wave shifts folded into the adds (v_add_f32_dpp wave_shl/shr), no LDS traffic. Per pixel and
+// shift that is 2 + 4 + 4 flops instead of 50, and the lane only keeps its own 12 centre luminances (12 VGPRs
+// instead of 60 -> 3+ waves/SIMD). The association of the 25-term sum differs from the reference's single running
+// sum (5 partial sums of 5), i.e. ~1 ulp of the patch distance; measured against the oracle in the parity tests
+// (rtol 1e-5). The reference-order kernel above stays available through ADAISP_NLM_EXACT.
+// A wave covers 64 columns but only its inner 60 are complete (2 on each side lack neighbours): tiles advance by 60.
+// ---------------------------------------------------------------------------------------------------------
+constexpr int SW = 60;                          // valid columns per wave
+constexpr int SP = 64 + 2 * SR;                 // staged columns: x0-2-5 .. x0+61+5  (74)
+constexpr int kSepBytes = (YROWS * SP + 3 * CROWS * SP) * 4;
+
+// (the wave's end lanes keep their own value: they belong to the 2+2 columns that are discarded anyway)
+__device__ __forceinline__ float lane_up(float v) {     // value of lane+1
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0x130, 0xF, 0xF, false));
+}
+__device__ __forceinline__ float lane_down(float v) {   // value of lane-1
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0x138, 0xF, 0xF, false));
+}
+
+template <bool GRAD>
+__global__ __launch_bounds__(kThreads) void k_nlm_sep(const float* __restrict__ img, float* __restrict__ out,
+                                                      const int32_t* __restrict__ ids, int uniform_op,
+                                                      const float* __restrict__ params, int pstride, int H, int W,
+                                                      const float* __restrict__ grad_out,
+                                                      float* __restrict__ grad_params) {
+    __shared__ float ylds[YROWS * SP];
+    __shared__ float clds[3 * CROWS * SP];
+    const int b = blockIdx.z;
+    const int op = ids ? ids[b] : uniform_op;
+    if (op != ADAISP_OP_NLM) return;
+    const long plane = (long)H * W;
+    const float* __restrict__ in = img + (long)b * 3 * plane;
+    const int x0 = blockIdx.x * SW, y0 = blockIdx.y * TH;
+    const int tid = threadIdx.x;
+
+    // staged column c <-> image column x0 - 2 - SR + c ; y rows start at y0 - HY, colour rows at y0 - SR
+    for (int q = tid; q < YROWS * SP; q += kThreads) {
+        const int ly = q / SP, lx = q - ly * SP;
+        const int gy = wrap(y0 + ly - HY, H), gx = wrap(x0 - 2 - SR + lx, W);
+        const long g = (long)gy * W + gx;
+        const float r = clamp01(in[g]), gg = clamp01(in[g + plane]), bb = clamp01(in[g + 2 * plane]);
+        ylds[q] = (0.299f * r + 0.587f * gg) + 0.114f * bb;
+        const int cy = ly - PR;
+        if (cy >= 0 && cy < CROWS) {
+            clds[(0 * CROWS + cy) * SP + lx] = r;
+            clds[(1 * CROWS + cy) * SP + lx] = gg;
+            clds[(2 * CROWS + cy) * SP + lx] = bb;
+        }
+    }
+    __syncthreads();
+
+    const int lane = tid & 63, ty = tid >> 6;
+    const int rb = ty * RPT;
+    const float hh = fmaxf(params[(long)b * pstride], 0.0f) + 1e-8f;
+    const float nc = -1.44269504088896341f / hh;
+    const float inv_hh2 = 1.0f / (hh * hh);
+
+    float yc[NK];                                  // this lane's own column, rows rb-2 .. rb+9
+#pragma unroll
+    for (int k = 0; k < NK; ++k) yc[k] = ylds[(rb + HY - PR + k) * SP + lane + SR];
+
+    v2f num2[3][RPT / 2], den2[RPT / 2];
+    v2f ga2[GRAD ? 3 : 1][GRAD ? RPT / 2 : 1], gb2[GRAD ? RPT / 2 : 1];
+#pragma unroll
+    for (int r = 0; r < RPT / 2; ++r) { num2[0][r] = num2[1][r] = num2[2][r] = den2[r] = v2f{0.0f, 0.0f}; }
+    if (GRAD) {
+#pragma unroll
+        for (int r = 0; r < RPT / 2; ++r) { ga2[0][r] = ga2[1][r] = ga2[2][r] = gb2[r] = v2f{0.0f, 0.0f}; }
+    }
+
+    for (int dx = -SR; dx <= SR; ++dx) {
+        for (int dy = -SR; dy <= SR; ++dy) {
+            const float* ys = ylds + (rb + HY - PR - dy) * SP + lane + SR - dx;
+            float sq[NK];
+#pragma unroll
+            for (int k = 0; k < NK; ++k) {
+                const float d = yc[k] - ys[k * SP];
+                sq[k] = d * d;
+            }
+            const float* cs = clds + (rb + SR - dy) * SP + lane + SR - dx;
+            // pixels are finished in row pairs so that the weighting runs on packed fp32 (v_pk_mul/fma_f32)
+#pragma unroll
+            for (int rp = 0; rp < RPT / 2; ++rp) {
+                v2f D2;
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const int r = 2 * rp + e;
+                    // column sum, patch rows by = -2..2  <->  sq[r+4] .. sq[r]
+                    const float c = (((sq[r + 4] + sq[r + 3]) + sq[r + 2]) + sq[r + 1]) + sq[r];
+                    // row sum, patch columns bx = -2..2  <->  lanes +2 .. -2
+                    const float u1 = lane_up(c), u2 = lane_up(u1), d1 = lane_down(c), d2 = lane_down(d1);
+                    D2[e] = (((u2 + u1) + c) + d1) + d2;
+                }
+                D2 = __builtin_elementwise_max(D2, v2f{0.0f, 0.0f});
+                const v2f dist = v2f{__builtin_amdgcn_sqrtf(D2.x), __builtin_amdgcn_sqrtf(D2.y)};
+                const v2f ex = dist * nc;
+                const v2f wgt = v2f{__builtin_amdgcn_exp2f(ex.x), __builtin_amdgcn_exp2f(ex.y)};
+                const int r = 2 * rp;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const v2f cv = v2f{cs[(c * CROWS + r) * SP], cs[(c * CROWS + r + 1) * SP]};
+                    num2[c][rp] = __builtin_elementwise_fma(cv, wgt, num2[c][rp]);
+                    if (GRAD) ga2[c][rp] = __builtin_elementwise_fma(cv, wgt * dist * inv_hh2, ga2[c][rp]);
+                }
+                den2[rp] += wgt;
+                if (GRAD) gb2[rp] += wgt * dist * inv_hh2;
+            }
+        }
+    }
+    float num[3][RPT], den[RPT];
+    float ga[GRAD ? 3 : 1][GRAD ? RPT : 1], gb[GRAD ? RPT : 1];
+#pragma unroll
+    for (int rp = 0; rp < RPT / 2; ++rp)
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            den[2 * rp + e] = den2[rp][e];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) num[c][2 * rp + e] = num2[c][rp][e];
+            if (GRAD) {
+                gb[2 * rp + e] = gb2[rp][e];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) ga[c][2 * rp + e] = ga2[c][rp][e];
+            }
+        }
+
+    const int gx = x0 - 2 + lane;
+    const bool mine = lane >= 2 && lane < 2 + SW && gx < W;
+    if (!GRAD) {
+        float* __restrict__ o = out + (long)b * 3 * plane;
+        if (mine) {
+#pragma unroll
+            for (int r = 0; r < RPT; ++r) {
+                const int gy = y0 + rb + r;
+                if (gy < H) {
+                    const long g = (long)gy * W + gx;
+                    o[g] = clamp01(num[0][r] / den[r]);
+                    o[g + plane] = clamp01(num[1][r] / den[r]);
+                    o[g + 2 * plane] = clamp01(num[2][r] / den[r]);
+                }
+            }
+        }
+    } else {
+        float acc = 0.0f;
+        const float* go = grad_out + (long)b * 3 * plane;
+        if (mine && params[(long)b * pstride] > 0.0f) {
+#pragma unroll
+            for (int r = 0; r < RPT; ++r) {
+                const int gy = y0 + rb + r;
+                if (gy < H) {
+                    const long g = (long)gy * W + gx;
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        const float oc = num[c][r] / den[r];
+                        if (oc >= 0.0f && oc <= 1.0f) acc += go[g + c * plane] * (ga[c][r] - oc * gb[r]) / den[r];
+                    }
+                }
+            }
+        }
+        __shared__ float red[4];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+        if ((tid & 63) == 0) red[tid >> 6] = acc;
+        __syncthreads();
+        if (tid == 0) atomicAdd(grad_params + (long)b * pstride, (red[0] + red[1]) + (red[2] + red[3]));
+    }
+}
+
 }  // namespace
 
 hipError_t launch_nlm(const Batch& a, hipStream_t s) {
+    if (!(a.flags & ADAISP_NLM_EXACT)) {
+        dim3 g((a.W + SW - 1) / SW, (a.H + TH - 1) / TH, a.B);
+        hipLaunchKernelGGL(k_nlm_sep<false>, g, dim3(kThreads), 0, s, a.img, a.out, a.ids, a.uniform_op, a.params,
+                           a.pstride, a.H, a.W, static_cast<const float*>(nullptr), static_cast<float*>(nullptr));
+        return hipGetLastError();
+    }
     dim3 grid((a.W + TW - 1) / TW, (a.H + TH - 1) / TH, a.B);
-    hipLaunchKernelGGL(k_nlm<false>, grid, dim3(kThreads), 0, s, a.img, a.out, a.ids, a.uniform_op, a.params, a.pstride,
+    static bool configured = false;          // dynamic LDS above the 64 KB default (idempotent)
+    if (!configured) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_nlm<false>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, kSmemBytes);
+        if (e != hipSuccess) return e;
+        configured = true;
+    }
+    hipLaunchKernelGGL(k_nlm<false>, grid, dim3(kThreads), kSmemBytes, s, a.img, a.out, a.ids, a.uniform_op, a.params, a.pstride,
                        a.H, a.W, static_cast<const float*>(nullptr), static_cast<float*>(nullptr));
     return hipGetLastError();
 }
 
 hipError_t launch_nlm_backward(const float* img, const float* grad_out, const int32_t* ids, const float* params,
-                               int pstride, float* grad_params, int B, int H, int W, hipStream_t s) {
+                               int pstride, float* grad_params, int B, int H, int W, unsigned flags, hipStream_t s) {
+    if (!(flags & ADAISP_NLM_EXACT)) {
+        dim3 g((W + SW - 1) / SW, (H + TH - 1) / TH, B);
+        hipLaunchKernelGGL(k_nlm_sep<true>, g, dim3(kThreads), 0, s, img, static_cast<float*>(nullptr), ids, 0, params,
+                           pstride, H, W, grad_out, grad_params);
+        return hipGetLastError();
+    }
     dim3 grid((W + TW - 1) / TW, (H + TH - 1) / TH, B);
-    hipLaunchKernelGGL(k_nlm<true>, grid, dim3(kThreads), 0, s, img, static_cast<float*>(nullptr), ids, 0, params,
+    static bool configured = false;
+    if (!configured) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_nlm<true>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, kSmemBytes);
+        if (e != hipSuccess) return e;
+        configured = true;
+    }
+    hipLaunchKernelGGL(k_nlm<true>, grid, dim3(kThreads), kSmemBytes, s, img, static_cast<float*>(nullptr), ids, 0, params,
                        pstride, H, W, grad_out, grad_params);
     return hipGetLastError();
 }

@@ -49,6 +49,8 @@ enum adaisp_op {
 
 /* flags */
 #define ADAISP_CLIP01 1u /* clamp the result to [0,1]: Filter.forward's final clip, isp/filters.py:125 */
+#define ADAISP_NLM_EXACT 2u /* NLM: add the 25 patch terms in the reference's single running-sum order
+                               (isp/denoise.py:60-63) instead of the default 5x5 separable association; ~3.5x slower */
 
 /* error codes */
 #define ADAISP_OK          0

@@ -57,6 +57,20 @@ def test_golden_nlm_wrap(golden, tag):
     np.testing.assert_allclose(out, g[f"{tag}.out"], rtol=RTOL, atol=ATOL)
 
 
+@pytest.mark.parametrize("tag", ["a", "tiny", "odd"])
+def test_nlm_reference_order_kernel(golden, oracle_mod, tag):
+    """ADAISP_NLM_EXACT: the 25 patch terms in the reference's running-sum order; and how far the default
+    (separable association) is from it."""
+    from adaptiveisp_amd import _lib
+    g = golden("nlm")
+    img, h = torch.from_numpy(g[f"{tag}.img"]).to(dev()), torch.from_numpy(g[f"{tag}.h"]).to(dev())
+    exact = _lib.process(OPS["NLM"], img, h, clip=True, nlm_exact=True).cpu().numpy()
+    fast = _lib.process(OPS["NLM"], img, h, clip=True).cpu().numpy()
+    np.testing.assert_allclose(exact, g[f"{tag}.out"], rtol=RTOL, atol=ATOL)
+    np.testing.assert_allclose(fast, g[f"{tag}.out"], rtol=RTOL, atol=ATOL)
+    assert np.abs(fast - exact).max() < 2e-6
+
+
 @pytest.mark.parametrize("tag", ["a", "small", "exact", "hd"])
 def test_golden_pool64(golden, tag):
     from adaptiveisp_amd import _lib
