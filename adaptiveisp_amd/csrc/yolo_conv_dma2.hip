@@ -279,6 +279,8 @@ hipError_t launch_conv_dma2(ConvArgs a, hipStream_t s, int variant) {
     if (variant == 13) return launch<256, 256, 4, 2, 2>(a, s);       // 8 waves, 256 px x 256 ch, wave tile 64 px x 128 ch
     if (variant == 14) return launch<256, 256, 4, 2, 2, 1>(a, s);
     if (variant == 15) return launch<256, 256, 4, 2, 2, 2>(a, s);
+    if (variant == 22) return launch<128, 64, 4, 1, 4, 0, 32>(a, s);    // small Cin/Cout: BK=32 (no half-empty k-steps at Cin=32)
+    if (variant == 24) return launch<256, 128, 4, 2, 4, 0, 32>(a, s);   // 8 waves, 256 px x 128 ch, BK=32
     if (variant == 20) return launch<256, 256, 4, 2, 2, 3>(a, s);     // ablation: MFMA only
     if (variant == 21) return launch<256, 256, 4, 2, 2, 4>(a, s);     // ablation: LDS reads only
     if (variant == 16) return launch<256, 256, 4, 2, 4, 0, 32>(a, s);   // BK=32, 4-stage ring (128 KB), 3 steps of look-ahead

@@ -144,38 +144,42 @@ hipError_t launch_upsample2x(const void* in, int in_cs, void* out, int out_cs, i
 // ---------------------------------------------------------------------------------------------------
 // Detect decode (eval branch of Detect.forward, yolov3/models/yolo.py:56-76).
 // ---------------------------------------------------------------------------------------------------
+// grid: x over the (cell, channel) pairs of one anchor map, y = anchor, z = image. Consecutive lanes walk the 85
+// channels of a cell (contiguous bf16 reads, contiguous fp32 writes); one constant division per element.
 __global__ __launch_bounds__(256) void k_detect_decode(const unsigned short* __restrict__ raw, int raw_cs,
                                                        float* __restrict__ pred, int pred_rows, int row_offset,
-                                                       const float* __restrict__ anchors_px, float det_stride, int B,
-                                                       int ny, int nx, int na, int no) {
-    const long total = (long)B * na * ny * nx * no;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-        const int j = (int)(i % no);
-        long c = i / no;
-        const int x = (int)(c % nx); c /= nx;
-        const int y = (int)(c % ny); c /= ny;
-        const int an = (int)(c % na);
-        const long b = c / na;
-        const float t = bf2f(raw[((b * ny + y) * nx + x) * raw_cs + an * no + j]);
-        const float s = 1.0f / (1.0f + expf(-t));
+                                                       const float* __restrict__ anchors_px, float det_stride, int ny,
+                                                       int nx, int na, int no) {
+    const int an = blockIdx.y;
+    const long b = blockIdx.z;
+    const int per_map = ny * nx * no;
+    const float aw = anchors_px[2 * an], ah = anchors_px[2 * an + 1];
+    const unsigned short* src = raw + b * ny * nx * raw_cs + an * no;
+    float* dst = pred + (b * pred_rows + row_offset + (long)an * ny * nx) * no;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < per_map; i += gridDim.x * 256) {
+        const int cell = i / no, j = i - cell * no;
+        const float t = bf2f(src[(long)cell * raw_cs + j]);
+        const float s = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504088896341f * t));
         float v = s;
-        if (j == 0) v = (s * 2.0f + ((float)x - 0.5f)) * det_stride;
-        else if (j == 1) v = (s * 2.0f + ((float)y - 0.5f)) * det_stride;
-        else if (j == 2) v = (s * 2.0f) * (s * 2.0f) * anchors_px[2 * an];
-        else if (j == 3) v = (s * 2.0f) * (s * 2.0f) * anchors_px[2 * an + 1];
-        pred[(b * pred_rows + row_offset + ((long)an * ny + y) * nx + x) * no + j] = v;
+        if (j < 4) {
+            const int y = cell / nx, x = cell - y * nx;
+            const float s2 = s * 2.0f;
+            v = (j == 0) ? (s2 + ((float)x - 0.5f)) * det_stride
+              : (j == 1) ? (s2 + ((float)y - 0.5f)) * det_stride
+              : (j == 2) ? s2 * s2 * aw : s2 * s2 * ah;
+        }
+        dst[i] = v;
     }
 }
 
 hipError_t launch_detect_decode(const void* raw, int raw_cs, float* pred, int pred_rows, int row_offset,
                                 const float* anchors_px, float det_stride, int B, int ny, int nx, int na, int no,
                                 hipStream_t s) {
-    const long total = (long)B * na * ny * nx * no;
-    long blocks = (total + 255) / 256;
-    if (blocks > 8192) blocks = 8192;
-    hipLaunchKernelGGL(k_detect_decode, dim3((unsigned)blocks), dim3(256), 0, s,
-                       static_cast<const unsigned short*>(raw), raw_cs, pred, pred_rows, row_offset, anchors_px,
-                       det_stride, B, ny, nx, na, no);
+    const int per_map = ny * nx * no;
+    int bx = (per_map + 255) / 256;
+    if (bx > 1024) bx = 1024;
+    hipLaunchKernelGGL(k_detect_decode, dim3(bx, na, B), dim3(256), 0, s, static_cast<const unsigned short*>(raw),
+                       raw_cs, pred, pred_rows, row_offset, anchors_px, det_stride, ny, nx, na, no);
     return hipGetLastError();
 }
 

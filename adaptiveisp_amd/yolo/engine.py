@@ -171,7 +171,7 @@ class YoloEngine:
         self.views = view
 
     # ------------------------------------------------------------------------------------------
-    TUNE_CANDIDATES = (2, 5, 12, 13, 18, 19)
+    TUNE_CANDIDATES = (2, 5, 12, 13, 18, 19, 22, 24)
 
     def autotune(self, reps=3):
         """Pick the fastest conv kernel variant per layer by timing it on this engine's own buffers (all variants

@@ -32,7 +32,9 @@ MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 peak
 CONV_KERNEL_NAMES = {1: "k_conv_igemm<128,128,2,2>", 2: "dma::k_conv_igemm_dma<128,128,2,2,2>",
                      5: "dma2::k_conv_igemm_dma32<128,128,2,2,2,0,64>", 12: "dma2::k_conv_igemm_dma32<256,128,4,2,2,0,64>",
                      13: "dma2::k_conv_igemm_dma32<256,256,4,2,2,0,64>", 18: "dma2::k_conv_igemm_dma32<128,128,2,2,4,0,32>",
-                     19: "dma2::k_conv_igemm_dma32<128,256,2,4,3,0,32>"}
+                     19: "dma2::k_conv_igemm_dma32<128,256,2,4,3,0,32>", 22: "dma2::k_conv_igemm_dma32<128,64,4,1,4,0,32>",
+                     23: "dma2::k_conv_igemm_dma32<256,64,8,1,4,0,32>", 24: "dma2::k_conv_igemm_dma32<256,128,4,2,4,0,32>",
+                     25: "dma2::k_conv_igemm_dma32<128,32,4,1,4,0,32>"}
 
 
 def parse():
