@@ -113,7 +113,7 @@ int adaisp_backward_params(const float* img, const float* grad_out, const int32_
 int adaisp_policy_conv(const float* in, const float* states, int n_state, const float* w, const float* bias, float* out,
                        int G, int B, int Cin, int Hin, int Cout, void* stream) {
     if (!in || !w || !bias || !out || G <= 0 || B <= 0 || Cin <= 0 || Hin <= 1 || Cout <= 0) return ADAISP_EINVAL;
-    if (Cout % 8 || Hin % 2 || G > 65535 || (states && (Cin < 3 || n_state != Cin - 3))) return ADAISP_ESHAPE;
+    if (Cout % 8 || Hin % 2 || G > 65535 || Cin > 128 || (states && (Cin < 3 || n_state != Cin - 3))) return ADAISP_ESHAPE;
     return launch_policy_conv(in, states, n_state, w, bias, out, G, B, Cin, Hin, Cout,
                               static_cast<hipStream_t>(stream)) == hipSuccess ? ADAISP_OK : ADAISP_ELAUNCH;
 }
@@ -121,7 +121,7 @@ int adaisp_policy_conv(const float* in, const float* states, int n_state, const 
 int adaisp_policy_fc1(const float* feats, const int32_t* head_src, const float* w1, const float* b1, float* hidden,
                       int B, int D, int NH, int HID, void* stream) {
     if (!feats || !head_src || !w1 || !b1 || !hidden || B <= 0 || D <= 0 || NH <= 0 || HID <= 0) return ADAISP_EINVAL;
-    if (D % 4) return ADAISP_ESHAPE;
+    if (D % 1024 || HID % 4) return ADAISP_ESHAPE;     // 4 waves x 64 lanes x float4 per trip; 4 neurons per workgroup
     return launch_policy_fc1(feats, head_src, w1, b1, hidden, B, D, NH, HID, static_cast<hipStream_t>(stream)) ==
                    hipSuccess ? ADAISP_OK : ADAISP_ELAUNCH;
 }

@@ -37,7 +37,9 @@ __global__ __launch_bounds__(1024) void k_trunk_conv(const float* __restrict__ i
                                                      int n_state, const float* __restrict__ w,
                                                      const float* __restrict__ bias, float* __restrict__ out, int B,
                                                      int Cin, int Hin, int Cout, int KS) {
-    extern __shared__ float part[];                             // [KS][CO_PER][PX_PER]
+    // LDS: this workgroup's weights [Cin][CO_PER][16] (staged once with coalesced loads, then read back as
+    // wave-uniform broadcasts), later reused for the partial sums [KS][CO_PER][PX_PER]
+    extern __shared__ __attribute__((aligned(16))) float lds[];
     const int Ho = Hin >> 1;
     const int g = blockIdx.z, co0 = blockIdx.y * CO_PER;
     const int lane = threadIdx.x & 63, ks = threadIdx.x >> 6;
@@ -47,6 +49,12 @@ __global__ __launch_bounds__(1024) void k_trunk_conv(const float* __restrict__ i
     const int pid = live ? idx : 0;
     const int b = pid / (Ho * Ho), r = pid - b * Ho * Ho, oy = r / Ho, ox = r - oy * Ho;
     const float* wg = w + ((long)g * Cout + co0) * Cin * 16;
+    for (int i = threadIdx.x; i < Cin * CO_PER * 16; i += blockDim.x) {
+        const int c = i / (Cin * 16), rem = i - c * (Cin * 16);      // global order [c][ci][t] -> LDS [ci][c][t]
+        const int ci = rem >> 4, t = rem & 15;
+        lds[(ci * CO_PER + c) * 16 + t] = wg[i];
+    }
+    __syncthreads();
     float acc[CO_PER];
 #pragma unroll
     for (int c = 0; c < CO_PER; ++c) acc[c] = 0.0f;
@@ -61,27 +69,47 @@ __global__ __launch_bounds__(1024) void k_trunk_conv(const float* __restrict__ i
                              : in + ((long)g * B + b) * Cin * Hin * Hin;
     const int cps = (Cin + KS - 1) / KS;                        // channels per slice
     const int c_lo = ks * cps, c_hi = min(Cin, c_lo + cps);
-    for (int ci = c_lo; ci < c_hi; ++ci) {
-        float v[16];
-        if (ci < n_img) {
-            const float* p = ib + (long)ci * Hin * Hin + (2 * oy - 1) * Hin + (2 * ox - 1);
+    // four input channels per trip: all 64 window loads are issued before the first FMA needs one, so a wave pays the
+    // global-memory latency twice (8 channels per slice) instead of eight times
+    constexpr int CU = 2;
+    for (int cb = c_lo; cb < c_hi; cb += CU) {
+        float v[CU][16];
 #pragma unroll
-            for (int kh = 0; kh < 4; ++kh)
+        for (int u = 0; u < CU; ++u) {
+            const int ci = cb + u;
+            const bool cok = ci < c_hi;
+            if (ci < n_img) {
+                const float* p = ib + (long)(cok ? ci : c_lo) * Hin * Hin + (2 * oy - 1) * Hin + (2 * ox - 1);
 #pragma unroll
-                for (int kw = 0; kw < 4; ++kw) v[kh * 4 + kw] = (vy[kh] && vx[kw]) ? p[kh * Hin + kw] : 0.0f;
-        } else {
-            const float s = states[b * n_state + (ci - 3)];     // constant plane, still zero outside the frame
+                for (int kh = 0; kh < 4; ++kh)
 #pragma unroll
-            for (int kh = 0; kh < 4; ++kh)
+                    for (int kw = 0; kw < 4; ++kw) v[u][kh * 4 + kw] = (cok && vy[kh] && vx[kw]) ? p[kh * Hin + kw] : 0.0f;
+            } else {
+                const float s = cok ? states[b * n_state + (ci - 3)] : 0.0f;   // constant plane, zero outside the frame
 #pragma unroll
-                for (int kw = 0; kw < 4; ++kw) v[kh * 4 + kw] = (vy[kh] && vx[kw]) ? s : 0.0f;
+                for (int kh = 0; kh < 4; ++kh)
+#pragma unroll
+                    for (int kw = 0; kw < 4; ++kw) v[u][kh * 4 + kw] = (vy[kh] && vx[kw]) ? s : 0.0f;
+            }
         }
-        const float* wc = wg + ci * 16;
 #pragma unroll
-        for (int c = 0; c < CO_PER; ++c)
+        for (int u = 0; u < CU; ++u) {
+            const int ci = min(cb + u, Cin - 1);                  // (values are zero when cb+u is past the slice)
+            const float4* wl = reinterpret_cast<const float4*>(lds + ci * CO_PER * 16);
 #pragma unroll
-            for (int t = 0; t < 16; ++t) acc[c] = fmaf(v[t], wc[(long)c * Cin * 16 + t], acc[c]);
+            for (int c = 0; c < CO_PER; ++c)
+#pragma unroll
+                for (int t4 = 0; t4 < 4; ++t4) {
+                    const float4 wv = wl[c * 4 + t4];             // same address in every lane: LDS broadcast
+                    acc[c] = fmaf(v[u][4 * t4 + 0], wv.x, acc[c]);
+                    acc[c] = fmaf(v[u][4 * t4 + 1], wv.y, acc[c]);
+                    acc[c] = fmaf(v[u][4 * t4 + 2], wv.z, acc[c]);
+                    acc[c] = fmaf(v[u][4 * t4 + 3], wv.w, acc[c]);
+                }
+        }
     }
+    __syncthreads();                                            // weights no longer needed: reuse LDS for the partials
+    float* part = lds;
 #pragma unroll
     for (int c = 0; c < CO_PER; ++c) part[(ks * CO_PER + c) * PX_PER + lane] = acc[c];
     __syncthreads();
@@ -94,47 +122,69 @@ __global__ __launch_bounds__(1024) void k_trunk_conv(const float* __restrict__ i
 }
 
 // ---- fc1 of every head: hidden[b][h][j] = lrelu(b1[h][j] + feats[src(h)][b][:] . w1[h][j][:]) ------------
+// Workgroup = 4 neurons of one head x the whole batch. The four waves split the 4096-long reduction, so every
+// feature vector is fetched once per 4 neurons (not once per neuron) and each lane has only D/4/64/4 = 4 trips,
+// two of them in flight; partial sums meet in LDS.
 constexpr int FC_MAXB = 8;
+constexpr int FC_NPB = 4;
 
 __global__ __launch_bounds__(256) void k_fc1(const float* __restrict__ feats, const int32_t* __restrict__ head_src,
                                              const float* __restrict__ w1, const float* __restrict__ b1,
                                              float* __restrict__ hidden, int B, int D, int NH, int HID) {
+    __shared__ float part[4][FC_NPB * FC_MAXB];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int neuron = blockIdx.x * 4 + wave;                 // over NH*HID
-    if (neuron >= NH * HID) return;
-    const int h = neuron / HID;
-    const float4* wr = reinterpret_cast<const float4*>(w1 + (long)neuron * D);
+    const int n0 = blockIdx.x * FC_NPB;                        // first neuron (over NH*HID); HID % FC_NPB == 0
+    const int h = n0 / HID;
     const float* fb = feats + (long)head_src[h] * B * D;
+    const int q4 = D / 16;                                     // float4 per wave-quarter of the reduction
     for (int b0 = 0; b0 < B; b0 += FC_MAXB) {
         const int nb = min(FC_MAXB, B - b0);
-        float acc[FC_MAXB];
+        float acc[FC_NPB][FC_MAXB];
 #pragma unroll
-        for (int i = 0; i < FC_MAXB; ++i) acc[i] = 0.0f;
-#pragma unroll 4
-        for (int k = lane; k < D / 4; k += 64) {
-            const float4 wv = wr[k];
+        for (int n = 0; n < FC_NPB; ++n)
+#pragma unroll
+            for (int i = 0; i < FC_MAXB; ++i) acc[n][i] = 0.0f;
+#pragma unroll 2
+        for (int k = wave * q4 + lane; k < (wave + 1) * q4; k += 64) {
+            float4 wv[FC_NPB];
+#pragma unroll
+            for (int n = 0; n < FC_NPB; ++n) wv[n] = reinterpret_cast<const float4*>(w1 + (long)(n0 + n) * D)[k];
 #pragma unroll
             for (int i = 0; i < FC_MAXB; ++i) {
                 if (i < nb) {
                     const float4 f = reinterpret_cast<const float4*>(fb + (long)(b0 + i) * D)[k];
-                    acc[i] = fmaf(wv.x, f.x, fmaf(wv.y, f.y, fmaf(wv.z, f.z, fmaf(wv.w, f.w, acc[i]))));
+#pragma unroll
+                    for (int n = 0; n < FC_NPB; ++n)
+                        acc[n][i] = fmaf(wv[n].x, f.x, fmaf(wv[n].y, f.y, fmaf(wv[n].z, f.z, fmaf(wv[n].w, f.w, acc[n][i]))));
                 }
             }
         }
 #pragma unroll
-        for (int i = 0; i < FC_MAXB; ++i) {
-            float v = acc[i];
+        for (int n = 0; n < FC_NPB; ++n)
 #pragma unroll
-            for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-            if (lane == 0 && i < nb) hidden[((long)(b0 + i) * NH + h) * HID + neuron - h * HID] = lrelu02(v + b1[neuron]);
+            for (int i = 0; i < FC_MAXB; ++i) {
+                float v = acc[n][i];
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+                if (lane == 0) part[wave][n * FC_MAXB + i] = v;
+            }
+        __syncthreads();
+        if (threadIdx.x < FC_NPB * FC_MAXB) {
+            const int n = threadIdx.x / FC_MAXB, i = threadIdx.x - n * FC_MAXB;
+            if (i < nb) {
+                const float v = (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
+                const int neuron = n0 + n;
+                hidden[((long)(b0 + i) * NH + h) * HID + neuron - h * HID] = lrelu02(v + b1[neuron]);
+            }
         }
+        __syncthreads();
     }
 }
 
 // ---- finish ------------------------------------------------------------------------------------------
 __device__ __forceinline__ float tanh01f(float x) { return tanhf(x) * 0.5f + 0.5f; }
 
-__global__ __launch_bounds__(256) void k_finish(adaisp_policy_finish_args a) {
+__global__ __launch_bounds__(1024) void k_finish(adaisp_policy_finish_args a) {
     const int b = blockIdx.x, t = threadIdx.x;
     const int F = a.num_filters, HID = a.hid, PW = a.param_width;
     __shared__ float raw[ADAISP_POLICY_MAX_FILTERS * ADAISP_MAX_PARAMS];   // fc_filter outputs
@@ -147,7 +197,7 @@ __global__ __launch_bounds__(256) void k_finish(adaisp_policy_finish_args a) {
     // lanes stride the hidden dimension, shuffle reduction
     {
         const int lane = t & 63, wv = t >> 6;
-        for (int r = wv; r < a.num_rows + F; r += 4) {
+        for (int r = wv; r < a.num_rows + F; r += 16) {
             const bool is_sel = r >= a.num_rows;
             const int rr = is_sel ? r - a.num_rows : r;
             const int f = is_sel ? F : a.row_filter[rr];
@@ -167,7 +217,7 @@ __global__ __launch_bounds__(256) void k_finish(adaisp_policy_finish_args a) {
     __syncthreads();
 
     // regressors (isp/filters.py: filter_param_regressor of each class) -> params_all[b][f][slot]
-    for (int r = t; r < a.num_rows; r += 256) {
+    for (int r = t; r < a.num_rows; r += 1024) {
         const int f = a.row_filter[r], s = a.row_slot[r];
         const adaisp_regressor rg = a.reg[f];
         const float x = raw[f * ADAISP_MAX_PARAMS + s];
@@ -246,7 +296,7 @@ __global__ __launch_bounds__(256) void k_finish(adaisp_policy_finish_args a) {
     __syncthreads();
     // packed parameter row of the selected filter (zeros for the all-zero one-hot)
     const int sel = sel_sh;
-    for (int s = t; s < PW; s += 256) {
+    for (int s = t; s < PW; s += 1024) {
         float v = 0.0f;
         if (sel >= 0 && sel < F && s < a.reg[sel].n) v = a.params_all[((long)b * F + sel) * PW + s];
         a.packed[(long)b * PW + s] = v;
@@ -262,7 +312,9 @@ hipError_t launch_policy_conv(const float* in, const float* states, int n_state,
     if (KS < 1) KS = 1;
     if (KS > 16) KS = 16;
     dim3 grid((B * Ho * Ho + PX_PER - 1) / PX_PER, Cout / CO_PER, G);
-    const size_t smem = (size_t)KS * CO_PER * PX_PER * sizeof(float);
+    size_t smem = (size_t)KS * CO_PER * PX_PER * sizeof(float);            // partial sums
+    const size_t wbytes = (size_t)Cin * CO_PER * 16 * sizeof(float);      // staged weights (Cin <= 128: 64 KB)
+    if (wbytes > smem) smem = wbytes;
     hipLaunchKernelGGL(k_trunk_conv, grid, dim3(64 * KS), smem, s, in, states, n_state, w, bias, out, B, Cin, Hin, Cout,
                        KS);
     return hipGetLastError();
@@ -270,12 +322,12 @@ hipError_t launch_policy_conv(const float* in, const float* states, int n_state,
 
 hipError_t launch_policy_fc1(const float* feats, const int32_t* head_src, const float* w1, const float* b1,
                              float* hidden, int B, int D, int NH, int HID, hipStream_t s) {
-    hipLaunchKernelGGL(k_fc1, dim3((NH * HID + 3) / 4), dim3(256), 0, s, feats, head_src, w1, b1, hidden, B, D, NH, HID);
+    hipLaunchKernelGGL(k_fc1, dim3(NH * HID / FC_NPB), dim3(256), 0, s, feats, head_src, w1, b1, hidden, B, D, NH, HID);
     return hipGetLastError();
 }
 
 hipError_t launch_policy_finish(const adaisp_policy_finish_args& a, int B, hipStream_t s) {
-    hipLaunchKernelGGL(k_finish, dim3(B), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(k_finish, dim3(B), dim3(1024), 0, s, a);
     return hipGetLastError();
 }
 

@@ -171,7 +171,7 @@ class YoloEngine:
         self.views = view
 
     # ------------------------------------------------------------------------------------------
-    TUNE_CANDIDATES = (2, 5, 12, 13, 18, 19, 22, 24)
+    TUNE_CANDIDATES = (2, 5, 12, 13, 18, 19, 22, 24, 30, 31, 32, 33)
 
     def autotune(self, reps=3):
         """Pick the fastest conv kernel variant per layer by timing it on this engine's own buffers (all variants
@@ -186,6 +186,8 @@ class YoloEngine:
                 if key not in chosen:
                     best = (None, float("inf"))
                     for v in self.TUNE_CANDIDATES:
+                        if v >= 30 and not (args[13] == 3 and args[14] == 1):
+                            continue                             # patch-resident kernels serve 3x3 stride-1 only
                         args[16] = v
                         fn(*args, st)
                         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -51,7 +51,9 @@ int adayolo_conv_fwd(const void* in, int in_cstride,
 /*
  * Same as adayolo_conv_fwd with an explicit kernel variant (tuning / A-B measurements; results are identical):
  * 0 = library default, 1 = register-staged tile loads, 2/3/4 = LDS-DMA ring with 2/3/4 stages (16x16x32 MFMA),
- * 5/6 = lean-address LDS-DMA ring with 2/3 stages (32x32x16 MFMA).
+ * 5/6 = lean-address LDS-DMA ring with 2/3 stages (32x32x16 MFMA); 9..24 = fixed tile shapes of that kernel
+ * (256x128 / 256x256 / 128x256 px x ch, BK 32 or 64; see yolo_conv_dma2.hip); 30..33 = 3x3 stride-1 kernels with
+ * the input patch resident in LDS (yolo_conv_patch.hip; other shapes fall back to the default).
  */
 int adayolo_conv_fwd_variant(const void* in, int in_cstride,
                              const void* weight, const float* bias,
