@@ -1,0 +1,70 @@
+"""Reward / TD-target / loss arithmetic of one RL training iteration — the caller side of the hot path
+(reference train.py:262-305, 341-351), written as pure functions so it can be tested without a dataset.
+
+The literal semantics are kept, including the `truncated` flag: the bootstrap term is multiplied by
+(1 - truncated) where truncated = 1 for images whose mean brightness is inside (0.01, max_bri), i.e. the value
+bootstrap survives only for too-dark / too-bright results (train.py:287-291).
+"""
+import torch
+
+from .util import STATE_STEP_DIM, STATE_STOPPED_DIM
+
+
+def td_losses(cfg, detect_input_loss, detect_retouch_loss, penalty, surrogate, new_states, old_value, new_value,
+              retouch_mean, use_truncated=True, max_bri=0.9):
+    """All inputs [B,1] except new_states [B,3+F]. Returns dict(reward, q_value, advantage, value_loss, agent_loss).
+
+    detect_*_loss are the per-sample detection losses BEFORE weighting/clipping (train.py:264-271)."""
+    l_in = torch.clip(detect_input_loss * cfg.detect_loss_weight, 0, 1.0)
+    l_re = torch.clip(detect_retouch_loss * cfg.detect_loss_weight, 0, 1.0)
+    stopped = new_states[:, STATE_STOPPED_DIM:STATE_STOPPED_DIM + 1]
+    reward = (cfg.all_reward + (1 - cfg.all_reward) * stopped) * (l_in.detach() - l_re) * cfg.critic_logit_multiplier
+    if cfg.use_penalty:
+        reward = reward - penalty
+    clear_final = torch.gt(new_states[:, STATE_STEP_DIM:STATE_STEP_DIM + 1], cfg.maximum_trajectory_length).float()
+    new_value = new_value * (1.0 - clear_final)
+    if use_truncated:
+        truncated = torch.where(0.01 < retouch_mean, 1.0, 0.0)
+        truncated = torch.where(retouch_mean < max_bri, truncated, torch.zeros_like(truncated))
+        q_value = reward + (1.0 - stopped) * cfg.discount_factor * new_value * (1.0 - truncated)
+    else:
+        q_value = reward + (1.0 - stopped) * cfg.discount_factor * new_value
+    advantage = q_value.detach() - old_value
+    value_loss = torch.mean(advantage ** 2)
+    if cfg.use_TD:
+        routine_loss, adv_for_policy = -q_value * cfg.parameter_lr_mul, -advantage
+    else:
+        routine_loss, adv_for_policy = -reward, -reward
+    agent_loss = torch.mean(routine_loss + surrogate * adv_for_policy.detach())
+    return dict(reward=reward, q_value=q_value, advantage=advantage, value_loss=value_loss, agent_loss=agent_loss)
+
+
+def lr_lambda(max_iter):
+    """LambdaLR factor 0.1^(3*it/max_it) (train.py:206-218)."""
+    return lambda it: 0.1 ** (3.0 * it / max_iter)
+
+
+def train_iteration(cfg, agent, value, detector, loss_fn, imgs, z, states, labels, progress, optimizers, buckets=None,
+                    use_truncated=True, max_bri=0.9):
+    """One optimisation step (train.py:255-351). `detector(x)` must return the three raw head maps with autograd
+    through to x (the frozen reward model); `buckets` (adaptiveisp_amd.dist.GradBucket per model) enables the
+    data-parallel gradient all-reduce before the 1e-5 clip. Returns the scalars of td_losses plus the retouched batch."""
+    from . import dist as adist
+    from .yolo.loss import per_sample_loss
+    (retouch, new_states, surrogate, penalty), _, _ = agent((imgs, z, states), progress)
+    with torch.no_grad():
+        l_in = per_sample_loss(loss_fn, detector(imgs), labels)
+    l_re = per_sample_loss(loss_fn, detector(retouch), labels)
+    old_value = value(imgs, states)
+    new_value = value(retouch, new_states)
+    out = td_losses(cfg, l_in, l_re, penalty, surrogate, new_states, old_value, new_value,
+                    torch.mean(retouch, dim=(1, 2, 3)).unsqueeze(-1), use_truncated, max_bri)
+    out["value_loss"].backward(retain_graph=False)
+    out["agent_loss"].backward(retain_graph=False)
+    models = [agent, value]
+    if buckets is None:
+        buckets = [adist.GradBucket(m) for m in models]
+    adist.synced_step(models, optimizers, buckets, max_grad_norm=1e-5)
+    out["retouch"] = retouch.detach()
+    out["new_states"] = new_states.detach()
+    return out

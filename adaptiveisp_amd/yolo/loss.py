@@ -1,0 +1,123 @@
+"""Detection loss used as the RL reward signal (CIoU box + BCE objectness + BCE class, YOLOv5-style target
+assignment). Restates the reference's `ComputeLossBatch` / `ComputeLoss` (yolov3/utils/loss.py:237-380,91-234),
+`build_targets` (:320-380) and `bbox_iou(..., CIoU=True)` (yolov3/utils/metrics.py:222-260).
+
+Small, gather-heavy tensors ([n_targets, 85]); stays at PyTorch level. Inputs are the three raw
+head maps [B, na, ny, nx, 5+nc] (DetectionModel in train mode, or YoloEngine.raw_maps()).
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+# yolov3/data/hyps/hyp.scratch-low.yaml with the scaling applied by the reference's train.py:141-144
+def default_hyp(nc=80, imgsz=512, nl=3):
+    return dict(box=0.05 * 3 / nl, cls=0.5 * nc / 80 * 3 / nl, obj=1.0 * (imgsz / 640) ** 2 * 3 / nl,
+                anchor_t=4.0, cls_pw=1.0, obj_pw=1.0, fl_gamma=0.0, label_smoothing=0.0)
+
+
+def ciou(box1, box2, eps=1e-7):
+    """Complete-IoU of xywh boxes [n,4] vs [n,4] -> [n,1]."""
+    x1, y1, w1, h1 = box1.chunk(4, -1)
+    x2, y2, w2, h2 = box2.chunk(4, -1)
+    l1, r1, t1, b1 = x1 - w1 / 2, x1 + w1 / 2, y1 - h1 / 2, y1 + h1 / 2
+    l2, r2, t2, b2 = x2 - w2 / 2, x2 + w2 / 2, y2 - h2 / 2, y2 + h2 / 2
+    inter = (r1.minimum(r2) - l1.maximum(l2)).clamp(0) * (b1.minimum(b2) - t1.maximum(t2)).clamp(0)
+    union = w1 * h1 + w2 * h2 - inter + eps
+    iou = inter / union
+    cw = r1.maximum(r2) - l1.minimum(l2)
+    ch = b1.maximum(b2) - t1.minimum(t2)
+    c2 = cw ** 2 + ch ** 2 + eps
+    rho2 = ((l2 + r2 - l1 - r1) ** 2 + (t2 + b2 - t1 - b1) ** 2) / 4
+    v = (4 / math.pi ** 2) * (torch.atan(w2 / h2) - torch.atan(w1 / h1)).pow(2)
+    with torch.no_grad():
+        alpha = v / (v - iou + (1 + eps))
+    return iou - (rho2 / c2 + v * alpha)
+
+
+class DetectionLoss:
+    """loss(preds, targets) -> (lbox*bs, lobj*bs, lcls*bs); targets [n,6] = (image, class, x, y, w, h) normalised."""
+
+    balance3 = (4.0, 1.0, 0.4)
+
+    def __init__(self, anchors_grid, nc=80, hyp=None, device="cpu"):
+        self.anchors = anchors_grid.to(device)          # [nl, na, 2] in grid units (Detect.anchors)
+        self.nl, self.na = self.anchors.shape[:2]
+        self.nc = nc
+        self.hyp = hyp or default_hyp(nc)
+        self.device = torch.device(device)
+        eps = self.hyp.get("label_smoothing", 0.0)
+        self.cp, self.cn = 1.0 - 0.5 * eps, 0.5 * eps
+        self.balance = list(self.balance3) if self.nl == 3 else [4.0, 1.0, 0.25, 0.06, 0.02][: self.nl]
+        self._off = torch.tensor([[0, 0], [1, 0], [0, 1], [-1, 0], [0, -1]], device=self.device).float() * 0.5
+
+    def assign(self, preds, targets):
+        """Target assignment: every target is matched to the anchors whose w/h ratio is < anchor_t and replicated
+        into the (up to 2) neighbouring cells its centre is closest to."""
+        na, nt = self.na, targets.shape[0]
+        ai = torch.arange(na, device=self.device).float().view(na, 1).repeat(1, nt)
+        tgt = torch.cat((targets.repeat(na, 1, 1), ai[..., None]), 2)            # [na, nt, 7]
+        out = []
+        gain = torch.ones(7, device=self.device)
+        for i in range(self.nl):
+            anchors, shape = self.anchors[i], preds[i].shape
+            gain[2:6] = torch.tensor(shape, device=self.device)[[3, 2, 3, 2]].float()
+            t = tgt * gain
+            if nt:
+                ratio = t[..., 4:6] / anchors[:, None]
+                t = t[torch.max(ratio, 1 / ratio).max(2)[0] < self.hyp["anchor_t"]]
+                gxy = t[:, 2:4]
+                gxi = gain[[2, 3]] - gxy
+                j, k = ((gxy % 1 < 0.5) & (gxy > 1)).T
+                l, m = ((gxi % 1 < 0.5) & (gxi > 1)).T
+                sel = torch.stack((torch.ones_like(j), j, k, l, m))
+                t = t.repeat((5, 1, 1))[sel]
+                offsets = (torch.zeros_like(gxy)[None] + self._off[:, None])[sel]
+            else:
+                t, offsets = tgt[0], 0
+            bc, gxy, gwh, a = t.chunk(4, 1)
+            a, (b, c) = a.long().view(-1), bc.long().T
+            gij = (gxy - offsets).long()
+            gi, gj = gij.T
+            out.append(dict(b=b, a=a, gj=gj.clamp_(0, shape[2] - 1), gi=gi.clamp_(0, shape[3] - 1),
+                            box=torch.cat((gxy - gij, gwh), 1), anchors=anchors[a], cls=c))
+        return out
+
+    def __call__(self, preds, targets):
+        lcls = torch.zeros(1, device=self.device)
+        lbox = torch.zeros(1, device=self.device)
+        lobj = torch.zeros(1, device=self.device)
+        assigned = self.assign(preds, targets)
+        for i, (pi, m) in enumerate(zip(preds, assigned)):
+            tobj = torch.zeros(pi.shape[:4], dtype=pi.dtype, device=self.device)
+            n = m["b"].shape[0]
+            if n:
+                pxy, pwh, _, pcls = pi[m["b"], m["a"], m["gj"], m["gi"]].split((2, 2, 1, self.nc), 1)
+                pxy = pxy.sigmoid() * 2 - 0.5
+                pwh = (pwh.sigmoid() * 2) ** 2 * m["anchors"]
+                iou = ciou(torch.cat((pxy, pwh), 1), m["box"]).squeeze()
+                lbox = lbox + (1.0 - iou).mean()
+                tobj[m["b"], m["a"], m["gj"], m["gi"]] = iou.detach().clamp(0).type(tobj.dtype)
+                if self.nc > 1:
+                    t = torch.full_like(pcls, self.cn)
+                    t[range(n), m["cls"]] = self.cp
+                    lcls = lcls + F.binary_cross_entropy_with_logits(
+                        pcls, t, pos_weight=torch.tensor([self.hyp["cls_pw"]], device=self.device))
+            lobj = lobj + F.binary_cross_entropy_with_logits(
+                pi[..., 4], tobj, pos_weight=torch.tensor([self.hyp["obj_pw"]], device=self.device)) * self.balance[i]
+        bs = preds[0].shape[0]
+        return lbox * self.hyp["box"] * bs, lobj * self.hyp["obj"] * bs, lcls * self.hyp["cls"] * bs
+
+
+def per_sample_loss(loss_fn, preds, labels):
+    """Per-image detection loss [B,1] (reference train.py:175-197: each sample is scored alone with its targets'
+    image index set to 0). `labels` is a list of [n_b, 6] tensors."""
+    B = preds[0].shape[0]
+    rows = []
+    for b in range(B):
+        one = [p[b:b + 1] for p in preds]
+        t = labels[b].clone().to(preds[0].device)
+        t[:, 0] = 0
+        lbox, lobj, lcls = loss_fn(one, t)
+        rows.append(lbox + lobj + lcls)
+    return torch.stack(rows).view(B, 1)

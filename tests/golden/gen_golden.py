@@ -93,6 +93,27 @@ def gen_yolo():
     for i, r in enumerate(raws):
         out[f"raw{i}"] = r.numpy()
     np.savez_compressed(os.path.join(HERE, "yolo.npz"), **out)
+    # detection loss (reward signal): the reference's ComputeLossBatch on random head maps + hand-made targets
+    from utils.loss import ComputeLossBatch
+    m.hyp = dict(box=0.05, cls=0.5, obj=1.0 * (96 / 640) ** 2, anchor_t=4.0, cls_pw=1.0, obj_pw=1.0, fl_gamma=0.0,
+                 label_smoothing=0.0)
+    m.train()
+    crit = ComputeLossBatch(m)
+    g = torch.Generator().manual_seed(9)
+    preds = [torch.randn(2, 3, 8, 12, 85, generator=g), torch.randn(2, 3, 4, 6, 85, generator=g),
+             torch.randn(2, 3, 2, 3, 85, generator=g)]
+    targets = torch.tensor([[0, 3, 0.30, 0.40, 0.20, 0.30], [0, 17, 0.70, 0.55, 0.50, 0.60], [1, 0, 0.52, 0.48, 0.10, 0.15],
+                            [1, 79, 0.15, 0.85, 0.25, 0.20], [1, 5, 0.9, 0.1, 0.6, 0.9]])
+    lbox, lobj, lcls = crit([p.clone() for p in preds], targets.clone())
+    lo = {f"p{i}": p.numpy() for i, p in enumerate(preds)}
+    lo.update(targets=targets.numpy(), lbox=lbox.numpy(), lobj=lobj.numpy(), lcls=lcls.numpy(),
+              anchors=m.model[-1].anchors.numpy())
+    for b in range(2):          # per-sample scoring as in train.py:184-196
+        tb = targets[targets[:, 0] == b].clone(); tb[:, 0] = 0
+        l3 = crit([p[b:b + 1].clone() for p in preds], tb)
+        lo[f"sample{b}"] = torch.cat(l3).numpy()
+    np.savez_compressed(os.path.join(HERE, "detloss.npz"), **lo)
+    m.eval()
     p = os.path.join(HERE, "state_dict_keys.json")
     keys = json.load(open(p))
     keys["yolo"] = {k: list(v.shape) for k, v in m.state_dict().items()}

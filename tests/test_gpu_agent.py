@@ -128,3 +128,48 @@ def test_fused_eval_forced_and_highres(golden):
             ag.fc2.bias.add_(torch.tensor([0, 0, 0, 0, 0, 0, 0, 0, 50.0, 0], device=dev))
         (_, _, _, _), dbg, _ = ag(inp, 1.0)
         assert (dbg["selected_filter"] == 8).all()
+
+
+def test_training_iteration_end_to_end():
+    """One RL optimisation step on the device: policy heads (PyTorch) -> HIP ISP forward -> frozen detector with
+    autograd -> per-sample detection loss -> TD losses -> HIP parameter-gradient kernels -> clip -> Adam."""
+    from _synth import synth_state_dict, synth_yolo_state_dict, test_image
+    from adaptiveisp_amd import dist as adist
+    from adaptiveisp_amd.agent import Agent
+    from adaptiveisp_amd.config import cfg
+    from adaptiveisp_amd.rl import train_iteration
+    from adaptiveisp_amd.value import Value
+    from adaptiveisp_amd.yolo import yolov3
+    from adaptiveisp_amd.yolo.loss import DetectionLoss, default_hyp
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    agent = Agent(cfg, shape=(16, 64, 64), device=dev)
+    agent.load_state_dict(synth_state_dict(agent, seed=0))
+    agent = agent.to(dev).train()
+    value = Value(cfg, shape=(19, 64, 64))
+    value.load_state_dict(synth_state_dict(value, seed=1))
+    value = value.to(dev).train()
+    det = yolov3()
+    det.load_state_dict(synth_yolo_state_dict(det))
+    det = det.to(dev).train()
+    for m in det.modules():                                   # frozen reward model: BN statistics fixed, no grads
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.eval()
+    for p in det.parameters():
+        p.requires_grad_(False)
+    loss_fn = DetectionLoss(det.model[-1].anchors, nc=80, hyp=default_hyp(80, 96), device=dev)
+    B = 4
+    imgs = T(test_image(B, 64, 96, seed=3, special=False)).to(dev)
+    z = torch.rand(B, cfg.z_dim, device=dev) * 0.98 + 0.01
+    states = torch.zeros(B, cfg.num_state_dim, device=dev)
+    labels = [torch.tensor([[0, 1 + b, 0.5, 0.5, 0.3, 0.4]]) for b in range(B)]
+    opts = [torch.optim.Adam(agent.parameters(), lr=3e-5), torch.optim.Adam(value.parameters(), lr=3e-5)]
+    before = torch.cat([p.detach().reshape(-1) for p in agent.parameters()]).clone()
+    out = train_iteration(cfg, agent, value, det, loss_fn, imgs, z, states, labels, 0.1, opts,
+                          buckets=[adist.GradBucket(agent), adist.GradBucket(value)])
+    torch.cuda.synchronize()
+    for k in ("reward", "q_value", "value_loss", "agent_loss"):
+        assert torch.isfinite(out[k]).all(), k
+    after = torch.cat([p.detach().reshape(-1) for p in agent.parameters()])
+    assert (after != before).any()                            # the heads moved
+    assert out["retouch"].shape == imgs.shape and float(out["retouch"].min()) >= 0 and float(out["retouch"].max()) <= 1
