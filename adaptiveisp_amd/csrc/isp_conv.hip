@@ -144,6 +144,143 @@ __device__ void conv_tile(float* __restrict__ lds, const float* __restrict__ in,
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Row-sliding variant (used whenever rows are 16-byte aligned): no LDS at all. A wave owns a 256-px wide strip of
+// ONE plane and walks down RS output rows; each lane holds 4 consecutive pixels of the current 3 (5) input rows
+// in registers and gets its horizontal neighbours from the adjacent lanes with DPP wave shifts
+// (v_mov_b32_dpp wave_shl/shr). Every input row is loaded once per strip with one coalesced 16-B load per lane
+// ((RS+2R)/RS re-read factor along y only), every output row is one 16-B store per lane.
+// ---------------------------------------------------------------------------------------------------------
+constexpr int RS = 16;                          // output rows per wave
+
+__device__ __forceinline__ float dpp_from_prev(float v) {   // lane i <- lane i-1
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0x138, 0xF, 0xF, false));
+}
+__device__ __forceinline__ float dpp_from_next(float v) {   // lane i <- lane i+1
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0x130, 0xF, 0xF, false));
+}
+
+// one input row of this lane: its 4 pixels plus R neighbours on each side -> v[0 .. 4+2R)
+template <int R, int MODE>
+__device__ __forceinline__ void load_row(const float* __restrict__ src, int y, int H, int W, int gx, int lane,
+                                         bool active, float* v) {
+    int yy = y;
+    if (MODE == kUSM) yy = reflect(y, H);
+    const bool row_ok = yy >= 0 && yy < H;
+    float4 c = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float* rowp = src + (long)(row_ok ? yy : 0) * W;
+    if (active && row_ok) c = *reinterpret_cast<const float4*>(rowp + gx);
+    v[R + 0] = c.x; v[R + 1] = c.y; v[R + 2] = c.z; v[R + 3] = c.w;
+    // neighbours inside the wave
+    float l1 = dpp_from_prev(c.w), r1 = dpp_from_next(c.x);
+    float l2 = 0.f, r2 = 0.f;
+    if (R == 2) { l2 = dpp_from_prev(c.z); r2 = dpp_from_next(c.y); }
+    // strip edges: the first lane and the last active lane fetch their outside neighbours themselves
+    if (lane == 0 || !active) {
+        l1 = 0.f; l2 = 0.f;
+        if (active && row_ok) {
+            if (MODE == kUSM) { l1 = rowp[reflect(gx - 1, W)]; l2 = rowp[reflect(gx - 2, W)]; }
+            else if (gx > 0) l1 = rowp[gx - 1];
+        }
+    }
+    if (lane == 63 || gx + 4 >= W) {
+        r1 = 0.f; r2 = 0.f;
+        if (active && row_ok) {
+            if (MODE == kUSM) { r1 = rowp[reflect(gx + 4, W)]; r2 = rowp[reflect(gx + 5, W)]; }
+            else if (gx + 4 < W) r1 = rowp[gx + 4];
+        }
+    }
+    if (R == 1) { v[0] = l1; v[5] = r1; }
+    else { v[0] = l2; v[1] = l1; v[6] = r1; v[7] = r2; }
+}
+
+template <int R, int MODE>
+__device__ void conv_rows(const float* __restrict__ in, float* __restrict__ out, const float* __restrict__ p, int H,
+                          int W, int c, int strip, int band) {
+    const int lane = threadIdx.x & 63;
+    const long plane = (long)H * W;
+    const float* src = in + c * plane;
+    float* dst = out + c * plane;
+    const int gx = strip * 256 + 4 * lane;
+    const bool active = gx < W;                      // W % 4 == 0 on this path
+    const int y_begin = band * RS, y_end = min(H, y_begin + RS);
+
+    float w[2 * R + 1][2 * R + 1];
+    float amount;
+    if (MODE == kUSM) {
+        const float sigma = p[0];
+        amount = p[1];
+        float g1[5], sum = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            const float t = (float)(i - 2) / sigma;
+            g1[i] = expf(-0.5f * (t * t));
+            sum += g1[i];
+        }
+#pragma unroll
+        for (int i = 0; i < 5; ++i) g1[i] = g1[i] / sum;
+#pragma unroll
+        for (int i = 0; i < 2 * R + 1; ++i)
+#pragma unroll
+            for (int j = 0; j < 2 * R + 1; ++j) w[i][j] = g1[i] * g1[j];
+    } else {
+        amount = p[0];
+        const float a = 1.0f / 13.0f, c5 = 5.0f / 13.0f;
+#pragma unroll
+        for (int i = 0; i < 2 * R + 1; ++i)
+#pragma unroll
+            for (int j = 0; j < 2 * R + 1; ++j) w[i][j] = (i == R && j == R) ? c5 : a;
+    }
+
+    float rows[2 * R + 1][4 + 2 * R];                // sliding window of input rows y-R .. y+R
+#pragma unroll
+    for (int i = 0; i < 2 * R; ++i) load_row<R, MODE>(src, y_begin - R + i, H, W, gx, lane, active, rows[i + 1]);
+    for (int y = y_begin; y < y_end; ++y) {
+#pragma unroll
+        for (int i = 0; i < 2 * R; ++i)
+#pragma unroll
+            for (int j = 0; j < 4 + 2 * R; ++j) rows[i][j] = rows[i + 1][j];
+        load_row<R, MODE>(src, y + R, H, W, gx, lane, active, rows[2 * R]);
+        float o[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float blur = 0.0f;
+#pragma unroll
+            for (int i = 0; i < 2 * R + 1; ++i)
+#pragma unroll
+                for (int j = 0; j < 2 * R + 1; ++j) blur = fmaf(w[i][j], rows[i][k + j], blur);
+            const float ctr = rows[R][k + R];
+            if (MODE != kUSM) {
+                const int xx = gx + k;
+                if (y == 0 || y == H - 1 || xx == 0 || xx >= W - 1) blur = ctr;
+            }
+            const float r = (MODE == kAdjust) ? ctr * amount + blur * (1.0f - amount) : ctr + (ctr - blur) * amount;
+            o[k] = clamp01(r);
+        }
+        if (active) *reinterpret_cast<float4*>(dst + (long)y * W + gx) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+}
+
+__global__ __launch_bounds__(kThreads) void k_conv_rows(const float* __restrict__ img, float* __restrict__ out,
+                                                        const int32_t* __restrict__ ids, int uniform_op,
+                                                        const float* __restrict__ params, int pstride, int H, int W,
+                                                        int strips) {
+    const int b = blockIdx.z;
+    const int op = ids ? ids[b] : uniform_op;
+    if (op != ADAISP_OP_SHARPEN && op != ADAISP_OP_SHARPEN_V2 && op != ADAISP_OP_USM) return;
+    const int wave = threadIdx.x >> 6;
+    const int band = blockIdx.y * 4 + wave;          // 4 waves = 4 consecutive row bands
+    if (band * RS >= H) return;
+    const int c = blockIdx.x / strips, strip = blockIdx.x - c * strips;
+    const long off = (long)b * 3 * H * W;
+    const float* p = params + (long)b * pstride;
+    switch (op) {
+        case ADAISP_OP_SHARPEN:    conv_rows<1, kAdjust>(img + off, out + off, p, H, W, c, strip, band); break;
+        case ADAISP_OP_SHARPEN_V2: conv_rows<1, kSharpness>(img + off, out + off, p, H, W, c, strip, band); break;
+        default:                   conv_rows<2, kUSM>(img + off, out + off, p, H, W, c, strip, band); break;
+    }
+}
+
 template <bool VEC>
 __global__ __launch_bounds__(kThreads) void k_conv(const float* __restrict__ img, float* __restrict__ out,
                                                    const int32_t* __restrict__ ids, int uniform_op,
@@ -167,10 +304,11 @@ hipError_t launch_conv(const Batch& a, hipStream_t s) {
     const bool vec = (a.W % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.img) & 15) == 0) &&
                      ((reinterpret_cast<uintptr_t>(a.out) & 15) == 0);
     dim3 grid((a.W + TW - 1) / TW, (a.H + TH - 1) / TH, a.B);
-    if (vec)
-        hipLaunchKernelGGL(k_conv<true>, grid, dim3(kThreads), 0, s, a.img, a.out, a.ids, a.uniform_op, a.params,
-                           a.pstride, a.H, a.W);
-    else
+    if (vec) {
+        const int strips = (a.W + 255) / 256, bands = (a.H + RS - 1) / RS;
+        hipLaunchKernelGGL(k_conv_rows, dim3(3 * strips, (bands + 3) / 4, a.B), dim3(kThreads), 0, s, a.img, a.out,
+                           a.ids, a.uniform_op, a.params, a.pstride, a.H, a.W, strips);
+    } else
         hipLaunchKernelGGL(k_conv<false>, grid, dim3(kThreads), 0, s, a.img, a.out, a.ids, a.uniform_op, a.params,
                            a.pstride, a.H, a.W);
     return hipGetLastError();
