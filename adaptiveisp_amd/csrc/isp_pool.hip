@@ -16,41 +16,55 @@ constexpr int kThreads = 256;
 __device__ __forceinline__ int win_lo(int o, int n) { return (int)(((long)o * n) / 64); }
 __device__ __forceinline__ int win_hi(int o, int n) { return (int)((((long)(o + 1)) * n + 63) / 64); }
 
+// grid: (64 output rows, B, XCH column chunks of 64/XCH output cells); rows of the window are unrolled 4-deep so
+// several 16-B loads per lane are in flight.
+constexpr int XCH = 4;
+
 template <bool VEC>
 __global__ __launch_bounds__(kThreads) void k_pool64(const float* __restrict__ img, float* __restrict__ pooled,
                                                      int H, int W) {
-    extern __shared__ __attribute__((aligned(16))) float colsum[];   // [W]
-    const int oy = blockIdx.x, b = blockIdx.y;
+    extern __shared__ __attribute__((aligned(16))) float colsum[];   // [3][span] column sums of this chunk
+    const int oy = blockIdx.x, b = blockIdx.y, ch = blockIdx.z;
+    const int ox0 = ch * (64 / XCH), ox1 = ox0 + 64 / XCH;
     const int ys = win_lo(oy, H), ye = win_hi(oy, H);
+    const int x_lo = win_lo(ox0, W) & ~3, x_hi = win_hi(ox1 - 1, W);  // quad-aligned start of the chunk's columns
+    const int span = x_hi - x_lo;
     const float kh = (float)(ye - ys);
     const long plane = (long)H * W;
-    for (int c = 0; c < 3; ++c) {
-        const float* __restrict__ src = img + ((long)b * 3 + c) * plane;
-        if (VEC) {
-            for (int x = 4 * threadIdx.x; x < W; x += 4 * kThreads) {
-                float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float* __restrict__ base = img + (long)b * 3 * plane;
+    if (VEC) {
+        const int nq = (span + 3) >> 2;
+        for (int i = threadIdx.x; i < 3 * nq; i += kThreads) {
+            const int c = i / nq, q = i - c * nq;
+            const int x = x_lo + 4 * q;
+            const float* src = base + c * plane + x;
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (x + 3 < W) {
+#pragma unroll 4
                 for (int y = ys; y < ye; ++y) {
-                    const float4 v = *reinterpret_cast<const float4*>(src + (long)y * W + x);
+                    const float4 v = *reinterpret_cast<const float4*>(src + (long)y * W);
                     acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
                 }
-                *reinterpret_cast<float4*>(colsum + x) = acc;
             }
-        } else {
-            for (int x = threadIdx.x; x < W; x += kThreads) {
-                float acc = 0.f;
-                for (int y = ys; y < ye; ++y) acc += src[(long)y * W + x];
-                colsum[x] = acc;
-            }
+            *reinterpret_cast<float4*>(colsum + c * ((span + 7) & ~3) + 4 * q) = acc;
         }
-        __syncthreads();
-        if (threadIdx.x < 64) {
-            const int ox = threadIdx.x;
-            const int xs = win_lo(ox, W), xe = win_hi(ox, W);
+    } else {
+        for (int i = threadIdx.x; i < 3 * span; i += kThreads) {
+            const int c = i / span, xo = i - c * span;
+            const float* src = base + c * plane + x_lo + xo;
             float acc = 0.f;
-            for (int x = xs; x < xe; ++x) acc += colsum[x];
-            pooled[(((long)b * 3 + c) * 64 + oy) * 64 + ox] = acc / kh / (float)(xe - xs);
+            for (int y = ys; y < ye; ++y) acc += src[(long)y * W];
+            colsum[c * ((span + 7) & ~3) + xo] = acc;
         }
-        __syncthreads();
+    }
+    __syncthreads();
+    if (threadIdx.x < 3 * (64 / XCH)) {
+        const int c = threadIdx.x / (64 / XCH), ox = ox0 + threadIdx.x % (64 / XCH);
+        const int xs = win_lo(ox, W), xe = win_hi(ox, W);
+        const float* cs = colsum + c * ((span + 7) & ~3) - x_lo;
+        float acc = 0.f;
+        for (int x = xs; x < xe; ++x) acc += cs[x];
+        pooled[(((long)b * 3 + c) * 64 + oy) * 64 + ox] = acc / kh / (float)(xe - xs);
     }
 }
 
@@ -58,8 +72,8 @@ __global__ __launch_bounds__(kThreads) void k_pool64(const float* __restrict__ i
 
 hipError_t launch_pool64(const float* img, float* pooled, int B, int H, int W, hipStream_t s) {
     const bool vec = (W % 4 == 0) && ((reinterpret_cast<uintptr_t>(img) & 15) == 0);
-    dim3 grid(64, B);
-    const size_t smem = (size_t)W * sizeof(float);
+    dim3 grid(64, B, XCH);
+    const size_t smem = 3 * ((size_t)(W + XCH - 1) / XCH + 16 + W / 64) * sizeof(float);   // >= 3 x padded chunk span
     if (vec) hipLaunchKernelGGL(k_pool64<true>, grid, dim3(kThreads), smem, s, img, pooled, H, W);
     else hipLaunchKernelGGL(k_pool64<false>, grid, dim3(kThreads), smem, s, img, pooled, H, W);
     return hipGetLastError();
