@@ -53,8 +53,9 @@ __device__ __forceinline__ unsigned long long sel(bool ok, unsigned long long p,
 }
 
 // ABL: ablation switch for measurements only (0 = real kernel, 1 = no DMA inside the k-loop, 2 = no LDS reads/MFMA)
-template <int BM, int BN, int WM, int WN, int STAGES, int ABL = 0, int BK = 64>
-__global__ __launch_bounds__(64 * WM * WN) void k_conv_igemm_dma32(const ConvArgs a) {
+// MINW: minimum waves per SIMD the register allocation must allow (2 co-resident workgroups of 8 waves need 4)
+template <int BM, int BN, int WM, int WN, int STAGES, int ABL = 0, int BK = 64, int MINW = 1>
+__global__ __launch_bounds__(64 * WM * WN, MINW) void k_conv_igemm_dma32(const ConvArgs a) {
     constexpr int NW = WM * WN, kThreads = 64 * NW;
     constexpr int TM = BM / WM, TN = BN / WN, MI = TM / 32, NI = TN / 32;
     static_assert(MI >= 1 && NI >= 1, "wave tile must be a multiple of 32x32");
@@ -246,12 +247,12 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_igemm_dma32(const ConvArg
     }
 }
 
-template <int BM, int BN, int WM, int WN, int STAGES, int ABL = 0, int BK = 64>
+template <int BM, int BN, int WM, int WN, int STAGES, int ABL = 0, int BK = 64, int MINW = 1>
 static hipError_t launch(ConvArgs a, hipStream_t s) {
     constexpr int ring = STAGES * (BM + BN) * BK * 2, epi = BM * (BN + 8) * 2;
     constexpr int smem = ring > epi ? ring : epi;          // the epilogue tile reuses (and may exceed) the ring
     static_assert(smem <= 160 * 1024, "LDS budget");
-    auto kern = k_conv_igemm_dma32<BM, BN, WM, WN, STAGES, ABL, BK>;
+    auto kern = k_conv_igemm_dma32<BM, BN, WM, WN, STAGES, ABL, BK, MINW>;
     static bool configured = false;
     if (!configured) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -281,6 +282,10 @@ hipError_t launch_conv_dma2(ConvArgs a, hipStream_t s, int variant) {
     if (variant == 15) return launch<256, 256, 4, 2, 2, 2>(a, s);
     if (variant == 22) return launch<128, 64, 4, 1, 4, 0, 32>(a, s);    // small Cin/Cout: BK=32 (no half-empty k-steps at Cin=32)
     if (variant == 24) return launch<256, 128, 4, 2, 4, 0, 32>(a, s);   // 8 waves, 256 px x 128 ch, BK=32
+    if (variant == 26) return launch<128, 256, 2, 4, 3, 0, 32, 4>(a, s);   // v19 squeezed to 128 VGPRs: 2 workgroups/CU
+    if (variant == 27) return launch<256, 128, 4, 2, 3, 0, 32, 4>(a, s);   // 256 px x 128 ch, 72 KB, 2 workgroups/CU
+    if (variant == 28) return launch<128, 128, 2, 2, 3, 0, 64, 3>(a, s);   // 4 waves, 96 KB... 1/CU by LDS; 3 waves/SIMD regs
+    if (variant == 29) return launch<256, 64, 4, 1, 4, 0, 32>(a, s);       // small Cout: 256 px x 64 ch, 80 KB
     if (variant == 20) return launch<256, 256, 4, 2, 2, 3>(a, s);     // ablation: MFMA only
     if (variant == 21) return launch<256, 256, 4, 2, 2, 4>(a, s);     // ablation: LDS reads only
     if (variant == 16) return launch<256, 256, 4, 2, 4, 0, 32>(a, s);   // BK=32, 4-stage ring (128 KB), 3 steps of look-ahead

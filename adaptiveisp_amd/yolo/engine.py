@@ -171,9 +171,9 @@ class YoloEngine:
         self.views = view
 
     # ------------------------------------------------------------------------------------------
-    TUNE_CANDIDATES = (2, 5, 12, 13, 18, 19, 22, 24, 30, 31, 32, 33)
+    TUNE_CANDIDATES = (2, 5, 12, 13, 18, 19, 22, 24, 26, 27, 30, 31, 32, 33, 40, 41)
 
-    def autotune(self, reps=3):
+    def autotune(self, reps=5):
         """Pick the fastest conv kernel variant per layer by timing it on this engine's own buffers (all variants
         compute the same result; see include/adayolo.h). Like a vendor library's 'find' step, done once."""
         st = _lib.stream_ptr()
@@ -186,17 +186,20 @@ class YoloEngine:
                 if key not in chosen:
                     best = (None, float("inf"))
                     for v in self.TUNE_CANDIDATES:
-                        if v >= 30 and not (args[13] == 3 and args[14] == 1):
+                        if 30 <= v < 40 and not (args[13] == 3 and args[14] == 1):
                             continue                             # patch-resident kernels serve 3x3 stride-1 only
+                        if v >= 40 and not (args[13] == 3 and args[11] in (32, 64)):
+                            continue                             # whole-K-resident kernels: 3x3 with Cin 32 / 64
                         args[16] = v
                         fn(*args, st)
                         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                        e0.record()
-                        for _ in range(reps):
+                        t = float("inf")
+                        for _ in range(reps):                     # best of `reps` single launches
+                            e0.record()
                             fn(*args, st)
-                        e1.record()
-                        e1.synchronize()
-                        t = e0.elapsed_time(e1)
+                            e1.record()
+                            e1.synchronize()
+                            t = min(t, e0.elapsed_time(e1))
                         if t < best[1]:
                             best = (v, t)
                     chosen[key] = best[0]
