@@ -173,11 +173,26 @@ class YoloEngine:
     # ------------------------------------------------------------------------------------------
     TUNE_CANDIDATES = (2, 5, 12, 13, 18, 19, 22, 24, 26, 27, 30, 31, 32, 33, 40, 41)
 
-    def autotune(self, reps=5):
+    def autotune(self, reps=5, cache=None, retune=False):
         """Pick the fastest conv kernel variant per layer by timing it on this engine's own buffers (all variants
-        compute the same result; see include/adayolo.h). Like a vendor library's 'find' step, done once."""
+        compute the same result; see include/adayolo.h). Like a vendor library's 'find' step. With `cache` (a JSON
+        path) the choices are loaded when every layer shape is present, otherwise measured and written back."""
+        import json
+        import os
         st = _lib.stream_ptr()
         chosen = {}
+        keys = {tuple(args[8:16]) for kind, _, args in self.plan if kind == "conv"}
+        if cache and os.path.exists(cache) and not retune:
+            try:
+                table = {tuple(int(x) for x in k.split(",")): int(v) for k, v in json.load(open(cache)).items()}
+            except Exception:
+                table = {}
+            if keys <= set(table):
+                for kind, fn, args in self.plan:
+                    if kind == "conv":
+                        args[16] = table[tuple(args[8:16])]
+                self.tuned = {k: table[k] for k in keys}
+                return self.tuned
         with torch.cuda.device(self.dev):
             for kind, fn, args in self.plan:
                 if kind != "conv":
@@ -205,6 +220,14 @@ class YoloEngine:
                     chosen[key] = best[0]
                 args[16] = chosen[key]
         self.tuned = chosen
+        if cache:
+            try:
+                old = json.load(open(cache)) if os.path.exists(cache) else {}
+                old.update({",".join(str(int(x)) for x in k): int(v) for k, v in chosen.items()})
+                os.makedirs(os.path.dirname(cache), exist_ok=True)
+                json.dump(old, open(cache, "w"), indent=0, sort_keys=True)
+            except OSError:
+                pass                                            # read-only checkout: keep the in-memory choice
         return chosen
 
     # ------------------------------------------------------------------------------------------

@@ -29,11 +29,12 @@ SCHEDULES = {"mixed": [0, 2, 4, 3, 5], "point": [0, 9, 2, 5, 1], "heavy": [4, 3]
 NAMES = ["E", "G", "CCM", "Shr", "NLM", "T", "Ct", "S+", "BW", "W"]
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 peak
+TUNE_CACHE = os.path.join(ROOT, "adaptiveisp_amd", "yolo", "tuning", "mi355x.json")
 CONV_KERNEL_NAMES = {1: "k_conv_igemm<128,128,2,2>", 2: "dma::k_conv_igemm_dma<128,128,2,2,2>",
-                     5: "dma2::k_conv_igemm_dma32<128,128,2,2,2,0,64>", 12: "dma2::k_conv_igemm_dma32<256,128,4,2,2,0,64>",
-                     13: "dma2::k_conv_igemm_dma32<256,256,4,2,2,0,64>", 18: "dma2::k_conv_igemm_dma32<128,128,2,2,4,0,32>",
-                     19: "dma2::k_conv_igemm_dma32<128,256,2,4,3,0,32>", 22: "dma2::k_conv_igemm_dma32<128,64,4,1,4,0,32>",
-                     24: "dma2::k_conv_igemm_dma32<256,128,4,2,4,0,32>",
+                     5: "dma2::k_conv_igemm_dma32<128,128,2,2,2,0,64,1>", 12: "dma2::k_conv_igemm_dma32<256,128,4,2,2,0,64,1>",
+                     13: "dma2::k_conv_igemm_dma32<256,256,4,2,2,0,64,1>", 18: "dma2::k_conv_igemm_dma32<128,128,2,2,4,0,32,1>",
+                     19: "dma2::k_conv_igemm_dma32<128,256,2,4,3,0,32,1>", 22: "dma2::k_conv_igemm_dma32<128,64,4,1,4,0,32,1>",
+                     24: "dma2::k_conv_igemm_dma32<256,128,4,2,4,0,32,1>",
                      26: "dma2::k_conv_igemm_dma32<128,256,2,4,3,0,32,4>", 27: "dma2::k_conv_igemm_dma32<256,128,4,2,3,0,32,4>",
                      40: "smallk::k_conv3x3_small<..., 256|128 px>", 41: "smallk::k_conv3x3_small<..., 128|64 px>", 30: "patch::k_conv3x3_patch<128,256,2>", 31: "patch::k_conv3x3_patch<64,256,2>",
                      32: "patch::k_conv3x3_patch<128,128,3>", 33: "patch::k_conv3x3_patch<64,128,3>"}
@@ -49,6 +50,8 @@ def parse():
     ap.add_argument("--width", type=int, default=1280)
     ap.add_argument("--schedule", default="mixed", choices=sorted(SCHEDULES))
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
+    ap.add_argument("--retune", action="store_true", help="re-measure the per-layer conv variants instead of loading "
+                    "adaptiveisp_amd/yolo/tuning/*.json")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-detail", action="store_true", help="skip the per-kernel roofline passes")
     return ap.parse_args()
@@ -63,7 +66,7 @@ def build_workload(a, dev):
     torch.manual_seed(1)
     det = yolov3().eval()
     engine = YoloEngine(det, a.batch, a.height, a.width, device=dev)
-    engine.autotune()
+    engine.autotune(cache=TUNE_CACHE, retune=a.retune)
     g = torch.Generator(device="cpu").manual_seed(1234 + 1)
     x0 = (torch.rand(a.batch, 3, a.height, a.width, generator=g) ** 2.2 * 0.5).to(dev)
     z = torch.rand(a.batch, cfg.z_dim, generator=g).to(dev)
@@ -151,6 +154,23 @@ def time_dominant_conv(engine, x, reps=3):
             "tflops": tot_fl / (tot_ms * 1e-3) / 1e12 if tot_ms else 0.0,
             "flops_per_launch": tot_fl / max(n, 1), "detector_ms": det_ms,
             "detector_tflops": engine.flops / (det_ms * 1e-3) / 1e12}
+
+
+def pmc_traffic(kernel_name):
+    """HBM bytes per launch of `kernel_name` from the committed PMC passes (profiles/*_pmc_traffic.json, produced by
+    tools/refresh_profiles.sh: separate --pmc runs, FETCH_SIZE x2 per the gfx950 note). None if not collected."""
+    import glob
+    best = None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json"))):
+        try:
+            table = json.load(open(path))
+        except Exception:
+            continue
+        key = kernel_name.split("::")[-1].replace(" ", "")
+        for name, rec in table.items():
+            if key and key in name.replace(" ", ""):
+                best = rec["hbm_bytes_per_launch"]
+    return best
 
 
 def cpu_baseline(a, sched):
@@ -256,7 +276,8 @@ def main():
         d = time_dominant_conv(engine, x0)
         line["roofline"] = {"bound": "mfma", "kernel": CONV_KERNEL_NAMES.get(d["variant"], f"conv variant {d['variant']}"),
                             "achieved": round(d["tflops"], 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                            "frac": round(d["tflops"] / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None,
+                            "frac": round(d["tflops"] / MFMA_BF16_PEAK_TFLOPS, 4),
+                            "traffic": pmc_traffic(CONV_KERNEL_NAMES.get(d["variant"], "")),
                             "avg_launch_ms": round(d["avg_launch_ms"], 4), "launches_per_step": d["launches_per_forward"],
                             "flops_per_launch": d["flops_per_launch"]}
         line["detector"] = {"ms": round(d["detector_ms"], 3), "tflops": round(d["detector_tflops"], 1),

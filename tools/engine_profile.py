@@ -7,7 +7,7 @@ from adaptiveisp_amd.yolo import YoloEngine, yolov3
 from adaptiveisp_amd.yolo import _lib
 torch.manual_seed(1)
 eng = YoloEngine(yolov3().eval(), 8, 720, 1280)
-eng.autotune()
+eng.autotune(cache=os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'adaptiveisp_amd', 'yolo', 'tuning', 'mi355x.json'), retune='--retune' in sys.argv)
 x = torch.rand(8, 3, 720, 1280, device="cuda")
 eng(x); torch.cuda.synchronize()
 st = _lib.stream_ptr()
