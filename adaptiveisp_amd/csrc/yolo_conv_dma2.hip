@@ -229,6 +229,8 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void k_conv_igemm_dma32(const C
     }
     __syncthreads();
     constexpr int CPR = BN / 8;
+    // fixed trip count -> fully unrolled, so all residual loads / LDS reads are in flight before the first store
+#pragma unroll
     for (int idx = tid; idx < BM * CPR; idx += kThreads) {
         const int ml = idx / CPR, ch = (idx - ml * CPR) * 8;
         const int m = m0 + ml, n = n0 + ch;

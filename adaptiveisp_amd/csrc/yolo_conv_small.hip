@@ -170,6 +170,8 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv3x3_small(const ConvArgs a
     }
     __syncthreads();
     constexpr int CPR = BN / 8;
+    // fixed trip count -> fully unrolled, so all residual loads / LDS reads are in flight before the first store
+#pragma unroll
     for (int idx = tid; idx < BM * CPR; idx += kThreads) {
         const int ml = idx / CPR, ch = (idx - ml * CPR) * 8;
         const int oy = oy0 + ml / TPW, ox = ox0 + ml % TPW, n = n0 + ch;
