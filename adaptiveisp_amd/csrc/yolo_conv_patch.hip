@@ -73,6 +73,8 @@ __global__ __launch_bounds__(kThreads) void k_conv3x3_patch(const ConvArgs a, in
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* pbuf = smem;
     unsigned char* wring = smem + PALLOC;
+    constexpr int kRing = PALLOC + NSW * WSTAGE, kEpi = BM * CP * 2;
+    float* bias_s = reinterpret_cast<float*>(smem + (kRing > kEpi ? kRing : kEpi));   // [BN]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave % WM, wn = wave / WM;
@@ -85,6 +87,7 @@ __global__ __launch_bounds__(kThreads) void k_conv3x3_patch(const ConvArgs a, in
     const int b = t / tiles_y;
     const int x0 = tx * TPW, y0 = ty * TPH, n0 = nt * BN;
     const unsigned long long zaddr = (unsigned long long)(const void*)g_zero16;
+    for (int i = tid; i < BN; i += kThreads) bias_s[i] = (n0 + i < a.Cout) ? a.bias[n0 + i] : 0.0f;   // once, coalesced
 
     // ---- patch DMA state: instruction j of this wave covers patch rows RPI*(wave*NPI + j) .. +RPI-1 -----------
     const int pslot = lane % PCH, prsub = lane / PCH;
@@ -207,9 +210,8 @@ __global__ __launch_bounds__(kThreads) void k_conv3x3_patch(const ConvArgs a, in
 #pragma unroll
         for (int qd = 0; qd < 4; ++qd) {
             const int nl = wn * TN + ni * 32 + 8 * qd + 4 * (lane >> 5);
-            float bv[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) bv[i] = (n0 + nl + i < a.Cout) ? a.bias[n0 + nl + i] : 0.0f;
+            const float4 b4 = *reinterpret_cast<const float4*>(bias_s + nl);
+            const float bv[4] = {b4.x, b4.y, b4.z, b4.w};
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi) {
                 float v[4];
@@ -250,7 +252,7 @@ template <int CKP, int BN, int NSW>
 static hipError_t launch(ConvArgs a, hipStream_t s) {
     constexpr int PCH = CKP / 8, RPI = 64 / PCH, NPI = (PROWS + RPI * NW - 1) / (RPI * NW);
     constexpr int ring = NPI * NW * RPI * CKP * 2 + NSW * BN * 128, epi = BM * (BN + 8) * 2;
-    constexpr int smem = ring > epi ? ring : epi;
+    constexpr int smem = (ring > epi ? ring : epi) + BN * 4;
     static_assert(smem <= 160 * 1024, "LDS budget");
     auto kern = k_conv3x3_patch<CKP, BN, NSW>;
     static bool configured = false;

@@ -57,6 +57,8 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv3x3_small(const ConvArgs a
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* pbuf = smem;
     unsigned char* wbuf = smem + PBYTES;          // [9][BN][CIN]
+    constexpr int kRing = PBYTES + 9 * BN * RB, kEpi = BM * CP * 2;
+    float* bias_s = reinterpret_cast<float*>(smem + (kRing > kEpi ? kRing : kEpi));   // [BN]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave % WM, wn = wave / WM;
@@ -69,6 +71,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv3x3_small(const ConvArgs a
     const int ox0 = tx * TPW, oy0 = ty * TPH, n0 = nt * BN;
     const int ix0 = ox0 * S - 1, iy0 = oy0 * S - 1;
     const unsigned long long zaddr = (unsigned long long)(const void*)g_zero16;
+    for (int i = tid; i < BN; i += kThreads) bias_s[i] = (n0 + i < a.Cout) ? a.bias[n0 + i] : 0.0f;   // once, coalesced
 
     // ---- one DMA round: patch rows, then the nine weight tiles; instructions are dealt round-robin to the waves ---
     const int slot = lane % CH, rsub = lane / CH;
@@ -152,9 +155,8 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv3x3_small(const ConvArgs a
 #pragma unroll
         for (int qd = 0; qd < 4; ++qd) {
             const int nl = wn * TN + ni * 32 + 8 * qd + 4 * (lane >> 5);
-            float bv[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) bv[i] = (n0 + nl + i < a.Cout) ? a.bias[n0 + nl + i] : 0.0f;
+            const float4 b4 = *reinterpret_cast<const float4*>(bias_s + nl);
+            const float bv[4] = {b4.x, b4.y, b4.z, b4.w};
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi) {
                 float v[4];
@@ -196,7 +198,7 @@ static hipError_t launch(ConvArgs a, hipStream_t s) {
     constexpr int PH = (TPH - 1) * S + 3, PW = (TPW - 1) * S + 3, RPD = 64 / (CIN / 8);
     constexpr int pbytes = ((PH * PW + RPD - 1) / RPD) * RPD * CIN * 2;
     constexpr int ring = pbytes + 9 * BN * CIN * 2, epi = TPH * TPW * (BN + 8) * 2;
-    constexpr int smem = ring > epi ? ring : epi;
+    constexpr int smem = (ring > epi ? ring : epi) + BN * 4;
     static_assert(smem <= 160 * 1024, "LDS budget");
     auto kern = k_conv3x3_small<CIN, BN, S, TPH, TPW, WM, WN>;
     static bool configured = false;
