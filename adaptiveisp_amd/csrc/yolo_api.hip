@@ -44,11 +44,11 @@ int adayolo_conv_fwd_variant(const void* in, int in_cstride, const void* weight,
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (variant == 0) variant = ADAYOLO_DEFAULT_VARIANT;
     hipError_t e = hipErrorInvalidValue;
-    if (variant == 35 || variant == 36) e = launch_conv_dma2(a, s, variant);   // ablation builds
+    if (variant >= 35 && variant <= 39) e = launch_conv_dma2(a, s, variant);   // ablation builds
     else if (variant >= 40) e = launch_conv_small(a, s, variant);            // 3x3, Cin 32/64 only; falls through otherwise
     else if (variant >= 30) e = launch_conv_patch(a, s, variant);       // 3x3 stride-1 only; falls through otherwise
     if (e == hipErrorInvalidValue && variant >= 30) variant = ADAYOLO_DEFAULT_VARIANT;
-    if (variant < 30 && variant != 35 && variant != 36) e = (variant == 1) ? launch_conv(a, s) : (variant >= 5) ? launch_conv_dma2(a, s, variant) : launch_conv_dma(a, s, variant);
+    if (variant < 30) e = (variant == 1) ? launch_conv(a, s) : (variant >= 5) ? launch_conv_dma2(a, s, variant) : launch_conv_dma(a, s, variant);
     return e == hipSuccess ? ADAYOLO_OK : ADAYOLO_ELAUNCH;
 }
 
