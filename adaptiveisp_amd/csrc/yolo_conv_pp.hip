@@ -1,0 +1,326 @@
+// Conv + bias + SiLU (+ residual) — implicit GEMM, 256 px x 256 ch tile, two wave groups in ping-pong.
+//
+// yolo_conv_dma2.hip runs all eight waves of a workgroup in lock-step (barrier -> issue DMA -> LDS reads -> MFMA):
+// while the waves read their fragments the matrix pipes idle, and with one look-ahead stage every k-step ends in
+// vmcnt(0). This kernel keeps its tile / swizzle / lean DMA addressing and changes the schedule:
+//
+//   * wave grid 2 (px) x 4 (ch), wave tile 128 px x 64 ch = four 64x32 quadrants. A k-tile (BK = 64) is four phases,
+//     one quadrant x full BK each (8 x v_mfma_f32_32x32x16_bf16 = 256 matrix-pipe cycles per phase per wave);
+//   * the two wave groups (waves 0-3 / 4-7: one wave of each per SIMD) are staggered by one barrier, so on every
+//     SIMD one wave's MFMA section runs beside the other wave's load section (ds_read_b128 fragment reads + the
+//     LDS-DMA issue for one half-tile) — the matrix pipe always has a client;
+//   * LDS = 2 k-tile buffers x {A-h0, A-h1, W-h0, W-h1} half-tiles of 16 KB (128 rows x 128 B). A half-tile holds
+//     the rows ONE quadrant index touches in every wave, so a slot is dead as soon as that phase's reads retired
+//     and is re-staged two phases later (the WAR distance the stagger needs), 4-5 phases before its data is read:
+//         P1(t): reads A0,W0   stages W1(t+1)        P3(t): reads A1   stages A0(t+2)
+//         P2(t): reads W1      stages A1(t+1)        P4(t): -          stages W0(t+2)
+//     with one counted `s_waitcnt vmcnt(8)` (4 half-tiles stay in flight) in P1, P2 and P4 — never vmcnt(0).
+//     A wait in phase X's load section retires data that is first read in phase X+1 (one barrier more than the
+//     lock-step ring needs, because of the stagger).
+//
+// Restrictions (the launcher falls back otherwise): Cin % 64 == 0, Cout % 256 == 0.
+#include "yolo_internal.h"
+
+namespace adayolo {
+namespace pp {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+
+__device__ __attribute__((aligned(16))) unsigned int g_zero16[4] = {0u, 0u, 0u, 0u};
+
+__device__ __forceinline__ float bf16_to_f32(unsigned short h) { return __uint_as_float(((unsigned)h) << 16); }
+__device__ __forceinline__ unsigned short f32_to_bf16(float f) {
+    unsigned u = __float_as_uint(f);
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+}
+__device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
+    return (unsigned)f32_to_bf16(lo) | ((unsigned)f32_to_bf16(hi) << 16);
+}
+__device__ __forceinline__ float silu(float x) {
+    return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504088896341f * x));
+}
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
+__device__ __forceinline__ void dma16(unsigned long long gaddr, void* l) {
+    __builtin_amdgcn_global_load_lds((gbl_ptr_t)gaddr, (lds_ptr_t)l, 16, 0, 0);
+}
+__device__ __forceinline__ unsigned long long sel(bool ok, unsigned long long p, unsigned long long z) {
+    const unsigned long long m = ok ? ~0ull : 0ull;
+    return (p & m) | (z & ~m);
+}
+__device__ __forceinline__ void barrier() {
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_barrier" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+}
+template <int N>
+__device__ __forceinline__ void wait_vm() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+constexpr int BM = 256, BN = 256, BK = 64;
+constexpr int kRow = BK * 2;                 // bytes per tile row
+constexpr int kTile = 256 * kRow;            // one operand k-tile: 32 KB
+constexpr int kBuf = 2 * kTile;              // A + W of one k-tile
+constexpr int CP = BN + 8;                   // epilogue tile pitch (bf16 elements)
+constexpr int kSmem = BM * CP * 2 + BN * 4;  // epilogue tile (>= the 128 KB ring) + bias
+
+// wave-uniform state of the k-tile a stage call addresses
+struct KPos {
+    int c0, kh, kw, tap;
+    long aoff, woff;
+};
+
+// ABL: 0 real kernel, 1 no DMA in the loop, 2 no LDS reads / MFMA, 3 no epilogue stores, 4 no k-loop (measurement builds)
+template <int ABL>
+__global__ __launch_bounds__(512) void k_conv_pp(const ConvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float* bias_s = reinterpret_cast<float*>(smem + BM * CP * 2);
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;           // wm is also the ping-pong group
+    const int lid = xcd_remap(blockIdx.x, a.mtiles * a.ntiles);
+    const int m0 = (lid / a.ntiles) * BM, n0 = (lid % a.ntiles) * BN;
+    if (tid < BN) bias_s[tid] = a.bias[n0 + tid];
+    const unsigned long long zaddr = (unsigned long long)(const void*)g_zero16;
+
+    // ---- per-row DMA state: one DMA instruction moves 8 tile rows (64 lanes x 16 B); a half-tile is 16 of them,
+    //      two per wave. Index i = 2*half + j.
+    const int slot = lane & 7, rsub = lane >> 3;
+    unsigned long long arow[4], wrow[4];
+    unsigned amask[4];
+    int alds[4], wlds[4];                                // wave-uniform LDS byte offsets inside an operand tile
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int h = i >> 1, g = 2 * wave + (i & 1);
+        {   // activation rows of half h: the first (h=0) / second (h=1) 64 px of each wave row's 128
+            const int rb = (g >> 3) * 128 + h * 64 + (g & 7) * 8, r = rb + rsub;
+            const int q = slot ^ ((r >> 1) & 7);
+            const int m = m0 + r;
+            unsigned mask = 0;
+            long off = 0;
+            if (m < a.M) {
+                const int b = m / (a.Ho * a.Wo), rem = m - b * (a.Ho * a.Wo);
+                const int ho = rem / a.Wo, wo = rem - ho * a.Wo;
+                const int hi0 = ho * a.stride - a.pad, wi0 = wo * a.stride - a.pad;
+                for (int kh = 0; kh < a.ks; ++kh)
+                    for (int kw = 0; kw < a.ks; ++kw)
+                        if (hi0 + kh >= 0 && hi0 + kh < a.H && wi0 + kw >= 0 && wi0 + kw < a.W) mask |= 1u << (kh * a.ks + kw);
+                off = ((long)b * a.H * a.W + (long)hi0 * a.W + wi0) * a.in_cs + 8 * q;
+            }
+            amask[i] = mask;
+            arow[i] = (unsigned long long)(a.in + off);
+            alds[i] = rb * kRow;
+        }
+        {   // weight rows of half h: the first / second 32 channels of each wave column's 64
+            const int rb = (g >> 2) * 64 + h * 32 + (g & 3) * 8, r = rb + rsub;
+            const int q = slot ^ ((r >> 1) & 7);
+            wrow[i] = (unsigned long long)(a.w + (long)(n0 + r) * (a.ks * a.ks * a.Cin) + 8 * q);
+            wlds[i] = kTile + rb * kRow;
+        }
+    }
+    const int cpt = a.Cin / BK;
+    const int nK = a.ks * a.ks * cpt;
+
+    auto advance = [&](KPos& p) {
+        p.c0 += BK;
+        if (p.c0 >= a.Cin) {
+            p.c0 = 0; ++p.tap; ++p.kw;
+            if (p.kw == a.ks) { p.kw = 0; ++p.kh; }
+        }
+        p.aoff = 2 * (((long)p.kh * a.W + p.kw) * a.in_cs + p.c0);
+        p.woff = 2 * ((long)p.tap * a.Cin + p.c0);
+    };
+    auto stage_a = [&](int h, unsigned char* buf, const KPos& p, bool live) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int i = 2 * h + j;
+            const bool ok = live && ((amask[i] >> p.tap) & 1u);
+            dma16(sel(ok, arow[i] + p.aoff, zaddr), buf + alds[i]);
+        }
+    };
+    auto stage_w = [&](int h, unsigned char* buf, const KPos& p, bool live) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int i = 2 * h + j;
+            dma16(sel(live, wrow[i] + p.woff, zaddr), buf + wlds[i]);
+        }
+    };
+
+    f32x16 acc[2][4];                                   // [channel frag][pixel frag]
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[ni][mi][e] = 0.0f;
+
+    // fragment addressing (32x32x16): lane -> tile row (lane & 31), 16-byte k-chunk 2*kk + (lane >> 5), XOR key
+    // (row >> 1) & 7 — the same for every fragment of this lane because fragment origins are multiples of 32 rows
+    const int frow = lane & 31, fq = lane >> 5, key = (frow >> 1) & 7;
+    const int abase = (wm * 128 + frow) * kRow, wbase = kTile + (wn * 64 + frow) * kRow;
+    int koff[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) koff[kk] = ((2 * kk + fq) ^ key) << 4;
+
+    // ---- prologue: k-tile 0 complete, A0 / W0 of k-tile 1 (what P3 / P4 of a preceding k-tile would have staged)
+    KPos p1{0, 0, 0, 0, 0, 0};
+    p1.aoff = 0; p1.woff = 0;
+    stage_a(0, smem, p1, true);
+    stage_w(0, smem, p1, true);
+    stage_w(1, smem, p1, true);
+    stage_a(1, smem, p1, true);
+    advance(p1);
+    stage_a(0, smem + kBuf, p1, 1 < nK);
+    stage_w(0, smem + kBuf, p1, 1 < nK);
+    wait_vm<4>();                                        // k-tile 0 landed (this wave's share)
+    barrier();
+    if (wm == 1) barrier();                              // stagger group 1 by one barrier
+
+    bf16x8 af[2][4], w0[4], w1[4];
+    auto read_a = [&](const unsigned char* buf, int half) {
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+                af[mi][kk] = *reinterpret_cast<const bf16x8*>(buf + abase + (2 * half + mi) * 32 * kRow + koff[kk]);
+    };
+    auto read_w = [&](const unsigned char* buf, int half, bf16x8 (&w)[4]) {
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+            w[kk] = *reinterpret_cast<const bf16x8*>(buf + wbase + half * 32 * kRow + koff[kk]);
+    };
+    auto mma = [&](int ni, int half, const bf16x8 (&w)[4]) {
+        if (ABL == 2) return;
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+                acc[ni][2 * half + mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[kk], af[mi][kk], acc[ni][2 * half + mi], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+    };
+
+    KPos p2 = p1;
+    auto ktile = [&](unsigned char* cur, unsigned char* oth, int t) {
+        const bool live1 = (ABL != 1) && t + 1 < nK, live2 = (ABL != 1) && t + 2 < nK;
+        // P1: quadrant (px half 0, ch half 0)
+        if (ABL != 2) { read_a(cur, 0); read_w(cur, 0, w0); }
+        stage_w(1, oth, p1, live1);
+        wait_vm<8>();
+        barrier();
+        mma(0, 0, w0);
+        barrier();
+        // P2: (px 0, ch 1)
+        if (ABL != 2) read_w(cur, 1, w1);
+        stage_a(1, oth, p1, live1);
+        wait_vm<8>();
+        barrier();
+        mma(1, 0, w1);
+        barrier();
+        // P3: (px 1, ch 1)
+        advance(p2);
+        if (ABL != 2) read_a(cur, 1);
+        stage_a(0, cur, p2, live2);
+        barrier();
+        mma(1, 1, w1);
+        barrier();
+        // P4: (px 1, ch 0)
+        stage_w(0, cur, p2, live2);
+        wait_vm<8>();
+        barrier();
+        mma(0, 1, w0);
+        barrier();
+        p1 = p2;
+    };
+    for (int t = 0; t < (ABL == 4 ? 0 : nK); t += 2) {
+        ktile(smem, smem + kBuf, t);
+        if (t + 1 < nK) ktile(smem + kBuf, smem, t + 1);
+    }
+    if (wm == 0) barrier();                              // pairs with group 1's last barrier
+    wait_vm<0>();                                        // the tail's zero-fill DMAs target the ring the epilogue reuses
+    barrier();
+
+    // ---- epilogue: D[row = channel][col = pixel]; lane holds channels (e&3) + 8*(e>>2) + 4*(lane>>5) -------
+    unsigned short* Cs = reinterpret_cast<unsigned short*>(smem);
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) {
+            const int nl = wn * 64 + ni * 32 + 8 * qd + 4 * (lane >> 5);     // 4 consecutive channels
+            const float4 b4 = *reinterpret_cast<const float4*>(bias_s + nl);
+            const float bv[4] = {b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) {
+                float v[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    v[i] = acc[ni][mi][4 * qd + i] + bv[i];
+                    if (a.act == ADAYOLO_ACT_SILU) v[i] = silu(v[i]);
+                }
+                const int ml = wm * 128 + mi * 32 + (lane & 31);
+                *reinterpret_cast<u32x2*>(Cs + ml * CP + nl) = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+            }
+        }
+    }
+    __syncthreads();
+    constexpr int CPR = BN / 8;
+#pragma unroll
+    for (int idx = tid; idx < BM * CPR; idx += 512) {
+        const int ml = idx / CPR, ch = (idx - ml * CPR) * 8;
+        const int m = m0 + ml, n = n0 + ch;
+        if (m >= a.M) continue;
+        u32x4 v = *reinterpret_cast<const u32x4*>(Cs + ml * CP + ch);
+        if (a.res) {
+            const u32x4 r = *reinterpret_cast<const u32x4*>(a.res + (long)m * a.res_cs + n);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float lo = bf16_to_f32((unsigned short)(v[j] & 0xFFFFu)) + bf16_to_f32((unsigned short)(r[j] & 0xFFFFu));
+                const float hi = bf16_to_f32((unsigned short)(v[j] >> 16)) + bf16_to_f32((unsigned short)(r[j] >> 16));
+                v[j] = pack_bf16x2(lo, hi);
+            }
+        }
+        if (ABL == 3 && v[0] != 0x12345678u) continue;
+        __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(a.out + (long)m * a.out_cs + n));
+    }
+}
+
+template <int ABL>
+static hipError_t launch(ConvArgs a, hipStream_t s) {
+    static_assert(kSmem <= 160 * 1024, "LDS budget");
+    auto kern = k_conv_pp<ABL>;
+    static bool configured = false;
+    if (!configured) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, kSmem);
+        if (e != hipSuccess) return e;
+        configured = true;
+    }
+    a.mtiles = (a.M + BM - 1) / BM;
+    a.ntiles = a.Cout / BN;
+    hipLaunchKernelGGL(kern, dim3(a.mtiles * a.ntiles), dim3(512), kSmem, s, a);
+    return hipGetLastError();
+}
+
+}  // namespace pp
+
+// variant 50 = the kernel, 51..53 = measurement builds. hipErrorInvalidValue -> caller falls back.
+hipError_t launch_conv_pp(ConvArgs a, hipStream_t s, int variant) {
+    if (a.Cin % 64 || a.Cout % 256) return hipErrorInvalidValue;
+    if (variant == 51) return pp::launch<1>(a, s);
+    if (variant == 52) return pp::launch<2>(a, s);
+    if (variant == 53) return pp::launch<3>(a, s);
+    if (variant == 54) return pp::launch<4>(a, s);
+    return pp::launch<0>(a, s);
+}
+
+}  // namespace adayolo
