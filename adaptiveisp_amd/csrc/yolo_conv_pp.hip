@@ -12,11 +12,13 @@
 //   * LDS = 2 k-tile buffers x {A-h0, A-h1, W-h0, W-h1} half-tiles of 16 KB (128 rows x 128 B). A half-tile holds
 //     the rows ONE quadrant index touches in every wave, so a slot is dead as soon as that phase's reads retired
 //     and is re-staged two phases later (the WAR distance the stagger needs), 4-5 phases before its data is read:
-//         P1(t): reads A0,W0   stages W1(t+1)        P3(t): reads A1   stages A0(t+2)
-//         P2(t): reads W1      stages A1(t+1)        P4(t): -          stages W0(t+2)
-//     with one counted `s_waitcnt vmcnt(8)` (4 half-tiles stay in flight) in P1, P2 and P4 — never vmcnt(0).
-//     A wait in phase X's load section retires data that is first read in phase X+1 (one barrier more than the
-//     lock-step ring needs, because of the stagger).
+//         P1(t): reads A0        stages W1(t+1)      P3(t): reads A1        stages W0(t+2)
+//         P2(t): reads W1        stages A1(t+1)      P4(t): reads W0(t+1)   stages A0(t+2)
+//     The two DMA instructions of a phase are issued INSIDE the MFMA section (after the first two MFMAs): issuing
+//     them costs the wave 60-180 cycles each, which in the load section made that section longer than the partner's
+//     256-cycle MFMA section. Every MFMA section ends with one counted `s_waitcnt vmcnt(6)` (three half-tiles stay
+//     in flight) — never vmcnt(0). A wait in phase X's MFMA section retires data that is first read in phase X+2's
+//     load section (with the stagger, only then has every wave passed a barrier behind every other wave's wait).
 //
 // Restrictions (the launcher falls back otherwise): Cin % 64 == 0, Cout % 256 == 0.
 #include "yolo_internal.h"
@@ -37,8 +39,10 @@ __device__ __forceinline__ unsigned short f32_to_bf16(float f) {
     u += 0x7FFFu + ((u >> 16) & 1u);
     return (unsigned short)(u >> 16);
 }
-__device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
-    return (unsigned)f32_to_bf16(lo) | ((unsigned)f32_to_bf16(hi) << 16);
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+__device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {      // round-to-nearest-even: v_cvt_pk_bf16_f32
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{lo, hi}, bf16x2));
 }
 __device__ __forceinline__ float silu(float x) {
     return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504088896341f * x));
@@ -140,21 +144,20 @@ __global__ __launch_bounds__(512) void k_conv_pp(const ConvArgs a) {
         p.aoff = 2 * (((long)p.kh * a.W + p.kw) * a.in_cs + p.c0);
         p.woff = 2 * ((long)p.tap * a.Cin + p.c0);
     };
-    auto stage_a = [&](int h, unsigned char* buf, const KPos& p, bool live) {
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int i = 2 * h + j;
-            const bool ok = live && ((amask[i] >> p.tap) & 1u);
-            dma16(sel(ok, arow[i] + p.aoff, zaddr), buf + alds[i]);
-        }
+    // one DMA instruction (j = 0 / 1) of a half-tile
+    auto stage_a1 = [&](int h, int j, unsigned char* buf, const KPos& p, bool live) {
+        if (ABL == 5 && !live) return;               // measurement build: no DMA instruction at all in the k-loop
+        const int i = 2 * h + j;
+        const bool ok = live && ((amask[i] >> p.tap) & 1u);
+        dma16(sel(ok, arow[i] + p.aoff, zaddr), buf + alds[i]);
     };
-    auto stage_w = [&](int h, unsigned char* buf, const KPos& p, bool live) {
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int i = 2 * h + j;
-            dma16(sel(live, wrow[i] + p.woff, zaddr), buf + wlds[i]);
-        }
+    auto stage_w1 = [&](int h, int j, unsigned char* buf, const KPos& p, bool live) {
+        if (ABL == 5 && !live) return;
+        const int i = 2 * h + j;
+        dma16(sel(live, wrow[i] + p.woff, zaddr), buf + wlds[i]);
     };
+    auto stage_a = [&](int h, unsigned char* buf, const KPos& p, bool live) { stage_a1(h, 0, buf, p, live); stage_a1(h, 1, buf, p, live); };
+    auto stage_w = [&](int h, unsigned char* buf, const KPos& p, bool live) { stage_w1(h, 0, buf, p, live); stage_w1(h, 1, buf, p, live); };
 
     f32x16 acc[2][4];                                   // [channel frag][pixel frag]
 #pragma unroll
@@ -172,22 +175,22 @@ __global__ __launch_bounds__(512) void k_conv_pp(const ConvArgs a) {
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) koff[kk] = ((2 * kk + fq) ^ key) << 4;
 
-    // ---- prologue: k-tile 0 complete, A0 / W0 of k-tile 1 (what P3 / P4 of a preceding k-tile would have staged)
+    // ---- prologue: k-tile 0 complete, W0 / A0 of k-tile 1 (what P3 / P4 of the preceding k-tiles would have staged)
     KPos p1{0, 0, 0, 0, 0, 0};
     p1.aoff = 0; p1.woff = 0;
-    stage_a(0, smem, p1, true);
     stage_w(0, smem, p1, true);
+    stage_a(0, smem, p1, true);
     stage_w(1, smem, p1, true);
     stage_a(1, smem, p1, true);
     advance(p1);
-    stage_a(0, smem + kBuf, p1, 1 < nK);
     stage_w(0, smem + kBuf, p1, 1 < nK);
+    stage_a(0, smem + kBuf, p1, 1 < nK);
     wait_vm<4>();                                        // k-tile 0 landed (this wave's share)
     barrier();
-    if (wm == 1) barrier();                              // stagger group 1 by one barrier
 
-    bf16x8 af[2][4], w0[4], w1[4];
+    bf16x8 af[2][4], wx[4], wy[4];
     auto read_a = [&](const unsigned char* buf, int half) {
+        if (ABL == 2) return;
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
@@ -195,56 +198,71 @@ __global__ __launch_bounds__(512) void k_conv_pp(const ConvArgs a) {
                 af[mi][kk] = *reinterpret_cast<const bf16x8*>(buf + abase + (2 * half + mi) * 32 * kRow + koff[kk]);
     };
     auto read_w = [&](const unsigned char* buf, int half, bf16x8 (&w)[4]) {
+        if (ABL == 2) return;
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk)
             w[kk] = *reinterpret_cast<const bf16x8*>(buf + wbase + half * 32 * kRow + koff[kk]);
     };
-    auto mma = [&](int ni, int half, const bf16x8 (&w)[4]) {
-        if (ABL == 2) return;
+    // MFMA section of one phase: 8 MFMAs with the phase's two LDS-DMA pieces issued in their shadow, then the counted
+    // wait that retires the half-tile issued three phases ago (readable from the load section two phases on)
+    auto mma = [&](int ni, int half, const bf16x8 (&w)[4], auto&& stage) {
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk)
+        for (int kk = 0; kk < 4; ++kk) {
 #pragma unroll
-            for (int mi = 0; mi < 2; ++mi)
-                acc[ni][2 * half + mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[kk], af[mi][kk], acc[ni][2 * half + mi], 0, 0, 0);
+            for (int mi = 0; mi < 2; ++mi) {
+                if (ABL != 2)
+                    acc[ni][2 * half + mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[kk], af[mi][kk], acc[ni][2 * half + mi], 0, 0, 0);
+                const int n = 2 * kk + mi;
+                if (n == 0 || n == 3) {              // one DMA instruction behind the 1st and the 4th MFMA
+                    __builtin_amdgcn_sched_barrier(0);
+                    stage(n == 0 ? 0 : 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
         __builtin_amdgcn_s_setprio(0);
+        wait_vm<6>();
     };
+    read_w(smem, 0, wx);                                 // W0 of k-tile 0
+    if (wm == 1) barrier();                              // stagger group 1 by one barrier
 
     KPos p2 = p1;
-    auto ktile = [&](unsigned char* cur, unsigned char* oth, int t) {
-        const bool live1 = (ABL != 1) && t + 1 < nK, live2 = (ABL != 1) && t + 2 < nK;
+    // w0 / w1: the two weight-fragment register sets; they swap roles every k-tile (P4 loads the next W0 into the
+    // set whose W1 died in P3)
+    auto ktile = [&](unsigned char* cur, unsigned char* oth, int t, bf16x8 (&w0)[4], bf16x8 (&w1)[4]) {
+        const bool live1 = (ABL != 1 && ABL != 5) && t + 1 < nK, live2 = (ABL != 1 && ABL != 5) && t + 2 < nK;
         // P1: quadrant (px half 0, ch half 0)
-        if (ABL != 2) { read_a(cur, 0); read_w(cur, 0, w0); }
-        stage_w(1, oth, p1, live1);
-        wait_vm<8>();
+        auto s1 = [&](int j) { stage_w1(1, j, oth, p1, live1); };
+        auto s2 = [&](int j) { stage_a1(1, j, oth, p1, live1); };
+        auto s3 = [&](int j) { stage_w1(0, j, cur, p2, live2); };
+        auto s4 = [&](int j) { stage_a1(0, j, cur, p2, live2); };
+        read_a(cur, 0);
         barrier();
-        mma(0, 0, w0);
+        mma(0, 0, w0, s1);
         barrier();
         // P2: (px 0, ch 1)
-        if (ABL != 2) read_w(cur, 1, w1);
-        stage_a(1, oth, p1, live1);
-        wait_vm<8>();
+        read_w(cur, 1, w1);
         barrier();
-        mma(1, 0, w1);
+        mma(1, 0, w1, s2);
         barrier();
         // P3: (px 1, ch 1)
         advance(p2);
-        if (ABL != 2) read_a(cur, 1);
-        stage_a(0, cur, p2, live2);
+        read_a(cur, 1);
         barrier();
-        mma(1, 1, w1);
+        mma(1, 1, w1, s3);
         barrier();
-        // P4: (px 1, ch 0)
-        stage_w(0, cur, p2, live2);
-        wait_vm<8>();
+        // P4: (px 1, ch 0); the load section fetches W0 of the NEXT k-tile
+        read_w(oth, 0, w1);
         barrier();
-        mma(0, 1, w0);
+        mma(0, 1, w0, s4);
         barrier();
         p1 = p2;
     };
     for (int t = 0; t < (ABL == 4 ? 0 : nK); t += 2) {
-        ktile(smem, smem + kBuf, t);
-        if (t + 1 < nK) ktile(smem + kBuf, smem, t + 1);
+        ktile(smem, smem + kBuf, t, wx, wy);
+        if (t + 1 < nK) ktile(smem + kBuf, smem, t + 1, wy, wx);
+        else asm volatile("" ::"v"(wy[0]));
     }
     if (wm == 0) barrier();                              // pairs with group 1's last barrier
     wait_vm<0>();                                        // the tail's zero-fill DMAs target the ring the epilogue reuses
@@ -274,13 +292,15 @@ __global__ __launch_bounds__(512) void k_conv_pp(const ConvArgs a) {
     }
     __syncthreads();
     constexpr int CPR = BN / 8;
+    // fixed trip count, no early exits -> fully unrolled: every residual load / LDS read is in flight before the first store
 #pragma unroll
-    for (int idx = tid; idx < BM * CPR; idx += 512) {
+    for (int it = 0; it < BM * CPR / 512; ++it) {
+        const int idx = tid + it * 512;
         const int ml = idx / CPR, ch = (idx - ml * CPR) * 8;
         const int m = m0 + ml, n = n0 + ch;
-        if (m >= a.M) continue;
+        const bool ok = m < a.M;
         u32x4 v = *reinterpret_cast<const u32x4*>(Cs + ml * CP + ch);
-        if (a.res) {
+        if (a.res && ok) {
             const u32x4 r = *reinterpret_cast<const u32x4*>(a.res + (long)m * a.res_cs + n);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -289,8 +309,8 @@ __global__ __launch_bounds__(512) void k_conv_pp(const ConvArgs a) {
                 v[j] = pack_bf16x2(lo, hi);
             }
         }
-        if (ABL == 3 && v[0] != 0x12345678u) continue;
-        __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(a.out + (long)m * a.out_cs + n));
+        if (ok && !(ABL == 3 && v[0] != 0x12345678u))
+            __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(a.out + (long)m * a.out_cs + n));
     }
 }
 
@@ -313,13 +333,14 @@ static hipError_t launch(ConvArgs a, hipStream_t s) {
 
 }  // namespace pp
 
-// variant 50 = the kernel, 51..53 = measurement builds. hipErrorInvalidValue -> caller falls back.
+// variant 50 = the kernel, 51..55 = measurement builds. hipErrorInvalidValue -> caller falls back.
 hipError_t launch_conv_pp(ConvArgs a, hipStream_t s, int variant) {
     if (a.Cin % 64 || a.Cout % 256) return hipErrorInvalidValue;
     if (variant == 51) return pp::launch<1>(a, s);
     if (variant == 52) return pp::launch<2>(a, s);
     if (variant == 53) return pp::launch<3>(a, s);
     if (variant == 54) return pp::launch<4>(a, s);
+    if (variant == 55) return pp::launch<5>(a, s);
     return pp::launch<0>(a, s);
 }
 

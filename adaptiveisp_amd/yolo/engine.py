@@ -171,7 +171,7 @@ class YoloEngine:
         self.views = view
 
     # ------------------------------------------------------------------------------------------
-    TUNE_CANDIDATES = (2, 5, 12, 13, 18, 19, 22, 24, 26, 27, 30, 31, 32, 33, 40, 41)
+    TUNE_CANDIDATES = (2, 5, 12, 13, 18, 19, 22, 24, 26, 27, 30, 31, 32, 33, 40, 41, 50)
 
     def autotune(self, reps=5, cache=None, retune=False):
         """Pick the fastest conv kernel variant per layer by timing it on this engine's own buffers (all variants
@@ -203,8 +203,10 @@ class YoloEngine:
                     for v in self.TUNE_CANDIDATES:
                         if 30 <= v < 40 and not (args[13] == 3 and args[14] == 1):
                             continue                             # patch-resident kernels serve 3x3 stride-1 only
-                        if v >= 40 and not (args[13] == 3 and args[11] in (32, 64)):
+                        if 40 <= v < 50 and not (args[13] == 3 and args[11] in (32, 64)):
                             continue                             # whole-K-resident kernels: 3x3 with Cin 32 / 64
+                        if v >= 50 and (args[11] % 64 or args[12] % 256):
+                            continue                             # ping-pong kernel: Cin % 64 == 0, Cout % 256 == 0
                         args[16] = v
                         fn(*args, st)
                         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
