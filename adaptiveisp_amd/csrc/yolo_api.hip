@@ -86,4 +86,18 @@ int adayolo_detect_decode(const void* raw, int raw_cstride, float* pred, int pre
                                 no, static_cast<hipStream_t>(stream)) == hipSuccess ? ADAYOLO_OK : ADAYOLO_ELAUNCH;
 }
 
+size_t adayolo_nms_workspace_bytes(int n) {
+    const size_t nb = (size_t)((n > 0 ? n : 0) + 63) / 64;
+    return (size_t)(n > 0 ? n : 0) * nb * 8 + 8;
+}
+
+int adayolo_nms(const float* boxes_xyxy, int n, float iou_thres, int max_det, void* workspace, int32_t* keep,
+                int32_t* num_keep, void* stream) {
+    if (n < 0 || max_det <= 0 || !keep || !num_keep || (n > 0 && (!boxes_xyxy || !workspace))) return ADAYOLO_EINVAL;
+    if (n > 30000 * 4) return ADAYOLO_ESHAPE;        // LDS bit set of the scan: n/64 words
+    if (!(iou_thres >= 0.0f && iou_thres <= 1.0f)) return ADAYOLO_EINVAL;
+    return launch_nms(boxes_xyxy, n, iou_thres, max_det, static_cast<unsigned long long*>(workspace), keep, num_keep,
+                      static_cast<hipStream_t>(stream)) == hipSuccess ? ADAYOLO_OK : ADAYOLO_ELAUNCH;
+}
+
 }  // extern "C"

@@ -29,5 +29,7 @@ hipError_t launch_upsample2x(const void* in, int in_cs, void* out, int out_cs, i
 hipError_t launch_detect_decode(const void* raw, int raw_cs, float* pred, int pred_rows, int row_offset,
                                 const float* anchors_px, float det_stride, int B, int ny, int nx, int na, int no,
                                 hipStream_t s);
+hipError_t launch_nms(const float* boxes, int n, float thr, int max_det, unsigned long long* mask_ws, int* keep,
+                      int* num_keep, hipStream_t s);
 
 }  // namespace adayolo

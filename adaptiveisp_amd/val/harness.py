@@ -1,0 +1,84 @@
+"""Evaluation loop — the counterpart of `run()` in yolov3/val_adaptiveisp.py:105-460 for the HIP path:
+per batch, `steps` RL steps of the ISP (early exit when image 0 reports `stopped`, :308), the detector forward,
+NMS, per-image matching, then mAP over the whole set. Dataset I/O is out of scope: the
+caller hands over an iterable of (images [B,3,H,W] fp32 in [0,1], targets [n,6] = (image, class, x, y, w, h)
+normalised, paths, shapes) — the tuple the reference's dataloader yields."""
+import os
+
+import numpy as np
+import torch
+
+from ..util import STATE_STOPPED_DIM
+from .boxes import scale_boxes, xywh2xyxy
+from .metrics import ap_per_class, process_batch
+from .nms import non_max_suppression
+
+
+def run_eval(agent, detector, batches, cfg, steps=5, conf_thres=0.001, iou_thres=0.6, max_det=300, single_cls=False,
+             pipeline=None, records_path=None, nc=80, nms_fn=None):
+    """Returns dict(mp, mr, map50, map75, map, seen, nt, ap_class, ap, records). `detector(x)` -> [B, N, 5+nc]
+    decoded predictions (YoloEngine or the module tree in eval mode). `pipeline`: optional list of forced filter ids
+    per step (val_adaptiveisp.py:292, --pipeline)."""
+    from ..util import get_initial_states, get_noise
+    dev = next(agent.parameters()).device
+    iouv = torch.linspace(0.5, 0.95, 10, device=dev)
+    niou = iouv.numel()
+    stats, records, seen = [], [], 0
+    filter_names = [f.get_short_name() for f in agent.filters]
+    for im, targets, paths, shapes in batches:
+        im = im.to(dev).float()
+        targets = targets.to(dev).clone()
+        nb, _, height, width = im.shape
+        noises = torch.from_numpy(np.array([get_noise(nb, cfg.z_type, cfg.z_dim) for _ in range(steps)])).to(dev)
+        states = torch.from_numpy(get_initial_states(nb, cfg.num_state_dim, len(agent.filters))).to(dev)
+        retouch, ids = im, []
+        with torch.no_grad():
+            for i in range(steps):
+                pipe = None if pipeline is None else pipeline[i]
+                (retouch, states, _, _), dbg, _ = agent((retouch, noises[i], states), 1.0, None, pipe)
+                ids.append([int(v) for v in dbg["selected_filter"].detach().cpu().tolist()])
+                if states[0][STATE_STOPPED_DIM] > 0:
+                    break
+            preds = detector(retouch)
+        for b in range(nb):
+            row = ["-1"] * steps
+            for i, step_ids in enumerate(ids):
+                row[i] = str(step_ids[b])
+            records.append((os.path.split(str(paths[b]))[1], row))
+        targets[:, 2:] *= torch.tensor((width, height, width, height), device=dev)
+        preds = non_max_suppression(preds, conf_thres, iou_thres, multi_label=True, agnostic=single_cls,
+                                    max_det=max_det, nms_fn=nms_fn)
+        for si, pred in enumerate(preds):
+            labels = targets[targets[:, 0] == si, 1:]
+            nl, npr = labels.shape[0], pred.shape[0]
+            shape = shapes[si][0]
+            correct = torch.zeros(npr, niou, dtype=torch.bool, device=dev)
+            seen += 1
+            if npr == 0:
+                if nl:
+                    stats.append((correct, *torch.zeros((2, 0), device=dev), labels[:, 0]))
+                continue
+            if single_cls:
+                pred[:, 5] = 0
+            predn = pred.clone()
+            scale_boxes(im[si].shape[1:], predn[:, :4], shape, shapes[si][1])
+            if nl:
+                tbox = xywh2xyxy(labels[:, 1:5])
+                scale_boxes(im[si].shape[1:], tbox, shape, shapes[si][1])
+                labelsn = torch.cat((labels[:, 0:1], tbox), 1)
+                correct = process_batch(predn, labelsn, iouv)
+            stats.append((correct, pred[:, 4], pred[:, 5], labels[:, 0]))
+    res = dict(mp=0.0, mr=0.0, map50=0.0, map75=0.0, map=0.0, seen=seen, ap_class=np.zeros(0, int), ap=np.zeros((0, niou)),
+               records=records, filter_names=filter_names)
+    stats = [torch.cat(x, 0).cpu().numpy() for x in zip(*stats)] if stats else []
+    if len(stats) and stats[0].any():
+        tp, fp, p, r, f1, ap, ap_class = ap_per_class(*stats)
+        res.update(mp=float(p.mean()), mr=float(r.mean()), map50=float(ap[:, 0].mean()), map75=float(ap[:, 5].mean()),
+                   map=float(ap.mean(1).mean()), ap=ap, ap_class=ap_class)
+    res["nt"] = np.bincount(stats[3].astype(int), minlength=nc) if len(stats) else np.zeros(nc, int)
+    if records_path:
+        with open(records_path, "w") as f:                         # val_adaptiveisp.py:269-322 "records.txt"
+            f.write(",".join(filter_names) + "\n")
+            for name, row in records:
+                f.write(name + "," + ",".join(row) + "\n")
+    return res

@@ -19,6 +19,7 @@
 #ifndef ADAYOLO_H_
 #define ADAYOLO_H_
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -85,6 +86,18 @@ int adayolo_upsample2x(const void* in, int in_cstride, void* out, int out_cstrid
 int adayolo_detect_decode(const void* raw, int raw_cstride, float* pred, int pred_rows, int row_offset,
                           const float* anchors_px, float det_stride,
                           int B, int ny, int nx, int na, int no, void* stream);
+
+/*
+ * Greedy IoU NMS (eval harness; replaces the reference's call of torchvision.ops.nms at
+ * yolov3/utils/general.py:949 — torchvision is an un-vendored dependency, pinned 0.15.2 in requirements.txt).
+ * boxes_xyxy: fp32 [n][4], ALREADY sorted by descending score and offset by class (general.py:945-948).
+ * A box is kept unless an earlier kept box has IoU > iou_thres with it. keep[0..*num_keep) receives the kept
+ * indices in score order (at most max_det; the rest of keep[] is set to -1). workspace: device memory of
+ * adayolo_nms_workspace_bytes(n) bytes. No host synchronisation.
+ */
+size_t adayolo_nms_workspace_bytes(int n);
+int adayolo_nms(const float* boxes_xyxy, int n, float iou_thres, int max_det, void* workspace,
+                int32_t* keep, int32_t* num_keep, void* stream);
 
 const char* adayolo_strerror(int code);
 int adayolo_abi_version(void);

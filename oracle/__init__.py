@@ -40,6 +40,8 @@ def lib():
         L.oracle_select_and_update.argtypes = [f32p, f32p, f32p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                                ctypes.c_int, ctypes.c_float, i32p, f32p]
         L.oracle_select_and_update.restype = ctypes.c_int
+        L.oracle_nms.argtypes = [f32p, ctypes.c_int, ctypes.c_float, ctypes.c_int, i32p]
+        L.oracle_nms.restype = ctypes.c_int
         L.oracle_num_params.argtypes = [ctypes.c_int]
         L.oracle_num_params.restype = ctypes.c_int
         _LIB = L
@@ -85,3 +87,14 @@ def select_and_update(pdf, u, states, train=False, forced=-1, test_steps=5.0):
     lib().oracle_select_and_update(_fp(pdf), _fp(u), _fp(states), B, F, 1 if train else 0, int(forced),
                                    float(test_steps), sel.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), _fp(ns))
     return sel, ns
+
+
+def nms(boxes, iou_thres, max_det=300):
+    """boxes [n,4] xyxy sorted by descending score -> kept indices (int64 numpy), greedy IoU NMS."""
+    boxes = _f32(boxes).reshape(-1, 4)
+    n = boxes.shape[0]
+    keep = np.empty(max(max_det, 1), np.int32)
+    cnt = lib().oracle_nms(_fp(boxes), n, float(iou_thres), int(max_det), keep.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)))
+    if cnt < 0:
+        raise MemoryError("oracle_nms")
+    return keep[:cnt].astype(np.int64)

@@ -340,3 +340,37 @@ int oracle_select_and_update(const float* pdf, const float* u, const float* stat
     }
     return 0;
 }
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Greedy IoU NMS — restates `torchvision.ops.nms(boxes, scores, iou_thres)` as the reference calls it at
+ * yolov3/utils/general.py:949 on boxes already sorted by descending score (general.py:943) and offset by class
+ * (general.py:946-947). torchvision (pinned 0.15.2, requirements.txt:135) is NOT vendored by the reference and
+ * not installed here: this function is written from its published algorithm (keep a box unless an earlier kept
+ * box has IoU > thr; IoU = inter / (area_a + area_b - inter), intersection extents clamped at 0) and is
+ * PARITY UNPINNED against torchvision itself; everything around it (candidate selection, multi-label expansion,
+ * class offsets, max_det) is pinned by tests/golden/evalharness.npz generated from the reference's own
+ * non_max_suppression.
+ * Returns the number of kept boxes (<= max_det); keep[] receives their indices in score order.
+ * ------------------------------------------------------------------------------------------------------------ */
+int oracle_nms(const float* boxes, int n, float thr, int max_det, int32_t* keep) {
+    int count = 0;
+    unsigned char* removed = (unsigned char*)calloc((size_t)(n > 0 ? n : 1), 1);
+    if (!removed) return -1;
+    for (int i = 0; i < n && count < max_det; ++i) {
+        if (removed[i]) continue;
+        keep[count++] = i;
+        const float ax1 = boxes[4 * i], ay1 = boxes[4 * i + 1], ax2 = boxes[4 * i + 2], ay2 = boxes[4 * i + 3];
+        const float area_a = (ax2 - ax1) * (ay2 - ay1);
+        for (int j = i + 1; j < n; ++j) {
+            if (removed[j]) continue;
+            const float bx1 = boxes[4 * j], by1 = boxes[4 * j + 1], bx2 = boxes[4 * j + 2], by2 = boxes[4 * j + 3];
+            const float area_b = (bx2 - bx1) * (by2 - by1);
+            float w = fminf(ax2, bx2) - fmaxf(ax1, bx1), h = fminf(ay2, by2) - fmaxf(ay1, by1);
+            w = fmaxf(w, 0.0f); h = fmaxf(h, 0.0f);
+            const float inter = w * h;
+            if (inter / (area_a + area_b - inter) > thr) removed[j] = 1;
+        }
+    }
+    free(removed);
+    return count;
+}

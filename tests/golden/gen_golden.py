@@ -267,9 +267,103 @@ def main():
     np.savez_compressed(os.path.join(HERE, "select.npz"), **out)
 
     gen_yolo()
+    gen_eval()
     tot = sum(os.path.getsize(os.path.join(HERE, f)) for f in os.listdir(HERE) if f.endswith(".npz"))
     print("fixtures written, total bytes:", tot)
 
 
-if __name__ == "__main__":
+if __name__ == "__main__" and "--eval-only" not in sys.argv:
     main()
+
+
+def _greedy_nms(boxes, scores, iou_thres):
+    """Stand-in for torchvision.ops.nms while generating the eval-harness fixture (torchvision is not installed):
+    its documented algorithm in plain Python, fp32 arithmetic. Only the suppression core comes from here; candidate
+    selection, multi-label expansion, class offsets and max_det are the reference's own code."""
+    order = torch.argsort(scores, descending=True, stable=True)
+    b = boxes[order].float()
+    n = b.shape[0]
+    area = (b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1])
+    removed = torch.zeros(n, dtype=torch.bool)
+    keep = []
+    for i in range(n):
+        if removed[i]:
+            continue
+        keep.append(i)
+        w = (torch.minimum(b[i, 2], b[i + 1:, 2]) - torch.maximum(b[i, 0], b[i + 1:, 0])).clamp(min=0)
+        h = (torch.minimum(b[i, 3], b[i + 1:, 3]) - torch.maximum(b[i, 1], b[i + 1:, 1])).clamp(min=0)
+        inter = w * h
+        removed[i + 1:] |= inter / (area[i] + area[i + 1:] - inter) > iou_thres
+    return order[torch.tensor(keep, dtype=torch.long)]
+
+
+def gen_eval():
+    """Eval-harness fixture: the reference's non_max_suppression / box helpers / process_batch / ap_per_class on
+    seeded synthetic predictions (yolov3/utils/general.py:732-966, utils/metrics.py:31-123,262-280, val.py
+    process_batch == val_adaptiveisp.py:79-103)."""
+    import importlib, io, contextlib
+    import_reference_yolo()
+    gen = importlib.import_module("utils.general")
+    met = importlib.import_module("utils.metrics")
+    with contextlib.redirect_stdout(io.StringIO()):
+        val = importlib.import_module("val")
+    sys.modules["torchvision.ops"].nms = _greedy_nms
+    gen.torchvision.ops = sys.modules["torchvision.ops"]
+    # the reference aborts NMS after a wall-clock limit (general.py:891,962); the slow Python stand-in would trip it
+    gen.time = types.SimpleNamespace(time=lambda: 0.0)
+    rng = np.random.default_rng(77)
+    out = {}
+    # predictions: 2 images x 400 candidates x (5 + 6 classes), clustered boxes so that NMS has work to do
+    B, N, nc = 2, 400, 6
+    centers = rng.uniform(40, 280, (B, 12, 2))
+    pred = np.zeros((B, N, 5 + nc), np.float32)
+    for b in range(B):
+        k = rng.integers(0, 12, N)
+        pred[b, :, 0:2] = centers[b, k] + rng.normal(0, 4, (N, 2))
+        pred[b, :, 2:4] = rng.uniform(20, 90, (N, 2))
+        pred[b, :, 4] = rng.random(N) ** 2
+        pred[b, :, 5:] = rng.random((N, nc)) ** 3
+    out["pred"] = pred
+    for tag, kw in (("ml", dict(conf_thres=0.05, iou_thres=0.6, multi_label=True, max_det=300)),
+                    ("best", dict(conf_thres=0.25, iou_thres=0.45, multi_label=False, max_det=50)),
+                    ("agn", dict(conf_thres=0.1, iou_thres=0.5, multi_label=True, agnostic=True, max_det=20)),
+                    ("cls", dict(conf_thres=0.1, iou_thres=0.5, multi_label=False, classes=[1, 4], max_det=300))):
+        res = gen.non_max_suppression(torch.from_numpy(pred.copy()), **kw)
+        for b, r in enumerate(res):
+            out[f"nms.{tag}.{b}"] = r.numpy()
+    # box helpers
+    boxes = rng.uniform(-20, 700, (50, 4)).astype(np.float32)
+    out["boxes"] = boxes
+    out["xywh2xyxy"] = gen.xywh2xyxy(torch.from_numpy(boxes.copy())).numpy()
+    out["xyxy2xywh"] = gen.xyxy2xywh(torch.from_numpy(boxes.copy())).numpy()
+    out["scale_auto"] = gen.scale_boxes((512, 512), torch.from_numpy(boxes.copy()), (375, 500)).numpy()
+    out["scale_ratio_pad"] = gen.scale_boxes((512, 512), torch.from_numpy(boxes.copy()), (375, 500),
+                                             ((1.024, 1.024), (0.0, 64.0))).numpy()
+    # matching + AP: 300 detections over 5 classes against 60 labels
+    det = np.zeros((300, 6), np.float32)
+    lab = np.zeros((60, 5), np.float32)
+    lab[:, 0] = rng.integers(0, 5, 60)
+    lab[:, 1:3] = rng.uniform(0, 400, (60, 2)); lab[:, 3:5] = lab[:, 1:3] + rng.uniform(20, 120, (60, 2))
+    src = rng.integers(0, 60, 300)
+    det[:, :4] = lab[src, 1:] + rng.normal(0, 6, (300, 4)) * (rng.random((300, 1)) < 0.7)
+    det[:, :4] += rng.uniform(-80, 80, (300, 4)) * (rng.random((300, 1)) < 0.25)
+    det[:, 4] = rng.random(300)
+    det[:, 5] = np.where(rng.random(300) < 0.8, lab[src, 0], rng.integers(0, 5, 300))
+    iouv = torch.linspace(0.5, 0.95, 10)
+    correct = val.process_batch(torch.from_numpy(det), torch.from_numpy(lab), iouv)
+    out["det"], out["lab"], out["correct"] = det, lab, correct.numpy()
+    out["iou"] = met.box_iou(torch.from_numpy(lab[:, 1:]), torch.from_numpy(det[:, :4])).numpy()
+    tp, fp, p, r, f1, ap, cls = met.ap_per_class(correct.numpy(), det[:, 4], det[:, 5], lab[:, 0], names={})
+    out.update(ap_tp=tp, ap_fp=fp, ap_p=p, ap_r=r, ap_f1=f1, ap_ap=ap, ap_cls=cls)
+    rec = np.sort(rng.random(40)); prec = np.sort(rng.random(40))[::-1].copy()
+    a, mpre, mrec = met.compute_ap(rec, prec)
+    out.update(cap_rec=rec, cap_prec=prec, cap_ap=np.float64(a), cap_mpre=mpre, cap_mrec=mrec)
+    np.savez_compressed(os.path.join(HERE, "evalharness.npz"), **out)
+    print("evalharness.npz written")
+
+
+if __name__ == "__main__" and "--eval-only" in sys.argv:
+    import matplotlib
+    matplotlib.use("Agg")
+    import matplotlib.pyplot  # noqa: F401
+    gen_eval()
