@@ -97,11 +97,21 @@ class Detect(nn.Module):
         return raws if self.training else (torch.cat(z, 1), raws)
 
 
+def make_divisible(x, divisor=8):
+    """Channel rounding of the reference's parse_model (yolov3/utils/general.py make_divisible)."""
+    import math
+    return math.ceil(x / divisor) * divisor
+
+
 class DetectionModel(nn.Module):
-    def __init__(self, cfg="yolov3.yaml", ch=3, nc=80, anchors=None):
+    def __init__(self, cfg="yolov3.yaml", ch=3, nc=80, anchors=None, width=1.0):
+        """`width`: the yaml's width_multiple (1.0 = yolov3.yaml); channels are make_divisible(c * width, 8)
+        exactly as the reference's parse_model does (yolov3/models/yolo.py:299-356)."""
         super().__init__()
         layers, chans = [], []
         for frm, n, kind, args in GRAPH:
+            if kind in ("conv", "bneck") and width != 1.0:
+                args = (make_divisible(args[0] * width, 8),) + tuple(args[1:])
             i = len(layers)
             c_prev = ch if i == 0 else (chans[i + frm if frm < 0 else frm] if isinstance(frm, int) else None)
             if kind == "conv":

@@ -268,11 +268,12 @@ def main():
 
     gen_yolo()
     gen_eval()
+    gen_ckpt()
     tot = sum(os.path.getsize(os.path.join(HERE, f)) for f in os.listdir(HERE) if f.endswith(".npz"))
     print("fixtures written, total bytes:", tot)
 
 
-if __name__ == "__main__" and "--eval-only" not in sys.argv:
+if __name__ == "__main__" and "--eval-only" not in sys.argv and "--ckpt-only" not in sys.argv:
     main()
 
 
@@ -367,3 +368,45 @@ if __name__ == "__main__" and "--eval-only" in sys.argv:
     matplotlib.use("Agg")
     import matplotlib.pyplot  # noqa: F401
     gen_eval()
+
+
+def gen_ckpt():
+    """Detector-checkpoint fixture: a width-0.0625 YOLOv3 built by the REFERENCE's Model class and saved the way its
+    trainer saves `yolov3.pt` (yolov3/train.py: {'epoch', 'best_fitness', 'model': deepcopy(model).half(), 'ema',
+    'updates', 'optimizer', 'opt', 'date'}) — i.e. a pickled module whose classes are models.yolo.* / models.common.*.
+    The .pt holds tensors and class NAMES only (no reference source). Golden output = that module, .float().eval()."""
+    import io, contextlib, copy, re
+    Model = import_reference_yolo()
+    text = open("/root/reference/yolov3/models/yolov3.yaml").read()
+    text = re.sub(r"width_multiple:\s*[0-9.]+", "width_multiple: 0.0625", text)
+    os.makedirs("/tmp/adaisp_gen", exist_ok=True)
+    ypath = "/tmp/adaisp_gen/yolov3_w0625.yaml"
+    open(ypath, "w").write(text)
+    with contextlib.redirect_stdout(io.StringIO()), contextlib.redirect_stderr(io.StringIO()):
+        m = Model(ypath, ch=3, nc=7)
+    m.load_state_dict(synth_yolo_state_dict(m, seed=4))
+    m.names = {i: f"c{i}" for i in range(7)}
+    ckpt = {"epoch": 3, "best_fitness": np.array([0.5]), "model": copy.deepcopy(m).half(), "ema": None, "updates": 0,
+            "optimizer": None, "opt": {"weights": "yolov3.pt", "imgsz": 512}, "date": "2025-01-01T00:00:00"}
+    path = os.path.join(HERE, "yolov3_w0625_refpickle.pt")
+    torch.save(ckpt, path)
+    ref = torch.load(path, map_location="cpu", weights_only=False)["model"].float().eval()
+    x = test_image(1, 64, 96, seed=52, special=False)
+    with torch.no_grad():
+        pred, raws = ref(torch.from_numpy(x))
+    fused = copy.deepcopy(ref).fuse().eval()
+    fpath = os.path.join(HERE, "yolov3_w0625_refpickle_fused.pt")
+    torch.save({"model": copy.deepcopy(fused).half()}, fpath)
+    fused = torch.load(fpath, map_location="cpu", weights_only=False)["model"].float().eval()
+    with torch.no_grad():
+        pred_f, _ = fused(torch.from_numpy(x))
+    np.savez_compressed(os.path.join(HERE, "ckpt_import.npz"), x=x, pred=pred.numpy(), raw0=raws[0].numpy(),
+                        pred_fused_fp32=pred_f.numpy(), nparams=np.int64(sum(p.numel() for p in ref.parameters())))
+    print("checkpoint fixtures written:", os.path.getsize(path), os.path.getsize(fpath))
+
+
+if __name__ == "__main__" and "--ckpt-only" in sys.argv:
+    import matplotlib
+    matplotlib.use("Agg")
+    import matplotlib.pyplot  # noqa: F401
+    gen_ckpt()
