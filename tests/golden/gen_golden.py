@@ -269,11 +269,12 @@ def main():
     gen_yolo()
     gen_eval()
     gen_ckpt()
+    gen_replay()
     tot = sum(os.path.getsize(os.path.join(HERE, f)) for f in os.listdir(HERE) if f.endswith(".npz"))
     print("fixtures written, total bytes:", tot)
 
 
-if __name__ == "__main__" and "--eval-only" not in sys.argv and "--ckpt-only" not in sys.argv:
+if __name__ == "__main__" and "--eval-only" not in sys.argv and "--ckpt-only" not in sys.argv and "--replay-only" not in sys.argv:
     main()
 
 
@@ -410,3 +411,63 @@ if __name__ == "__main__" and "--ckpt-only" in sys.argv:
     matplotlib.use("Agg")
     import matplotlib.pyplot  # noqa: F401
     gen_ckpt()
+
+
+def gen_replay():
+    """Replay-memory fixture: the REFERENCE's ReplayMemory methods (replay_memory.py:120-221) driven by a fake dataset
+    object and a scripted state update, with Python's `random` seeded — records the order in which records are drawn."""
+    import random
+    import_reference()
+    import_reference_yolo()
+    sys.path.insert(0, "/root/reference")
+    import replay_memory as rm
+    from config import cfg
+
+    class FakeDataset:
+        def __init__(self):
+            self.n = 0
+
+        def get_next_batch(self, bs):
+            ims, lbs, paths, shapes = [], [], [], []
+            for _ in range(bs):
+                ims.append(np.full((3, 2, 2), self.n, np.float32))
+                lbs.append(np.array([[0, self.n % 5, 0.5, 0.5, 0.2, 0.2]], np.float32))
+                paths.append(f"img{self.n}")
+                shapes.append(((2, 2), ((1.0, 1.0), (0.0, 0.0))))
+                self.n += 1
+            return ims, lbs, paths, shapes
+
+    mem = rm.ReplayMemory.__new__(rm.ReplayMemory)
+    mem.cfg, mem.dataset, mem.image_pool = cfg, FakeDataset(), []
+    mem.target_pool_size, mem.batch_size, mem.fake_output = 16, 4, None
+    random.seed(1234)
+    mem.fill_pool()
+    drawn, steps_after, pool_sizes = [], [], []
+    script = np.random.default_rng(8)
+    for it in range(40):
+        ims, lbs, paths, shapes, states = mem.get_next_fake_batch(4)
+        drawn.append([int(p[3:]) for p in paths])
+        new_states = []
+        for s in states:
+            s = s.copy()
+            s[2] += 1                                                        # step
+            if script.random() < 0.25 or s[2] >= 5:
+                s[1] = 1                                                     # stopped
+            if script.random() < 0.2:
+                s[2] = 9                                                     # over-long trajectory (> 7)
+            new_states.append(s)
+        steps_after.append([[float(s[1]), float(s[2])] for s in new_states])
+        mem.replace_memory(mem.images_and_states_to_records([i + 100 for i in ims], lbs, paths, shapes, new_states))
+        pool_sizes.append(len(mem.image_pool))
+    np.savez_compressed(os.path.join(HERE, "replay.npz"), drawn=np.array(drawn), script=np.array(steps_after),
+                        pool_sizes=np.array(pool_sizes), final_paths=np.array([int(r.path[3:]) for r in mem.image_pool]),
+                        final_im=np.array([float(np.asarray(r.im).reshape(-1)[0]) for r in mem.image_pool]),
+                        max_traj=np.int64(cfg.maximum_trajectory_length), keep_prob=np.float64(cfg.over_length_keep_prob))
+    print("replay.npz written")
+
+
+if __name__ == "__main__" and "--replay-only" in sys.argv:
+    import matplotlib
+    matplotlib.use("Agg")
+    import matplotlib.pyplot  # noqa: F401
+    gen_replay()
