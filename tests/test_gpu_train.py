@@ -1,0 +1,67 @@
+"""RL training loop on the HIP path: replay pool in HBM -> agent (HIP ISP + parameter-gradient kernels) -> frozen
+detector (autograd to the retouched image) -> TD losses -> clip/Adam/LR schedule -> records back into the pool."""
+import os
+import random
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _build(width=0.0625, nc=5, hw=(64, 96), pool=16, bs=4):
+    from _synth import synth_state_dict, synth_yolo_state_dict
+    from adaptiveisp_amd.agent import Agent
+    from adaptiveisp_amd.config import cfg
+    from adaptiveisp_amd.replay import DeviceReplayMemory, SyntheticSource
+    from adaptiveisp_amd.util import Dict
+    from adaptiveisp_amd.value import Value
+    from adaptiveisp_amd.yolo.loss import DetectionLoss, default_hyp
+    from adaptiveisp_amd.yolo.model import DetectionModel
+    c = Dict(cfg)
+    c.replay_memory_size = pool
+    c.save_model_freq = 2
+    agent = Agent(c, shape=(16, 64, 64), device=DEV)
+    agent.load_state_dict(synth_state_dict(agent, seed=0))
+    agent = agent.to(DEV)
+    value = Value(c, shape=(19, 64, 64))
+    value.load_state_dict(synth_state_dict(value, seed=1))
+    value = value.to(DEV)
+    det = DetectionModel(nc=nc, width=width)
+    det.load_state_dict(synth_yolo_state_dict(det))
+    det = det.to(DEV).train()
+    for m in det.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.eval()
+    for p in det.parameters():
+        p.requires_grad_(False)
+    loss_fn = DetectionLoss(det.model[-1].anchors, nc=nc, hyp=default_hyp(nc, hw[1]), device=DEV)
+    replay = DeviceReplayMemory(c, SyntheticSource((3,) + hw, nc=nc, seed=2), bs, DEV, (3,) + hw, rng=random.Random(5))
+    return c, agent, value, det, loss_fn, replay
+
+
+def test_trainer_runs_and_updates(tmp_path):
+    from adaptiveisp_amd.train import Trainer
+    from adaptiveisp_amd.yolo.checkpoint import ISP_KEYS, load_isp_checkpoint
+    np.random.seed(0)
+    torch.manual_seed(0)
+    c, agent, value, det, loss_fn, replay = _build()
+    tr = Trainer(c, agent, value, det, loss_fn, replay, batch_size=4, lr=3e-5, epochs=1, save_dir=str(tmp_path))
+    assert tr.max_iter_step == 250                                       # epochs*1000//batch (train.py:156)
+    before = torch.cat([p.detach().reshape(-1) for p in agent.parameters()]).clone()
+    hist = tr.train(iters=5)
+    torch.cuda.synchronize()
+    assert len(hist) == 5 and all(np.isfinite([h["agent_loss"], h["value_loss"], h["reward"]]).all() for h in hist)
+    after = torch.cat([p.detach().reshape(-1) for p in agent.parameters()])
+    assert (after != before).any()
+    assert len(replay.image_pool) == 16 and len(replay.image_pool) + len(replay.free) == replay.images.shape[0]
+    assert replay.images.device.type == "cuda"                           # the pool never left HBM
+    assert max(float(r.state[2]) for r in replay.image_pool) >= 1.0      # retouched records re-entered the pool
+    # LR schedule 0.1^(3 it / max_it) (train.py:206-218)
+    assert abs(tr.agent_scheduler.get_last_lr()[0] - 3e-5 * 0.1 ** (3 * 5 / 250)) < 1e-12
+    ck = sorted(os.listdir(tmp_path))
+    assert ck == ["ckpt-2.pth", "ckpt-4.pth"]
+    raw = load_isp_checkpoint(str(tmp_path / "ckpt-4.pth"))
+    assert tuple(raw) == ISP_KEYS and raw["iter"] == 4
