@@ -18,7 +18,7 @@ CLIP01 = 1
 NLM_EXACT = 2      # NLM patch sums in the reference's running-sum order (slower); default is the separable kernel
 ABI_VERSION = 3
 
-EXPORTS = ("adaisp_forward", "adaisp_process", "adaisp_backward_params", "adaisp_pool64", "adaisp_num_params",
+EXPORTS = ("adaisp_forward", "adaisp_process", "adaisp_backward_params", "adaisp_pool64", "adaisp_demosaic", "adaisp_num_params",
            "adaisp_policy_conv", "adaisp_policy_fc1", "adaisp_policy_finish",
            "adaisp_strerror", "adaisp_abi_version")
 
@@ -43,6 +43,8 @@ def load():
     L.adaisp_process.argtypes = [ci, vp, vp, vp, ci, ci, ci, ci, cu, vp]
     L.adaisp_backward_params.argtypes = [vp, vp, vp, vp, ci, vp, ci, ci, ci, cu, vp]
     L.adaisp_pool64.argtypes = [vp, vp, ci, ci, ci, vp]
+    L.adaisp_demosaic.argtypes = [vp, vp, ci, ci, ci, ci, ctypes.c_float, ctypes.c_float, vp]
+    L.adaisp_demosaic.restype = ci
     L.adaisp_num_params.argtypes = [ci]
     L.adaisp_strerror.argtypes = [ci]
     L.adaisp_strerror.restype = ctypes.c_char_p
@@ -139,3 +141,37 @@ def pool64(img):
         rc = L.adaisp_pool64(img.data_ptr(), out.data_ptr(), B, H, W, _stream())
     _check(rc, "adaisp_pool64")
     return out
+
+
+CFA = {"RGGB": 0, "GRBG": 1, "GBRG": 2, "BGGR": 3}
+
+
+def demosaic(raw, pattern="RGGB", black_level=0.0, white_level=65535.0, out=None):
+    """Bayer front-end: raw uint16 [B,H,W] on the device -> planar fp32 [B,3,H,W] in [0,1] (include/adaisp.h)."""
+    L = load()
+    if raw.device.type != "cuda":
+        raise AdaispError("demosaic: raw must live on a HIP device (there is no CPU path)")
+    if raw.dtype not in (torch.uint16, torch.int16) or raw.dim() != 3:
+        raise AdaispError(f"demosaic: raw must be uint16 [B,H,W], got {raw.dtype} {tuple(raw.shape)}")
+    raw = raw.contiguous()
+    B, H, W = raw.shape
+    if out is None:
+        out = torch.empty((B, 3, H, W), dtype=torch.float32, device=raw.device)
+    pat = CFA[pattern.upper()] if isinstance(pattern, str) else int(pattern)
+    with torch.cuda.device(raw.device):
+        rc = L.adaisp_demosaic(raw.data_ptr(), out.data_ptr(), B, H, W, pat, float(black_level), float(white_level),
+                               _stream())
+    _check(rc, "adaisp_demosaic")
+    return out
+
+
+def pack_rggb_to_plane(packed):
+    """The reference's 4-channel Bayer packing [..., H/2, W/2, 4] = (R, Gr, Gb, B) (`mosaic`, isp/unprocess_np.py:82-98)
+    -> the flat colour-filter-array plane [..., H, W] (`reconstruct_bayer` :111-128 for 'rggb')."""
+    h2, w2 = packed.shape[-3], packed.shape[-2]
+    plane = packed.new_empty(packed.shape[:-3] + (2 * h2, 2 * w2))
+    plane[..., 0::2, 0::2] = packed[..., 0]
+    plane[..., 0::2, 1::2] = packed[..., 1]
+    plane[..., 1::2, 0::2] = packed[..., 2]
+    plane[..., 1::2, 1::2] = packed[..., 3]
+    return plane

@@ -57,6 +57,15 @@ int adaisp_pool64(const float* img, float* pooled, int B, int H, int W, void* st
                                                                                                 : ADAISP_ELAUNCH;
 }
 
+int adaisp_demosaic(const uint16_t* raw, float* out, int B, int H, int W, int pattern, float black_level,
+                    float white_level, void* stream) {
+    if (!raw || !out || B <= 0 || H <= 0 || W <= 0) return ADAISP_EINVAL;
+    if (pattern < 0 || pattern > 3 || !(white_level > black_level)) return ADAISP_EINVAL;
+    if ((H & 1) || (W & 1) || H < 2 || W < 2 || B > 65535) return ADAISP_ESHAPE;   // whole 2x2 cells
+    return launch_demosaic(raw, out, B, H, W, pattern, black_level, white_level, static_cast<hipStream_t>(stream)) ==
+                   hipSuccess ? ADAISP_OK : ADAISP_ELAUNCH;
+}
+
 int adaisp_process(int op, const float* img, float* out, const float* params, int param_stride, int B, int H, int W,
                    unsigned flags, void* stream) {
     int rc = check_common(img, out, params, param_stride, B, H, W);

@@ -93,6 +93,20 @@ int adaisp_backward_params(const float* img, const float* grad_out,
                            float* grad_params,
                            int B, int H, int W, unsigned flags, void* stream);
 
+/*
+ * Bayer demosaic front-end — an EXTENSION (north_star's raw-Bayer entry; the reference has no demosaic, only the
+ * inverse packing `mosaic` / `reconstruct_bayer`, isp/unprocess_np.py:82-128).
+ * raw: uint16 [B,H,W] colour-filter-array samples; pattern = 2*ry + rx, the position of the RED sample in the 2x2
+ * cell (ADAISP_CFA_RGGB 0, GRBG 1, GBRG 2, BGGR 3). out: planar fp32 [B,3,H,W], bilinear interpolation of
+ * (raw - black_level) / (white_level - black_level); mirrored borders. H and W even.
+ */
+#define ADAISP_CFA_RGGB 0
+#define ADAISP_CFA_GRBG 1
+#define ADAISP_CFA_GBRG 2
+#define ADAISP_CFA_BGGR 3
+int adaisp_demosaic(const uint16_t* raw, float* out, int B, int H, int W, int pattern,
+                    float black_level, float white_level, void* stream);
+
 /* AdaptiveAvgPool2d((64,64)) of a [B,3,H,W] image: agent.py:85,97, value.py:61,63. */
 int adaisp_pool64(const float* img, float* pooled, int B, int H, int W, void* stream);
 

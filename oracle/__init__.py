@@ -40,6 +40,9 @@ def lib():
         L.oracle_select_and_update.argtypes = [f32p, f32p, f32p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                                ctypes.c_int, ctypes.c_float, i32p, f32p]
         L.oracle_select_and_update.restype = ctypes.c_int
+        L.oracle_demosaic.argtypes = [ctypes.POINTER(ctypes.c_uint16), f32p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                      ctypes.c_int, ctypes.c_float, ctypes.c_float]
+        L.oracle_demosaic.restype = ctypes.c_int
         L.oracle_nms.argtypes = [f32p, ctypes.c_int, ctypes.c_float, ctypes.c_int, i32p]
         L.oracle_nms.restype = ctypes.c_int
         L.oracle_num_params.argtypes = [ctypes.c_int]
@@ -98,3 +101,15 @@ def nms(boxes, iou_thres, max_det=300):
     if cnt < 0:
         raise MemoryError("oracle_nms")
     return keep[:cnt].astype(np.int64)
+
+
+def demosaic(raw, pattern=0, black=0.0, white=65535.0):
+    """raw uint16 [B,H,W] -> planar fp32 [B,3,H,W] (bilinear, mirrored borders); pattern = 2*ry + rx of the red sample."""
+    raw = np.ascontiguousarray(raw, dtype=np.uint16)
+    B, H, W = raw.shape
+    out = np.empty((B, 3, H, W), np.float32)
+    rc = lib().oracle_demosaic(raw.ctypes.data_as(ctypes.POINTER(ctypes.c_uint16)), _fp(out), B, H, W, int(pattern),
+                               float(black), float(white))
+    if rc != 0:
+        raise ValueError("oracle_demosaic: H and W must be even, pattern in 0..3")
+    return out

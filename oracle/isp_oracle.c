@@ -374,3 +374,40 @@ int oracle_nms(const float* boxes, int n, float thr, int max_det, int32_t* keep)
     free(removed);
     return count;
 }
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Bayer demosaic (EXTENSION; no reference implementation — the reference only has the inverse packing,
+ * isp/unprocess_np.py:82-98 `mosaic`, :111-128 `reconstruct_bayer`). This function DEFINES the operation for the HIP
+ * kernel: bilinear interpolation of the normalised samples with mirrored (edge-not-repeated) borders; fixed
+ * summation order ((N+S)+(W+E)) and ((NW+NE)+(SW+SE)). pattern = 2*ry + rx: position of the red sample in the cell.
+ * ------------------------------------------------------------------------------------------------------------ */
+static int mirror_idx(int i, int n) { return i < 0 ? -i : (i >= n ? 2 * n - 2 - i : i); }
+
+int oracle_demosaic(const uint16_t* raw, float* out, int B, int H, int W, int pattern, float black, float white) {
+    if (!raw || !out || (H & 1) || (W & 1) || pattern < 0 || pattern > 3) return -1;
+    const int ry = pattern >> 1, rx = pattern & 1;
+    const float inv = 1.0f / (white - black);
+    const long plane = (long)H * W;
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int b = 0; b < B; ++b)
+        for (int y = 0; y < H; ++y) {
+            const uint16_t* src = raw + (long)b * plane;
+            float* o = out + (long)b * 3 * plane;
+            for (int x = 0; x < W; ++x) {
+#define S_(yy, xx) ((((float)src[(long)mirror_idx((yy), H) * W + mirror_idx((xx), W)]) - black) * inv)
+                const float c = S_(y, x), n = S_(y - 1, x), s = S_(y + 1, x), w = S_(y, x - 1), e = S_(y, x + 1);
+                const float cross = ((n + s) + (w + e)) * 0.25f;
+                const float diag = ((S_(y - 1, x - 1) + S_(y - 1, x + 1)) + (S_(y + 1, x - 1) + S_(y + 1, x + 1))) * 0.25f;
+                const float horiz = (w + e) * 0.5f, vert = (n + s) * 0.5f;
+#undef S_
+                const int py = (y - ry) & 1, px = (x - rx) & 1;
+                float r, g, bl;
+                if (py == 0 && px == 0) { r = c; g = cross; bl = diag; }
+                else if (py == 0) { r = horiz; g = c; bl = vert; }
+                else if (px == 0) { r = vert; g = c; bl = horiz; }
+                else { r = diag; g = cross; bl = c; }
+                o[(long)y * W + x] = r; o[plane + (long)y * W + x] = g; o[2 * plane + (long)y * W + x] = bl;
+            }
+        }
+    return 0;
+}

@@ -270,11 +270,12 @@ def main():
     gen_eval()
     gen_ckpt()
     gen_replay()
+    gen_mosaic()
     tot = sum(os.path.getsize(os.path.join(HERE, f)) for f in os.listdir(HERE) if f.endswith(".npz"))
     print("fixtures written, total bytes:", tot)
 
 
-if __name__ == "__main__" and "--eval-only" not in sys.argv and "--ckpt-only" not in sys.argv and "--replay-only" not in sys.argv:
+if __name__ == "__main__" and "--eval-only" not in sys.argv and "--ckpt-only" not in sys.argv and "--replay-only" not in sys.argv and "--mosaic-only" not in sys.argv:
     main()
 
 
@@ -471,3 +472,22 @@ if __name__ == "__main__" and "--replay-only" in sys.argv:
     matplotlib.use("Agg")
     import matplotlib.pyplot  # noqa: F401
     gen_replay()
+
+
+def gen_mosaic():
+    """Bayer packing fixture: the reference's `mosaic` and `reconstruct_bayer` (isp/unprocess_np.py:82-128) on a seeded
+    image — what the demosaic extension must be the inverse of at the sampled sites."""
+    import_reference()
+    from isp import unprocess_np as up
+    rng = np.random.default_rng(12)
+    img = rng.random((10, 14, 3)).astype(np.float32)                 # HWC, as unprocess uses
+    packed = up.mosaic(img, "RGGB")
+    out = {"img": img, "packed": packed}
+    for pat in ("rggb", "bggr", "grbg", "gbrg"):
+        out[f"plane_{pat}"] = up.reconstruct_bayer(packed, pat)
+    np.savez_compressed(os.path.join(HERE, "mosaic.npz"), **out)
+    print("mosaic.npz written")
+
+
+if __name__ == "__main__" and "--mosaic-only" in sys.argv:
+    gen_mosaic()
