@@ -65,8 +65,61 @@ int adayolo_stem_fwd(const float* img, const float* weight, const float* bias, v
     if (!img || !weight || !bias || !out) return ADAYOLO_EINVAL;
     if (B <= 0 || H <= 0 || W <= 0 || Hp < H || pad_top < 0 || pad_top + H > Hp) return ADAYOLO_EINVAL;
     if (Cout != 32 || out_cstride % 8 || out_cstride < Cout || B > 65535) return ADAYOLO_ESHAPE;
-    return launch_stem(img, weight, bias, out, out_cstride, B, H, W, Hp, pad_top, pad_value,
+    return launch_stem(img, weight, bias, out, out_cstride, B, H, W, Hp, pad_top, pad_value, ADAYOLO_ACT_SILU,
                        static_cast<hipStream_t>(stream)) == hipSuccess ? ADAYOLO_OK : ADAYOLO_ELAUNCH;
+}
+
+int adayolo_stem_fwd_act(const float* img, const float* weight, const float* bias, void* out, int out_cstride, int B,
+                         int H, int W, int Hp, int pad_top, float pad_value, int Cout, int act, void* stream) {
+    if (!img || !weight || !bias || !out) return ADAYOLO_EINVAL;
+    if (B <= 0 || H <= 0 || W <= 0 || Hp < H || pad_top < 0 || pad_top + H > Hp) return ADAYOLO_EINVAL;
+    if (act != ADAYOLO_ACT_NONE && act != ADAYOLO_ACT_SILU) return ADAYOLO_EINVAL;
+    if (Cout != 32 || out_cstride % 8 || out_cstride < Cout || B > 65535) return ADAYOLO_ESHAPE;
+    return launch_stem(img, weight, bias, out, out_cstride, B, H, W, Hp, pad_top, pad_value, act,
+                       static_cast<hipStream_t>(stream)) == hipSuccess ? ADAYOLO_OK : ADAYOLO_ELAUNCH;
+}
+
+static bool ok8(int C, int cs) { return C > 0 && C % 8 == 0 && cs % 8 == 0 && cs >= C; }
+
+int adayolo_silu_fwd(const void* pre, int pre_cstride, const void* residual, int res_cstride, void* out,
+                     int out_cstride, long npix, int C, void* stream) {
+    if (!pre || !out || npix <= 0) return ADAYOLO_EINVAL;
+    if (!ok8(C, pre_cstride) || !ok8(C, out_cstride) || (residual && !ok8(C, res_cstride))) return ADAYOLO_ESHAPE;
+    return launch_silu_fwd(pre, pre_cstride, residual, res_cstride, out, out_cstride, npix, C,
+                           static_cast<hipStream_t>(stream)) == hipSuccess ? ADAYOLO_OK : ADAYOLO_ELAUNCH;
+}
+
+int adayolo_silu_bwd(const void* grad_out, int go_cstride, const void* pre, int pre_cstride, void* grad_pre,
+                     int gp_cstride, void* grad_res, int gr_cstride, int accumulate_res, long npix, int C, void* stream) {
+    if (!grad_out || npix <= 0 || (!grad_pre && !grad_res) || (grad_pre && !pre)) return ADAYOLO_EINVAL;
+    if (!ok8(C, go_cstride) || (grad_pre && (!ok8(C, pre_cstride) || !ok8(C, gp_cstride))) ||
+        (grad_res && !ok8(C, gr_cstride))) return ADAYOLO_ESHAPE;
+    return launch_silu_bwd(grad_out, go_cstride, pre, pre_cstride, grad_pre, gp_cstride, grad_res, gr_cstride,
+                           accumulate_res, npix, C, static_cast<hipStream_t>(stream)) == hipSuccess ? ADAYOLO_OK : ADAYOLO_ELAUNCH;
+}
+
+int adayolo_zero_insert2x(const void* in, int in_cstride, void* out, int out_cstride, int B, int Ho, int Wo, int H, int W,
+                          int C, void* stream) {
+    if (!in || !out || B <= 0 || Ho <= 0 || Wo <= 0 || H <= 0 || W <= 0) return ADAYOLO_EINVAL;
+    if (!ok8(C, in_cstride) || !ok8(C, out_cstride) || (H + 1) / 2 != Ho || (W + 1) / 2 != Wo) return ADAYOLO_ESHAPE;
+    return launch_zero_insert(in, in_cstride, out, out_cstride, B, Ho, Wo, H, W, C, static_cast<hipStream_t>(stream)) ==
+                   hipSuccess ? ADAYOLO_OK : ADAYOLO_ELAUNCH;
+}
+
+int adayolo_upsample2x_bwd(const void* grad_out, int go_cstride, void* grad_in, int gi_cstride, int accumulate, int B,
+                           int H, int W, int C, void* stream) {
+    if (!grad_out || !grad_in || B <= 0 || H <= 0 || W <= 0) return ADAYOLO_EINVAL;
+    if (!ok8(C, go_cstride) || !ok8(C, gi_cstride)) return ADAYOLO_ESHAPE;
+    return launch_upsample_bwd(grad_out, go_cstride, grad_in, gi_cstride, accumulate, B, H, W, C,
+                               static_cast<hipStream_t>(stream)) == hipSuccess ? ADAYOLO_OK : ADAYOLO_ELAUNCH;
+}
+
+int adayolo_image_grad(const void* grad_nhwc, int g_cstride, float* grad_img, int B, int H, int W, int Hp, int pad_top,
+                       void* stream) {
+    if (!grad_nhwc || !grad_img || B <= 0 || H <= 0 || W <= 0 || Hp < H || pad_top < 0 || pad_top + H > Hp) return ADAYOLO_EINVAL;
+    if (g_cstride < 4 || g_cstride % 2) return ADAYOLO_ESHAPE;
+    return launch_image_grad(grad_nhwc, g_cstride, grad_img, B, H, W, Hp, pad_top, static_cast<hipStream_t>(stream)) ==
+                   hipSuccess ? ADAYOLO_OK : ADAYOLO_ELAUNCH;
 }
 
 int adayolo_upsample2x(const void* in, int in_cstride, void* out, int out_cstride, int B, int H, int W, int C,

@@ -23,12 +23,22 @@ hipError_t launch_conv_patch(ConvArgs a, hipStream_t s, int variant); // 3x3 s1,
 hipError_t launch_conv_small(ConvArgs a, hipStream_t s, int variant);
 hipError_t launch_conv_pp(ConvArgs a, hipStream_t s, int variant);    // 256x256 ping-pong wave groups (yolo_conv_pp.hip) // 3x3, Cin 32/64, whole K resident (yolo_conv_small.hip)
 hipError_t launch_stem(const float* img, const float* w, const float* bias, void* out, int out_cs, int B, int H,
-                       int W, int Hp, int pad_top, float pad_value, hipStream_t s);
+                       int W, int Hp, int pad_top, float pad_value, int act, hipStream_t s);
 hipError_t launch_upsample2x(const void* in, int in_cs, void* out, int out_cs, int B, int H, int W, int C,
                              hipStream_t s);
 hipError_t launch_detect_decode(const void* raw, int raw_cs, float* pred, int pred_rows, int row_offset,
                                 const float* anchors_px, float det_stride, int B, int ny, int nx, int na, int no,
                                 hipStream_t s);
+hipError_t launch_silu_fwd(const void* pre, int pre_cs, const void* res, int res_cs, void* out, int out_cs, long npix,
+                           int C, hipStream_t s);
+hipError_t launch_silu_bwd(const void* gy, int gy_cs, const void* pre, int pre_cs, void* gp, int gp_cs, void* gres,
+                           int gres_cs, int accumulate, long npix, int C, hipStream_t s);
+hipError_t launch_zero_insert(const void* in, int in_cs, void* out, int out_cs, int B, int Ho, int Wo, int H, int W, int C,
+                              hipStream_t s);
+hipError_t launch_upsample_bwd(const void* gy, int gy_cs, void* gx, int gx_cs, int accumulate, int B, int H, int W, int C,
+                               hipStream_t s);
+hipError_t launch_image_grad(const void* g, int g_cs, float* grad_img, int B, int H, int W, int Hp, int pad_top,
+                             hipStream_t s);
 hipError_t launch_nms(const float* boxes, int n, float thr, int max_det, unsigned long long* mask_ws, int* keep,
                       int* num_keep, hipStream_t s);
 

@@ -50,7 +50,7 @@ def train_iteration(cfg, agent, value, detector, loss_fn, imgs, z, states, label
     through to x (the frozen reward model); `buckets` (adaptiveisp_amd.dist.GradBucket per model) enables the
     data-parallel gradient all-reduce before the 1e-5 clip. Returns the scalars of td_losses plus the retouched batch."""
     from . import dist as adist
-    from .yolo.loss import per_sample_loss
+    from .yolo.loss import batched_per_sample_loss as per_sample_loss
     (retouch, new_states, surrogate, penalty), _, _ = agent((imgs, z, states), progress)
     with torch.no_grad():
         l_in = per_sample_loss(loss_fn, detector(imgs), labels)

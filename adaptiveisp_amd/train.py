@@ -59,7 +59,7 @@ class Trainer:
         else:
             self.replay.replace_memory(feed["records"], retouch, out["new_states"])
         rec = dict(iter=it, agent_loss=float(out["agent_loss"].detach()), value_loss=float(out["value_loss"].detach()),
-                   reward=float(out["reward"].mean()), dropped=bad)
+                   reward=float(out["reward"].detach().mean()), dropped=bad)
         self.history.append(rec)
         self.iter += 1
         if self.save_dir and self.rank == 0 and it % self.cfg.save_model_freq == 0 and it > 0:

@@ -81,11 +81,13 @@ class YoloEngine:
                 ctypes.c_void_p(res.ptr) if res is not None else None, res.cs if res is not None else 0,
                 ctypes.c_void_p(dst.ptr), dst.cs, self.B, src.H, src.W, src.C, cout, k, s, act, 0]   # last: variant
         self.plan.append(("conv", self.L.adayolo_conv_fwd_variant, args))
+        self.ops.append(dict(kind="conv", src=src, dst=dst, res=res, w=w, b=b, k=k, s=s, act=act, cout=cout))
         flops = 2.0 * self.B * dst.H * dst.W * cout * k * k * src.C
         self.flops += flops
 
     def _build(self, model):
         self.flops = 0.0
+        self.ops = []            # the same launches as `plan`, with their views (used by the training engine)
         layers = list(model.model)
         # pass 1: shapes (C,H,W) of every layer output
         shp = []
@@ -130,6 +132,7 @@ class YoloEngine:
                 self._keep += [w, b]
                 self._stem = (w, b, view[0])
                 self.plan.append(("stem", None, None))
+                self.ops.append(dict(kind="stem", dst=view[0], w=w, b=b))
                 self.flops += 2.0 * self.B * self.Hp * self.W * 32 * 27
             elif isinstance(m, Conv):
                 w, b = _pack_conv(*m.folded())
@@ -150,6 +153,7 @@ class YoloEngine:
                 args = (ctypes.c_void_p(src.ptr), src.cs, ctypes.c_void_p(view[i].ptr), view[i].cs, self.B, src.H,
                         src.W, src.C)
                 self.plan.append(("up", self.L.adayolo_upsample2x, args))
+                self.ops.append(dict(kind="up", src=src, dst=view[i]))
             elif isinstance(m, Detect):
                 ins = [view[j] for j in m.f]
                 self.rows = sum(self.na * v.H * v.W for v in ins)
@@ -173,6 +177,9 @@ class YoloEngine:
     # ------------------------------------------------------------------------------------------
     TUNE_CANDIDATES = (2, 5, 12, 13, 18, 19, 22, 24, 26, 27, 30, 31, 32, 33, 40, 41, 50)
 
+    def _plans(self):
+        return [self.plan]
+
     def autotune(self, reps=5, cache=None, retune=False):
         """Pick the fastest conv kernel variant per layer by timing it on this engine's own buffers (all variants
         compute the same result; see include/adayolo.h). Like a vendor library's 'find' step. With `cache` (a JSON
@@ -181,20 +188,21 @@ class YoloEngine:
         import os
         st = _lib.stream_ptr()
         chosen = {}
-        keys = {tuple(args[8:16]) for kind, _, args in self.plan if kind == "conv"}
+        entries = [e for plan in self._plans() for e in plan]
+        keys = {tuple(args[8:16]) for kind, _, args in entries if kind == "conv"}
         if cache and os.path.exists(cache) and not retune:
             try:
                 table = {tuple(int(x) for x in k.split(",")): int(v) for k, v in json.load(open(cache)).items()}
             except Exception:
                 table = {}
             if keys <= set(table):
-                for kind, fn, args in self.plan:
+                for kind, fn, args in entries:
                     if kind == "conv":
                         args[16] = table[tuple(args[8:16])]
                 self.tuned = {k: table[k] for k in keys}
                 return self.tuned
         with torch.cuda.device(self.dev):
-            for kind, fn, args in self.plan:
+            for kind, fn, args in entries:
                 if kind != "conv":
                     continue
                 key = tuple(args[8:16])                      # B,H,W,Cin,Cout,k,s,act

@@ -121,3 +121,47 @@ def per_sample_loss(loss_fn, preds, labels):
         lbox, lobj, lcls = loss_fn(one, t)
         rows.append(lbox + lobj + lcls)
     return torch.stack(rows).view(B, 1)
+
+
+def batched_per_sample_loss(loss_fn, preds, labels):
+    """The same [B,1] per-image losses as `per_sample_loss` in ONE batched pass (the reference loops over the samples
+    in Python, train.py:184-196: 2*B loss evaluations of ~150 tiny launches each per iteration). Every reduction the
+    per-sample call does over "its" batch of one becomes a per-image segment reduction here:
+      lbox_b = mean over image b's matched targets of (1 - CIoU);  lcls_b = mean over (matches of b) x nc of BCE;
+      lobj_b = mean over image b's (na, ny, nx) cells of BCE, weighted by the layer balance."""
+    dev = preds[0].device
+    B = preds[0].shape[0]
+    rows = []
+    for b, lb in enumerate(labels):
+        t = torch.as_tensor(lb).clone().to(dev).float()
+        t[:, 0] = b
+        rows.append(t)
+    targets = torch.cat(rows, 0) if rows else torch.zeros((0, 6), device=dev)
+    assigned = loss_fn.assign(preds, targets)
+    lbox = torch.zeros(B, device=dev)
+    lobj = torch.zeros(B, device=dev)
+    lcls = torch.zeros(B, device=dev)
+    for i, (pi, m) in enumerate(zip(preds, assigned)):
+        tobj = torch.zeros(pi.shape[:4], dtype=pi.dtype, device=dev)
+        n = m["b"].shape[0]
+        if n:
+            bidx = m["b"]
+            cnt = torch.zeros(B, device=dev).index_add_(0, bidx, torch.ones(n, device=dev))
+            inv = torch.where(cnt > 0, 1.0 / cnt.clamp(min=1.0), torch.zeros_like(cnt))
+            pxy, pwh, _, pcls = pi[bidx, m["a"], m["gj"], m["gi"]].split((2, 2, 1, loss_fn.nc), 1)
+            pxy = pxy.sigmoid() * 2 - 0.5
+            pwh = (pwh.sigmoid() * 2) ** 2 * m["anchors"]
+            iou = ciou(torch.cat((pxy, pwh), 1), m["box"]).reshape(-1)
+            lbox = lbox + torch.zeros(B, device=dev).index_add_(0, bidx, 1.0 - iou) * inv
+            tobj[bidx, m["a"], m["gj"], m["gi"]] = iou.detach().clamp(0).type(tobj.dtype)
+            if loss_fn.nc > 1:
+                t = torch.full_like(pcls, loss_fn.cn)
+                t[range(n), m["cls"]] = loss_fn.cp
+                bce = F.binary_cross_entropy_with_logits(pcls, t, reduction="none",
+                                                         pos_weight=torch.tensor([loss_fn.hyp["cls_pw"]], device=dev))
+                lcls = lcls + torch.zeros(B, device=dev).index_add_(0, bidx, bce.sum(1)) * inv / loss_fn.nc
+        obj = F.binary_cross_entropy_with_logits(pi[..., 4], tobj, reduction="none",
+                                                 pos_weight=torch.tensor([loss_fn.hyp["obj_pw"]], device=dev))
+        lobj = lobj + obj.mean(dim=(1, 2, 3)) * loss_fn.balance[i]
+    total = lbox * loss_fn.hyp["box"] + lobj * loss_fn.hyp["obj"] + lcls * loss_fn.hyp["cls"]
+    return total.view(B, 1)

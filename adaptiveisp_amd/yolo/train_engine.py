@@ -1,0 +1,218 @@
+"""Training-mode detector on the HIP path: raw head maps with a gradient back to the input image.
+
+The reward model is frozen (train.py:239-243) and its BatchNorms stay in eval mode, so the forward is the same folded
+conv stack as YoloEngine; what training adds is (a) the three raw head maps instead of the decoded prediction
+(Detect.forward in training mode, yolo.py:56-60) and (b) the data gradient through every layer down to the retouched
+image (train.py:267-271,341-342) — no weight gradients.
+
+Forward (train): every Conv keeps its pre-activation P (bf16): conv kernel without activation -> P, then
+`adayolo_silu_fwd` writes silu(P) (+ shortcut) into the activation. Backward, layer by layer in reverse:
+    dP = dY * silu'(P)  (adayolo_silu_bwd; the shortcut gradient is added into the block input's gradient there)
+    dX (+)= conv(dP, W^T flipped)   — the SAME implicit-GEMM MFMA kernels as the forward (adayolo_conv_fwd_variant);
+                                      stride-2 layers convolve the zero-inserted dP (adayolo_zero_insert2x)
+Upsample backward sums 2x2 blocks, Concat is free (gradients are read from channel slices), the stem's gradient is
+converted from NHWC bf16 to the planar fp32 image layout without the letterbox rows.
+Gradients are bf16 tensors (fp32 accumulation inside every kernel), like the activations.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from .engine import LETTERBOX_VALUE, YoloEngine, _View
+
+
+class YoloTrainEngine(YoloEngine):
+    def __init__(self, model, batch, height, width, device="cuda:0"):
+        super().__init__(model, batch, height, width, device)
+        self._gen = 0
+        self._build_train()
+
+    # ------------------------------------------------------------------------------------------
+    def _dense(self, H, W, C):
+        return _View(self._new(H, W, C), 0, C)
+
+    def _conv_entry(self, src, w, b, dst, k, s, act, res, cout):
+        args = [ctypes.c_void_p(src.ptr), src.cs, ctypes.c_void_p(w.data_ptr()), ctypes.c_void_p(b.data_ptr()),
+                ctypes.c_void_p(res.ptr) if res is not None else None, res.cs if res is not None else 0,
+                ctypes.c_void_p(dst.ptr), dst.cs, self.B, src.H, src.W, src.C, cout, k, s, act, 0]
+        return ("conv", self.L.adayolo_conv_fwd_variant, args)
+
+    def _build_train(self):
+        L, B = self.L, self.B
+        self.tfwd, self.tbwd = [], []
+        gbuf = {}                                   # id(activation buffer) -> gradient buffer of the same shape
+
+        def G(v):
+            if id(v.buf) not in gbuf:
+                gbuf[id(v.buf)] = torch.zeros_like(v.buf)
+                self._keep.append(gbuf[id(v.buf)])
+            return _View(gbuf[id(v.buf)], v.coff, v.C)
+
+        written = []                                # (id(grad buffer), coff, C) ranges that already hold a gradient
+
+        def is_written(v):
+            return any(i == id(v.buf) and c0 <= v.coff and v.coff + v.C <= c0 + C for i, c0, C in written)
+
+        def mark(v):
+            written.append((id(v.buf), v.coff, v.C))
+
+        zeros_bias = {}
+
+        def zb(n):
+            if n not in zeros_bias:
+                zeros_bias[n] = torch.zeros(n, dtype=torch.float32, device=self.dev)
+                self._keep.append(zeros_bias[n])
+            return zeros_bias[n]
+
+        bwd = []                                    # built in forward order, reversed at the end
+        for op in self.ops:
+            if op["kind"] == "stem":
+                dst = op["dst"]
+                P = self._dense(dst.H, dst.W, 32)
+                self._stem_pre = P
+                self.tfwd.append(("stem", None, None))
+                self.tfwd.append(("silu", L.adayolo_silu_fwd, (ctypes.c_void_p(P.ptr), P.cs, None, 0, ctypes.c_void_p(dst.ptr),
+                                                                dst.cs, B * dst.H * dst.W, 32)))
+                # backward: dP0 = dY0 * silu'(P0); 3x3 data gradient to 3 (padded to 8) channels; unpack to planar fp32
+                w = op["w"]                                                         # fp32 [32][3][3][3] (co,kh,kw,ci)
+                wt = torch.zeros(8, 3, 3, 32, dtype=torch.float32, device=self.dev)
+                wt[:3] = w.flip(1, 2).permute(3, 1, 2, 0)
+                wt = wt.to(torch.bfloat16).contiguous()
+                dP, gimg = self._dense(dst.H, dst.W, 32), self._dense(dst.H, dst.W, 8)
+                self._keep.append(wt)
+                self._gimg = gimg
+                bwd.append([("dsilu", L.adayolo_silu_bwd, lambda dst=dst, P=P, dP=dP: (
+                                ctypes.c_void_p(G(dst).ptr), dst.cs, ctypes.c_void_p(P.ptr), P.cs, ctypes.c_void_p(dP.ptr),
+                                dP.cs, None, 0, 0, B * dst.H * dst.W, 32)),
+                            self._conv_entry(dP, wt, zb(8), gimg, 3, 1, _lib.ACT_NONE, None, 8),
+                            ("imggrad", None, None)])
+            elif op["kind"] == "up":
+                src, dst = op["src"], op["dst"]
+                self.tfwd.append(("up", L.adayolo_upsample2x, (ctypes.c_void_p(src.ptr), src.cs, ctypes.c_void_p(dst.ptr),
+                                                                dst.cs, B, src.H, src.W, src.C)))
+                bwd.append([("upbwd", L.adayolo_upsample2x_bwd, ("up", src, dst))])
+            else:
+                src, dst, res, k, s, act, cout = (op[n] for n in ("src", "dst", "res", "k", "s", "act", "cout"))
+                w, b = op["w"], op["b"]
+                wt = w.flip(1, 2).permute(3, 1, 2, 0).contiguous()                    # [Cin][k][k][Cout], taps flipped
+                self._keep.append(wt)
+                if act == _lib.ACT_SILU:
+                    P = self._dense(dst.H, dst.W, cout)
+                    self.tfwd.append(self._conv_entry(src, w, b, P, k, s, _lib.ACT_NONE, None, cout))
+                    self.tfwd.append(("silu", L.adayolo_silu_fwd, (ctypes.c_void_p(P.ptr), P.cs,
+                                                                    ctypes.c_void_p(res.ptr) if res is not None else None,
+                                                                    res.cs if res is not None else 0, ctypes.c_void_p(dst.ptr),
+                                                                    dst.cs, B * dst.H * dst.W, cout)))
+                    dP = self._dense(dst.H, dst.W, cout)
+                else:
+                    P, dP = None, None
+                    self.tfwd.append(self._conv_entry(src, w, b, dst, k, s, act, None, cout))
+                U = self._dense(src.H, src.W, cout) if s == 2 else None
+                bwd.append([("convbwd", None, dict(src=src, dst=dst, res=res, k=k, s=s, cout=cout, wt=wt, P=P, dP=dP, U=U))])
+
+        # resolve the backward launches in reverse order (accumulate-or-overwrite is decided here, once)
+        for group in reversed(bwd):
+            for kind, fn, a in group:
+                if kind == "convbwd":
+                    src, dst, res, k, s, cout, wt, P, dP, U = (a[n] for n in ("src", "dst", "res", "k", "s", "cout", "wt", "P", "dP", "U"))
+                    gdst = G(dst)
+                    if P is not None:
+                        gres, acc = (G(res), int(is_written(G(res)))) if res is not None else (None, 0)
+                        self.tbwd.append(("dsilu", self.L.adayolo_silu_bwd, (
+                            ctypes.c_void_p(gdst.ptr), gdst.cs, ctypes.c_void_p(P.ptr), P.cs, ctypes.c_void_p(dP.ptr), dP.cs,
+                            ctypes.c_void_p(gres.ptr) if gres is not None else None, gres.cs if gres is not None else 0, acc,
+                            self.B * dst.H * dst.W, cout)))
+                        if gres is not None:
+                            mark(gres)
+                        g_in = dP
+                    else:
+                        g_in = gdst                                                    # no activation: dP is dY itself
+                    if s == 2:
+                        self.tbwd.append(("zins", self.L.adayolo_zero_insert2x, (
+                            ctypes.c_void_p(g_in.ptr), g_in.cs, ctypes.c_void_p(U.ptr), U.cs, self.B, dst.H, dst.W, src.H, src.W, cout)))
+                        g_in = U
+                    gsrc = G(src)
+                    acc_view = gsrc if is_written(gsrc) else None
+                    # the data gradient is a stride-1 conv from `cout` channels to the layer's input channels
+                    gin_view = _View(g_in.buf, g_in.coff, cout)
+                    gin_view.H, gin_view.W = (src.H, src.W) if s == 2 else (dst.H, dst.W)
+                    self.tbwd.append(self._conv_entry(gin_view, wt, zb(src.C), gsrc, k, 1, _lib.ACT_NONE, acc_view, src.C))
+                    mark(gsrc)
+                elif kind == "upbwd":
+                    _, src, dst = a
+                    gsrc, gdst = G(src), G(dst)
+                    self.tbwd.append(("upbwd", fn, (ctypes.c_void_p(gdst.ptr), gdst.cs, ctypes.c_void_p(gsrc.ptr), gsrc.cs,
+                                                    int(is_written(gsrc)), self.B, src.H, src.W, src.C)))
+                    mark(gsrc)
+                elif kind == "dsilu":
+                    self.tbwd.append((kind, fn, a()))
+                else:
+                    self.tbwd.append((kind, fn, a))
+        self._graw = [G(v) for v in self.raw]
+
+    def _plans(self):
+        return [self.plan, [e for e in self.tfwd if e[0] == "conv"], [e for e in self.tbwd if e[0] == "conv"]]
+
+    # ------------------------------------------------------------------------------------------
+    def _run(self, plan, img=None, grad_img=None):
+        st = _lib.stream_ptr()
+        for kind, fn, args in plan:
+            if kind == "stem":
+                w, b, _ = self._stem
+                P = self._stem_pre
+                rc = self.L.adayolo_stem_fwd_act(ctypes.c_void_p(img.data_ptr()), ctypes.c_void_p(w.data_ptr()),
+                                                 ctypes.c_void_p(b.data_ptr()), ctypes.c_void_p(P.ptr), P.cs, self.B, self.H,
+                                                 self.W, self.Hp, self.pad_top, LETTERBOX_VALUE, 32, _lib.ACT_NONE, st)
+            elif kind == "imggrad":
+                g = self._gimg
+                rc = self.L.adayolo_image_grad(ctypes.c_void_p(g.ptr), g.cs, ctypes.c_void_p(grad_img.data_ptr()), self.B,
+                                               self.H, self.W, self.Hp, self.pad_top, st)
+            else:
+                rc = fn(*args, st)
+            if rc != 0:
+                _lib.check(rc, f"adayolo {kind}")
+
+    def forward_train(self, img):
+        """img planar fp32 [B,3,H,W] on the device -> the three raw head maps [B,na,ny,nx,no] fp32."""
+        if img.shape != (self.B, 3, self.H, self.W) or img.dtype != torch.float32 or img.device != self.dev:
+            raise ValueError(f"expected fp32 {(self.B, 3, self.H, self.W)} on {self.dev}")
+        img = img.contiguous()
+        with torch.cuda.device(self.dev):
+            self._run(self.tfwd, img=img)
+        self._gen += 1
+        return self.raw_maps()
+
+    def backward_image(self, grads):
+        """grads: three tensors shaped like forward_train's outputs -> d loss / d img, planar fp32 [B,3,H,W]."""
+        for g, gv, v in zip(grads, self._graw, self.raw):
+            t = gv.buf
+            t.zero_()
+            if g is not None:
+                t[..., : self.na * self.no] = g.permute(0, 2, 3, 1, 4).reshape(self.B, v.H, v.W, self.na * self.no).to(torch.bfloat16)
+        grad_img = torch.empty((self.B, 3, self.H, self.W), dtype=torch.float32, device=self.dev)
+        with torch.cuda.device(self.dev):
+            self._run(self.tbwd, grad_img=grad_img)
+        return grad_img
+
+    def __call__(self, img):
+        """Differentiable detector: raw maps with autograd to `img` (the frozen reward model of the RL loop)."""
+        if torch.is_grad_enabled() and img.requires_grad:
+            return list(_DetectorFn.apply(img, self))
+        return self.forward_train(img)
+
+
+class _DetectorFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, img, engine):
+        outs = engine.forward_train(img)
+        ctx.engine, ctx.gen = engine, engine._gen
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        eng = ctx.engine
+        if ctx.gen != eng._gen:
+            raise RuntimeError("YoloTrainEngine: backward after a newer forward overwrote the saved pre-activations "
+                               "(one engine holds one set of buffers; use a second engine for interleaved graphs)")
+        return eng.backward_image(grads), None

@@ -73,6 +73,32 @@ int adayolo_conv_fwd_variant(const void* in, int in_cstride,
 int adayolo_stem_fwd(const float* img, const float* weight, const float* bias, void* out, int out_cstride,
                      int B, int H, int W, int Hp, int pad_top, float pad_value, int Cout, void* stream);
 
+/* adayolo_stem_fwd with the activation selectable (ADAYOLO_ACT_NONE keeps the pre-activation for training). */
+int adayolo_stem_fwd_act(const float* img, const float* weight, const float* bias, void* out, int out_cstride,
+                         int B, int H, int W, int Hp, int pad_top, float pad_value, int Cout, int act, void* stream);
+
+/*
+ * Training side of the frozen reward model (train.py:239-243,262-271,341-342: weights have requires_grad False, the
+ * loss back-propagates THROUGH the detector to the retouched image). The backward convolutions are adayolo_conv_fwd
+ * on transposed / spatially flipped weights (stride-2 layers: on the zero-inserted output gradient); the rest:
+ *   adayolo_silu_fwd        out = silu(pre) (+ residual)            Conv.act / Bottleneck shortcut, common.py:45-59,110-120
+ *   adayolo_silu_bwd        grad_pre = grad_out * silu'(pre) (may be NULL); grad_res (=|+=) grad_out (may be NULL)
+ *   adayolo_zero_insert2x   out[b,2y,2x] = in[b,y,x], 0 elsewhere; out is [B,H,W,C] with (H+1)/2 == Ho
+ *   adayolo_upsample2x_bwd  grad_in[b,y,x] (=|+=) sum of the 2x2 block of grad_out [B,2H,2W,C]
+ *   adayolo_image_grad      NHWC bf16 [B,Hp,W,>=3] -> planar fp32 [B,3,H,W] (rows pad_top .. pad_top+H: letterbox removed)
+ * NHWC bf16 tensors with explicit channel strides, C % 8 == 0, npix = B*H*W.
+ */
+int adayolo_silu_fwd(const void* pre, int pre_cstride, const void* residual, int res_cstride, void* out,
+                     int out_cstride, long npix, int C, void* stream);
+int adayolo_silu_bwd(const void* grad_out, int go_cstride, const void* pre, int pre_cstride, void* grad_pre,
+                     int gp_cstride, void* grad_res, int gr_cstride, int accumulate_res, long npix, int C, void* stream);
+int adayolo_zero_insert2x(const void* in, int in_cstride, void* out, int out_cstride, int B, int Ho, int Wo, int H, int W,
+                          int C, void* stream);
+int adayolo_upsample2x_bwd(const void* grad_out, int go_cstride, void* grad_in, int gi_cstride, int accumulate, int B,
+                           int H, int W, int C, void* stream);
+int adayolo_image_grad(const void* grad_nhwc, int g_cstride, float* grad_img, int B, int H, int W, int Hp, int pad_top,
+                       void* stream);
+
 /* Nearest 2x up-sampling of in[B,H,W,C] into a channel slice of out[B,2H,2W,*] (Upsample + Concat). */
 int adayolo_upsample2x(const void* in, int in_cstride, void* out, int out_cstride,
                        int B, int H, int W, int C, void* stream);

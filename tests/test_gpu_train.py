@@ -65,3 +65,66 @@ def test_trainer_runs_and_updates(tmp_path):
     assert ck == ["ckpt-2.pth", "ckpt-4.pth"]
     raw = load_isp_checkpoint(str(tmp_path / "ckpt-4.pth"))
     assert tuple(raw) == ISP_KEYS and raw["iter"] == 4
+
+
+def test_train_iteration_with_hip_detector_matches_torch_detector():
+    """Same state, same batch: the iteration run with the HIP training engine (bf16 MFMA forward + HIP data-gradient
+    path) gives the same reward / losses as with the fp32 PyTorch module tree, and a parallel gradient on the heads."""
+    from _synth import synth_state_dict, synth_yolo_state_dict, test_image
+    from adaptiveisp_amd import dist as adist
+    from adaptiveisp_amd.agent import Agent
+    from adaptiveisp_amd.config import cfg
+    from adaptiveisp_amd.rl import train_iteration
+    from adaptiveisp_amd.value import Value
+    from adaptiveisp_amd.yolo import YoloTrainEngine, yolov3
+    from adaptiveisp_amd.yolo.loss import DetectionLoss, default_hyp
+    B, H, W = 4, 64, 96
+    det = yolov3()
+    det.load_state_dict(synth_yolo_state_dict(det))
+    det = det.to(DEV).train()
+    for m in det.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.eval()
+    for p in det.parameters():
+        p.requires_grad_(False)
+    Hp = (H + 31) // 32 * 32
+
+    def torch_detector(x):                                   # letterbox like the engine's stem does
+        top = (Hp - x.shape[2]) // 2
+        pad = torch.full((x.shape[0], 3, Hp, x.shape[3]), 114.0 / 255.0, device=x.device)
+        return det(torch.cat([pad[:, :, :top], x, pad[:, :, top + x.shape[2]:]], 2) if Hp != x.shape[2] else x)
+
+    eng = YoloTrainEngine(det, B, H, W, device=DEV)
+    loss_fn = DetectionLoss(det.model[-1].anchors, nc=80, hyp=default_hyp(80, W), device=DEV)
+    imgs = torch.from_numpy(test_image(B, H, W, seed=3, special=False)).to(DEV)
+    labels = [torch.tensor([[0, 1 + b, 0.5, 0.5, 0.3, 0.4]]) for b in range(B)]
+    outs, grads = [], []
+    for detector in (torch_detector, eng):
+        torch.manual_seed(0)
+        agent = Agent(cfg, shape=(16, 64, 64), device=DEV)
+        agent.load_state_dict(synth_state_dict(agent, seed=0))
+        agent = agent.to(DEV).train()
+        value = Value(cfg, shape=(19, 64, 64))
+        value.load_state_dict(synth_state_dict(value, seed=1))
+        value = value.to(DEV).train()
+        z = torch.full((B, cfg.z_dim), 0.37, device=DEV)
+        states = torch.zeros(B, cfg.num_state_dim, device=DEV)
+        opts = [torch.optim.SGD(agent.parameters(), lr=0.0), torch.optim.SGD(value.parameters(), lr=0.0)]
+        captured = {}
+
+        class Bucket(adist.GradBucket):                      # capture the pre-clip gradient
+            def finish(self, work=None):
+                super().finish(work)
+                captured[id(self)] = self.flat.clone()
+
+        bk = [Bucket(agent), Bucket(value)]
+        torch.manual_seed(7)                                 # same dropout masks / sampling in both runs
+        out = train_iteration(cfg, agent, value, detector, loss_fn, imgs, z, states, labels, 0.1, opts, buckets=bk)
+        torch.cuda.synchronize()
+        outs.append(out)
+        grads.append(captured[id(bk[0])])
+    a, b = outs
+    assert torch.allclose(a["reward"], b["reward"], rtol=0.1, atol=2.0), (a["reward"], b["reward"])
+    assert abs(float(a["value_loss"]) - float(b["value_loss"])) <= 0.1 * abs(float(a["value_loss"])) + 1.0
+    cos = torch.nn.functional.cosine_similarity(grads[0].reshape(1, -1), grads[1].reshape(1, -1)).item()
+    assert cos > 0.95, cos

@@ -1,0 +1,129 @@
+"""Detector training path on HIP: element-wise training kernels against PyTorch, and the whole backward (raw head
+maps -> gradient of the input image) against fp32 autograd of the plain module tree."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _p(t):
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def test_silu_fwd_bwd_kernels():
+    from adaptiveisp_amd.yolo import _lib
+    L, st = _lib.load(), _lib.stream_ptr
+    g = torch.Generator().manual_seed(0)
+    B, H, W, C = 2, 5, 7, 24
+    pre = (torch.randn(B, H, W, C, generator=g) * 2).to(torch.bfloat16).to(DEV)
+    res = torch.randn(B, H, W, C, generator=g).to(torch.bfloat16).to(DEV)
+    wide = torch.zeros(B, H, W, C + 16, dtype=torch.bfloat16, device=DEV)           # write into a channel slice
+    out = wide[..., 8:8 + C]
+    _lib.check(L.adayolo_silu_fwd(_p(pre), C, _p(res), C, ctypes.c_void_p(wide.data_ptr() + 16), C + 16, B * H * W, C, st()), "silu")
+    torch.cuda.synchronize()
+    ref = F.silu(pre.float()).to(torch.bfloat16).float() + res.float()
+    assert (out.float() - ref).abs().max() <= 2e-2 * max(1.0, ref.abs().max().item())
+    assert wide[..., :8].abs().sum() == 0 and wide[..., 8 + C:].abs().sum() == 0
+    gy = torch.randn(B, H, W, C, generator=g).to(torch.bfloat16).to(DEV)
+    gp = torch.empty_like(gy)
+    gres = torch.randn(B, H, W, C, generator=g).to(torch.bfloat16).to(DEV)
+    gres0 = gres.clone()
+    _lib.check(L.adayolo_silu_bwd(_p(gy), C, _p(pre), C, _p(gp), C, _p(gres), C, 1, B * H * W, C, st()), "dsilu")
+    torch.cuda.synchronize()
+    x = pre.float().requires_grad_(True)
+    F.silu(x).backward(gy.float())
+    assert (gp.float() - x.grad).abs().max() <= 2e-2 * max(1.0, x.grad.abs().max().item())
+    assert (gres.float() - (gres0.float() + gy.float())).abs().max() <= 3e-2 * 4
+
+
+def test_zero_insert_and_upsample_bwd():
+    from adaptiveisp_amd.yolo import _lib
+    L, st = _lib.load(), _lib.stream_ptr
+    g = torch.Generator().manual_seed(1)
+    B, Ho, Wo, C = 2, 3, 5, 8
+    x = torch.randn(B, Ho, Wo, C, generator=g).to(torch.bfloat16).to(DEV)
+    u = torch.full((B, 2 * Ho, 2 * Wo, C), 7.0, dtype=torch.bfloat16, device=DEV)
+    _lib.check(L.adayolo_zero_insert2x(_p(x), C, _p(u), C, B, Ho, Wo, 2 * Ho, 2 * Wo, C, st()), "zins")
+    ref = torch.zeros_like(u)
+    ref[:, 0::2, 0::2] = x
+    assert torch.equal(u, ref)
+    gy = torch.randn(B, 2 * Ho, 2 * Wo, C, generator=g).to(torch.bfloat16).to(DEV)
+    gx = torch.ones(B, Ho, Wo, C, dtype=torch.bfloat16, device=DEV)
+    _lib.check(L.adayolo_upsample2x_bwd(_p(gy), C, _p(gx), C, 1, B, Ho, Wo, C, st()), "upbwd")
+    r = gy.float().view(B, Ho, 2, Wo, 2, C).sum((2, 4)) + 1.0
+    assert (gx.float() - r).abs().max() <= 3e-2 * max(1.0, r.abs().max().item())
+
+
+def test_dgrad_is_conv_with_flipped_weights():
+    """The identity the backward engine relies on, checked on the conv kernel itself (stride 1 and 2)."""
+    from adaptiveisp_amd.yolo import _lib
+    L, st = _lib.load(), _lib.stream_ptr
+    g = torch.Generator().manual_seed(2)
+    for (H, W, cin, cout, k, s) in [(12, 20, 16, 32, 3, 1), (12, 20, 32, 16, 1, 1), (12, 20, 16, 32, 3, 2)]:
+        B = 2
+        w = (torch.randn(cout, k, k, cin, generator=g) / (k * k * cin) ** 0.5).to(torch.bfloat16).to(DEV)
+        Ho, Wo = (H - 1) // s + 1, (W - 1) // s + 1
+        dP = torch.randn(B, Ho, Wo, cout, generator=g).to(torch.bfloat16).to(DEV)
+        x = torch.zeros(B, cin, H, W, device=DEV, requires_grad=True)
+        y = F.conv2d(x, w.float().permute(0, 3, 1, 2), stride=s, padding=k // 2)
+        y.backward(dP.float().permute(0, 3, 1, 2))
+        ref = x.grad.permute(0, 2, 3, 1)
+        wt = w.flip(1, 2).permute(3, 1, 2, 0).contiguous()
+        g_in = dP
+        if s == 2:
+            g_in = torch.empty(B, H, W, cout, dtype=torch.bfloat16, device=DEV)
+            _lib.check(L.adayolo_zero_insert2x(_p(dP), cout, _p(g_in), cout, B, Ho, Wo, H, W, cout, st()), "zins")
+        out = torch.empty(B, H, W, cin, dtype=torch.bfloat16, device=DEV)
+        zb = torch.zeros(cin, device=DEV)
+        _lib.check(L.adayolo_conv_fwd(_p(g_in), cout, _p(wt), _p(zb), None, 0, _p(out), cin, B, H, W, cout, cin, k, 1, 0, st()), "dgrad")
+        torch.cuda.synchronize()
+        assert (out.float() - ref).abs().max() <= 2e-2 * max(1.0, ref.abs().max().item()), (H, W, cin, cout, k, s)
+
+
+@pytest.mark.parametrize("B,H,W", [(2, 64, 96), (1, 72, 128)])
+def test_backward_to_image_vs_fp32_autograd(B, H, W):
+    from _synth import synth_yolo_state_dict, test_image
+    from adaptiveisp_amd.yolo import YoloTrainEngine, yolov3
+    det = yolov3()
+    det.load_state_dict(synth_yolo_state_dict(det, seed=2))
+    det = det.to(DEV).train()
+    for m in det.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.eval()
+    for p in det.parameters():
+        p.requires_grad_(False)
+    eng = YoloTrainEngine(det, B, H, W, device=DEV)
+    x = torch.from_numpy(test_image(B, H, W, seed=61, special=False)).to(DEV)
+    Hp = (H + 31) // 32 * 32
+    top = (Hp - H) // 2
+    g = torch.Generator().manual_seed(5)
+    # reference: fp32 module tree on the letterboxed image
+    xr = x.clone().requires_grad_(True)
+    boxed = torch.full((B, 3, Hp, W), 114.0 / 255.0, device=DEV)
+    boxed = torch.cat([boxed[:, :, :top], xr, boxed[:, :, top + H:]], 2) if Hp != H else xr
+    raws_ref = det(boxed)
+    R = [torch.randn(r.shape, generator=g).to(DEV) for r in raws_ref]
+    sum((r * w).sum() for r, w in zip(raws_ref, R)).backward()
+    # HIP path
+    xh = x.clone().requires_grad_(True)
+    raws = eng(xh)
+    for a, b in zip(raws, raws_ref):
+        assert (a - b.detach()).abs().max() <= 5e-2 * max(1.0, b.abs().max().item())
+    sum((r * w).sum() for r, w in zip(raws, R)).backward()
+    torch.cuda.synchronize()
+    gh, gr = xh.grad, xr.grad
+    assert torch.isfinite(gh).all()
+    rel = ((gh - gr).norm() / gr.norm()).item()
+    cos = F.cosine_similarity(gh.reshape(1, -1), gr.reshape(1, -1)).item()
+    assert rel < 0.08 and cos > 0.995, (rel, cos)
+    # a stale backward (another forward ran in between) must fail loudly, not use overwritten buffers
+    xs = x.clone().requires_grad_(True)
+    stale = eng(xs)
+    eng.forward_train(x)
+    with pytest.raises(RuntimeError):
+        sum(r.sum() for r in stale).backward()

@@ -42,3 +42,35 @@ def test_libadayolo_exports_header_symbols():
         assert hasattr(L, n)
     assert L.adayolo_abi_version() == _lib.ABI_VERSION
     assert L.adayolo_conv_fwd(None, 8, None, None, None, 0, None, 8, 1, 4, 4, 8, 8, 1, 1, 0, None) == -1
+
+
+def test_batched_per_sample_loss_equals_the_loop(golden):
+    """One batched pass == the reference's per-sample Python loop (train.py:184-196), incl. images without targets,
+    and == the reference's own numbers (detloss.npz sample0/sample1)."""
+    import torch
+    from adaptiveisp_amd.yolo.loss import DetectionLoss, batched_per_sample_loss, per_sample_loss
+    g = golden("detloss")
+    hyp = dict(box=0.05, cls=0.5, obj=1.0 * (96 / 640) ** 2, anchor_t=4.0, cls_pw=1.0, obj_pw=1.0, fl_gamma=0.0,
+               label_smoothing=0.0)
+    crit = DetectionLoss(torch.from_numpy(g["anchors"]), nc=80, hyp=hyp)
+    preds = [torch.from_numpy(g[f"p{i}"]) for i in range(3)]
+    T = torch.from_numpy(g["targets"])
+    labels = [T[T[:, 0] == b].clone() for b in range(2)]
+    got = batched_per_sample_loss(crit, preds, labels)
+    for b in range(2):
+        assert abs(float(got[b]) - float(g[f"sample{b}"].sum())) < 2e-5 * max(1.0, abs(float(got[b])))
+    # 4 images, one of them without any target, a duplicate-cell pair in another
+    gen = torch.Generator().manual_seed(3)
+    preds4 = [torch.randn(4, 3, 8, 12, 85, generator=gen), torch.randn(4, 3, 4, 6, 85, generator=gen),
+              torch.randn(4, 3, 2, 3, 85, generator=gen)]
+    labels4 = [labels[0], torch.zeros((0, 6)), labels[1], torch.tensor([[0, 7, 0.5, 0.5, 0.2, 0.2], [0, 7, 0.5, 0.5, 0.2, 0.2]])]
+    a = batched_per_sample_loss(crit, preds4, labels4)
+    b = per_sample_loss(crit, preds4, labels4)
+    assert torch.allclose(a, b, rtol=1e-5, atol=1e-6), (a, b)
+    # gradients agree too
+    for p in preds4:
+        p.requires_grad_(True)
+    ga = torch.autograd.grad(batched_per_sample_loss(crit, preds4, labels4).sum(), preds4)
+    gb = torch.autograd.grad(per_sample_loss(crit, preds4, labels4).sum(), preds4)
+    for x, y in zip(ga, gb):
+        assert torch.allclose(x, y, rtol=1e-4, atol=1e-7)
