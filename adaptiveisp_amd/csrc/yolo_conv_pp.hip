@@ -83,7 +83,8 @@ struct KPos {
     long aoff, woff;
 };
 
-// ABL: 0 real kernel, 1 no DMA in the loop, 2 no LDS reads / MFMA, 3 no epilogue stores, 4 no k-loop (measurement builds)
+// ABL: 0 real kernel, 1 no DMA in the loop, 2 no LDS reads / MFMA, 3 no epilogue stores, 4 no k-loop, 5 no DMA
+// instructions in the loop, 6 no epilogue (measurement builds)
 template <int ABL>
 __global__ __launch_bounds__(512) void k_conv_pp(const ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -268,6 +269,13 @@ __global__ __launch_bounds__(512) void k_conv_pp(const ConvArgs a) {
     wait_vm<0>();                                        // the tail's zero-fill DMAs target the ring the epilogue reuses
     barrier();
 
+    if (ABL == 6) {                                      // measurement build: prologue + k-loop only
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) asm volatile("" ::"v"(acc[ni][mi]));
+        return;
+    }
     // ---- epilogue: D[row = channel][col = pixel]; lane holds channels (e&3) + 8*(e>>2) + 4*(lane>>5) -------
     unsigned short* Cs = reinterpret_cast<unsigned short*>(smem);
 #pragma unroll
@@ -341,6 +349,7 @@ hipError_t launch_conv_pp(ConvArgs a, hipStream_t s, int variant) {
     if (variant == 53) return pp::launch<3>(a, s);
     if (variant == 54) return pp::launch<4>(a, s);
     if (variant == 55) return pp::launch<5>(a, s);
+    if (variant == 56) return pp::launch<6>(a, s);
     return pp::launch<0>(a, s);
 }
 
