@@ -32,6 +32,8 @@ typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
 
 __device__ __attribute__((aligned(16))) unsigned int g_zero16[4] = {0u, 0u, 0u, 0u};
+__device__ unsigned long long g_stamp[4096 * 8];     // ABL 7: per-workgroup s_memtime stamps (measurement build)
+#define PP_STAMP(k) do { if (ABL == 7 && threadIdx.x == 0 && blockIdx.x < 4096) g_stamp[blockIdx.x * 8 + (k)] = __builtin_readcyclecounter(); } while (0)
 
 __device__ __forceinline__ float bf16_to_f32(unsigned short h) { return __uint_as_float(((unsigned)h) << 16); }
 __device__ __forceinline__ unsigned short f32_to_bf16(float f) {
@@ -89,6 +91,7 @@ template <int ABL>
 __global__ __launch_bounds__(512) void k_conv_pp(const ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float* bias_s = reinterpret_cast<float*>(smem + BM * CP * 2);
+    PP_STAMP(0);
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -176,6 +179,7 @@ __global__ __launch_bounds__(512) void k_conv_pp(const ConvArgs a) {
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) koff[kk] = ((2 * kk + fq) ^ key) << 4;
 
+    PP_STAMP(1);
     // ---- prologue: k-tile 0 complete, W0 / A0 of k-tile 1 (what P3 / P4 of the preceding k-tiles would have staged)
     KPos p1{0, 0, 0, 0, 0, 0};
     p1.aoff = 0; p1.woff = 0;
@@ -225,6 +229,7 @@ __global__ __launch_bounds__(512) void k_conv_pp(const ConvArgs a) {
         __builtin_amdgcn_s_setprio(0);
         wait_vm<6>();
     };
+    PP_STAMP(2);
     read_w(smem, 0, wx);                                 // W0 of k-tile 0
     if (wm == 1) barrier();                              // stagger group 1 by one barrier
 
@@ -265,6 +270,7 @@ __global__ __launch_bounds__(512) void k_conv_pp(const ConvArgs a) {
         if (t + 1 < nK) ktile(smem + kBuf, smem, t + 1, wy, wx);
         else asm volatile("" ::"v"(wy[0]));
     }
+    PP_STAMP(3);
     if (wm == 0) barrier();                              // pairs with group 1's last barrier
     wait_vm<0>();                                        // the tail's zero-fill DMAs target the ring the epilogue reuses
     barrier();
@@ -298,7 +304,9 @@ __global__ __launch_bounds__(512) void k_conv_pp(const ConvArgs a) {
             }
         }
     }
+    PP_STAMP(4);
     __syncthreads();
+    PP_STAMP(5);
     constexpr int CPR = BN / 8;
     // fixed trip count, no early exits -> fully unrolled: every residual load / LDS read is in flight before the first store
 #pragma unroll
@@ -320,6 +328,8 @@ __global__ __launch_bounds__(512) void k_conv_pp(const ConvArgs a) {
         if (ok && !(ABL == 3 && v[0] != 0x12345678u))
             __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(a.out + (long)m * a.out_cs + n));
     }
+    PP_STAMP(6);
+    if (ABL == 7) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); PP_STAMP(7); }
 }
 
 template <int ABL>
@@ -350,7 +360,13 @@ hipError_t launch_conv_pp(ConvArgs a, hipStream_t s, int variant) {
     if (variant == 54) return pp::launch<4>(a, s);
     if (variant == 55) return pp::launch<5>(a, s);
     if (variant == 56) return pp::launch<6>(a, s);
+    if (variant == 57) return pp::launch<7>(a, s);
     return pp::launch<0>(a, s);
+}
+
+// measurement helper (not part of the ABI): copies the stamps of the last variant-57 launch
+extern "C" int adayolo_debug_stamps(unsigned long long* dst, int n) {
+    return hipMemcpyFromSymbol(dst, HIP_SYMBOL(pp::g_stamp), sizeof(unsigned long long) * n) == hipSuccess ? 0 : -1;
 }
 
 }  // namespace adayolo
