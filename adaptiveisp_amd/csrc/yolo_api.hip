@@ -3,6 +3,16 @@
 
 using namespace adayolo;
 
+// n / d == umulhi(n, magic) >> sh for every 0 <= n < 2^31 (magic = ceil(2^(31+L) / d), L = ceil(log2 d), sh = L - 1)
+static void magic_div(unsigned d, unsigned* magic, int* sh) {
+    if (d <= 1) { *magic = 0; *sh = -1; return; }
+    int L = 0;
+    while ((1ull << L) < d) ++L;
+    const unsigned long long num = 1ull << (31 + L);
+    *magic = (unsigned)((num + d - 1) / d);
+    *sh = L - 1;
+}
+
 extern "C" {
 
 int adayolo_abi_version(void) { return ADAYOLO_ABI_VERSION; }
@@ -41,6 +51,8 @@ int adayolo_conv_fwd_variant(const void* in, int in_cstride, const void* weight,
     const long M = (long)B * a.Ho * a.Wo;
     if (M > 0x7fffffffL || (long)B * H * W * in_cstride > 0x7fffffffffL) return ADAYOLO_ESHAPE;
     a.M = (int)M; a.mtiles = a.ntiles = 0;
+    magic_div((unsigned)(a.Ho * a.Wo), &a.magic_hw, &a.sh_hw);
+    magic_div((unsigned)a.Wo, &a.magic_w, &a.sh_w);
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (variant == 0) variant = ADAYOLO_DEFAULT_VARIANT;
     hipError_t e = hipErrorInvalidValue;

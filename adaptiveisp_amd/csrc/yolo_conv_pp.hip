@@ -76,8 +76,9 @@ constexpr int BM = 256, BN = 256, BK = 64;
 constexpr int kRow = BK * 2;                 // bytes per tile row
 constexpr int kTile = 256 * kRow;            // one operand k-tile: 32 KB
 constexpr int kBuf = 2 * kTile;              // A + W of one k-tile
-constexpr int CP = BN + 8;                   // epilogue tile pitch (bf16 elements)
-constexpr int kSmem = BM * CP * 2 + BN * 4;  // epilogue tile (>= the 128 KB ring) + bias
+constexpr int kEpiPitch = 144;                // bytes per pixel row of a wave's private epilogue region (64 ch + pad)
+constexpr int kEpi = 8 * 128 * kEpiPitch;     // 8 waves x 128 px: 144 KB, overlays the (finished) ring
+constexpr int kSmem = (kEpi > 2 * kBuf ? kEpi : 2 * kBuf) + BN * 4;   // + bias
 
 // wave-uniform state of the k-tile a stage call addresses
 struct KPos {
@@ -90,7 +91,7 @@ struct KPos {
 template <int ABL>
 __global__ __launch_bounds__(512) void k_conv_pp(const ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    float* bias_s = reinterpret_cast<float*>(smem + BM * CP * 2);
+    float* bias_s = reinterpret_cast<float*>(smem + (kEpi > 2 * kBuf ? kEpi : 2 * kBuf));
     PP_STAMP(0);
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -98,7 +99,6 @@ __global__ __launch_bounds__(512) void k_conv_pp(const ConvArgs a) {
     const int wm = wave >> 2, wn = wave & 3;           // wm is also the ping-pong group
     const int lid = xcd_remap(blockIdx.x, a.mtiles * a.ntiles);
     const int m0 = (lid / a.ntiles) * BM, n0 = (lid % a.ntiles) * BN;
-    if (tid < BN) bias_s[tid] = a.bias[n0 + tid];
     const unsigned long long zaddr = (unsigned long long)(const void*)g_zero16;
 
     // ---- per-row DMA state: one DMA instruction moves 8 tile rows (64 lanes x 16 B); a half-tile is 16 of them,
@@ -107,35 +107,44 @@ __global__ __launch_bounds__(512) void k_conv_pp(const ConvArgs a) {
     unsigned long long arow[4], wrow[4];
     unsigned amask[4];
     int alds[4], wlds[4];                                // wave-uniform LDS byte offsets inside an operand tile
+    // weights first: their addresses need no division, so their DMA can be in flight while the pixel rows are decoded
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int h = i >> 1, g = 2 * wave + (i & 1);
-        {   // activation rows of half h: the first (h=0) / second (h=1) 64 px of each wave row's 128
+        // weight rows of half h: the first / second 32 channels of each wave column's 64
+        const int rb = (g >> 2) * 64 + h * 32 + (g & 3) * 8, r = rb + rsub;
+        const int q = slot ^ ((r >> 1) & 7);
+        wrow[i] = (unsigned long long)(a.w + (long)(n0 + r) * (a.ks * a.ks * a.Cin) + 8 * q);
+        wlds[i] = kTile + rb * kRow;
+    }
+    auto decode_rows = [&]() {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int h = i >> 1, g = 2 * wave + (i & 1);
+            // activation rows of half h: the first (h=0) / second (h=1) 64 px of each wave row's 128
             const int rb = (g >> 3) * 128 + h * 64 + (g & 7) * 8, r = rb + rsub;
             const int q = slot ^ ((r >> 1) & 7);
             const int m = m0 + r;
             unsigned mask = 0;
             long off = 0;
             if (m < a.M) {
-                const int b = m / (a.Ho * a.Wo), rem = m - b * (a.Ho * a.Wo);
-                const int ho = rem / a.Wo, wo = rem - ho * a.Wo;
+                // m -> (image, row, column) by multiply-high (the two runtime divisions cost ~80 VALU each otherwise)
+                const int b = a.sh_hw < 0 ? m : (int)(__umulhi((unsigned)m, a.magic_hw) >> a.sh_hw);
+                const int rem = m - b * (a.Ho * a.Wo);
+                const int ho = a.sh_w < 0 ? rem : (int)(__umulhi((unsigned)rem, a.magic_w) >> a.sh_w);
+                const int wo = rem - ho * a.Wo;
                 const int hi0 = ho * a.stride - a.pad, wi0 = wo * a.stride - a.pad;
+                unsigned vw = 0;                               // tap validity is separable: rows x columns
+                for (int kw = 0; kw < a.ks; ++kw) vw |= (unsigned)(wi0 + kw >= 0 && wi0 + kw < a.W) << kw;
                 for (int kh = 0; kh < a.ks; ++kh)
-                    for (int kw = 0; kw < a.ks; ++kw)
-                        if (hi0 + kh >= 0 && hi0 + kh < a.H && wi0 + kw >= 0 && wi0 + kw < a.W) mask |= 1u << (kh * a.ks + kw);
+                    if (hi0 + kh >= 0 && hi0 + kh < a.H) mask |= vw << (kh * a.ks);
                 off = ((long)b * a.H * a.W + (long)hi0 * a.W + wi0) * a.in_cs + 8 * q;
             }
             amask[i] = mask;
             arow[i] = (unsigned long long)(a.in + off);
             alds[i] = rb * kRow;
         }
-        {   // weight rows of half h: the first / second 32 channels of each wave column's 64
-            const int rb = (g >> 2) * 64 + h * 32 + (g & 3) * 8, r = rb + rsub;
-            const int q = slot ^ ((r >> 1) & 7);
-            wrow[i] = (unsigned long long)(a.w + (long)(n0 + r) * (a.ks * a.ks * a.Cin) + 8 * q);
-            wlds[i] = kTile + rb * kRow;
-        }
-    }
+    };
     const int cpt = a.Cin / BK;
     const int nK = a.ks * a.ks * cpt;
 
@@ -180,14 +189,17 @@ __global__ __launch_bounds__(512) void k_conv_pp(const ConvArgs a) {
     for (int kk = 0; kk < 4; ++kk) koff[kk] = ((2 * kk + fq) ^ key) << 4;
 
     PP_STAMP(1);
-    // ---- prologue: k-tile 0 complete, W0 / A0 of k-tile 1 (what P3 / P4 of the preceding k-tiles would have staged)
-    KPos p1{0, 0, 0, 0, 0, 0};
-    p1.aoff = 0; p1.woff = 0;
-    stage_w(0, smem, p1, true);
-    stage_a(0, smem, p1, true);
-    stage_w(1, smem, p1, true);
-    stage_a(1, smem, p1, true);
+    // ---- prologue: bias (one 1 KB DMA by wave 0), k-tile 0 complete, W0 / A0 of k-tile 1 (what P3 / P4 of the
+    //      preceding k-tiles would have staged). Issue order = retire order: the 8 instructions of k-tile 0 come first.
+    KPos p0{0, 0, 0, 0, 0, 0};
+    KPos p1 = p0;
     advance(p1);
+    if (wave == 0) dma16((unsigned long long)(a.bias + n0) + 16 * lane, bias_s);
+    stage_w(0, smem, p0, true);
+    stage_w(1, smem, p0, true);
+    decode_rows();
+    stage_a(0, smem, p0, true);
+    stage_a(1, smem, p0, true);
     stage_w(0, smem + kBuf, p1, 1 < nK);
     stage_a(0, smem + kBuf, p1, 1 < nK);
     wait_vm<4>();                                        // k-tile 0 landed (this wave's share)
@@ -272,7 +284,7 @@ __global__ __launch_bounds__(512) void k_conv_pp(const ConvArgs a) {
     }
     PP_STAMP(3);
     if (wm == 0) barrier();                              // pairs with group 1's last barrier
-    wait_vm<0>();                                        // the tail's zero-fill DMAs target the ring the epilogue reuses
+    wait_vm<0>();                                        // the tail's zero-fill DMAs target the ring the epilogue overlays
     barrier();
 
     if (ABL == 6) {                                      // measurement build: prologue + k-loop only
@@ -282,51 +294,50 @@ __global__ __launch_bounds__(512) void k_conv_pp(const ConvArgs a) {
             for (int mi = 0; mi < 4; ++mi) asm volatile("" ::"v"(acc[ni][mi]));
         return;
     }
-    // ---- epilogue: D[row = channel][col = pixel]; lane holds channels (e&3) + 8*(e>>2) + 4*(lane>>5) -------
-    unsigned short* Cs = reinterpret_cast<unsigned short*>(smem);
+    // ---- epilogue. D[row = channel][col = pixel]: lane holds pixel (lane & 31) and channels 8*qd + 4*(lane >> 5) + (0..3)
+    //      of every 32x32 fragment. Each wave transposes its own 128 px x 64 ch through a PRIVATE LDS region (pitch
+    //      144 B: 16-byte aligned rows, 2-way write conflicts at most) — no workgroup barrier, a wave's stores leave
+    //      as soon as its own fragment is converted — and writes whole 128-byte row segments (8 lanes x 16 B).
+    //      (Storing 8/16-byte pieces straight from the fragment layout was measured 2x slower: 32 rows x 32 B per
+    //      instruction instead of 8 rows x 128 B.)
+    unsigned char* my = smem + wave * (128 * kEpiPitch);
 #pragma unroll
-    for (int ni = 0; ni < 2; ++ni) {
+    for (int mi = 0; mi < 4; ++mi) {
 #pragma unroll
-        for (int qd = 0; qd < 4; ++qd) {
-            const int nl = wn * 64 + ni * 32 + 8 * qd + 4 * (lane >> 5);     // 4 consecutive channels
-            const float4 b4 = *reinterpret_cast<const float4*>(bias_s + nl);
-            const float bv[4] = {b4.x, b4.y, b4.z, b4.w};
+        for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
-            for (int mi = 0; mi < 4; ++mi) {
+            for (int qd = 0; qd < 4; ++qd) {
+                const int nl = wn * 64 + ni * 32 + 8 * qd + 4 * (lane >> 5);
+                const float4 b4 = *reinterpret_cast<const float4*>(bias_s + nl);
+                const float bv[4] = {b4.x, b4.y, b4.z, b4.w};
                 float v[4];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     v[i] = acc[ni][mi][4 * qd + i] + bv[i];
                     if (a.act == ADAYOLO_ACT_SILU) v[i] = silu(v[i]);
                 }
-                const int ml = wm * 128 + mi * 32 + (lane & 31);
-                *reinterpret_cast<u32x2*>(Cs + ml * CP + nl) = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+                *reinterpret_cast<u32x2*>(my + (mi * 32 + (lane & 31)) * kEpiPitch + (ni * 32 + 8 * qd + 4 * (lane >> 5)) * 2) =
+                    u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
             }
-        }
-    }
-    PP_STAMP(4);
-    __syncthreads();
-    PP_STAMP(5);
-    constexpr int CPR = BN / 8;
-    // fixed trip count, no early exits -> fully unrolled: every residual load / LDS read is in flight before the first store
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // same wave wrote and reads: in-order LDS, no barrier
 #pragma unroll
-    for (int it = 0; it < BM * CPR / 512; ++it) {
-        const int idx = tid + it * 512;
-        const int ml = idx / CPR, ch = (idx - ml * CPR) * 8;
-        const int m = m0 + ml, n = n0 + ch;
-        const bool ok = m < a.M;
-        u32x4 v = *reinterpret_cast<const u32x4*>(Cs + ml * CP + ch);
-        if (a.res && ok) {
-            const u32x4 r = *reinterpret_cast<const u32x4*>(a.res + (long)m * a.res_cs + n);
+        for (int it = 0; it < 4; ++it) {
+            const int row = mi * 32 + it * 8 + (lane >> 3), chunk = lane & 7;
+            const int m = m0 + wm * 128 + row, n = n0 + wn * 64 + chunk * 8;
+            const bool ok = m < a.M;
+            u32x4 v = *reinterpret_cast<const u32x4*>(my + row * kEpiPitch + chunk * 16);
+            if (a.res && ok) {
+                const u32x4 r = *reinterpret_cast<const u32x4*>(a.res + (long)m * a.res_cs + n);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float lo = bf16_to_f32((unsigned short)(v[j] & 0xFFFFu)) + bf16_to_f32((unsigned short)(r[j] & 0xFFFFu));
-                const float hi = bf16_to_f32((unsigned short)(v[j] >> 16)) + bf16_to_f32((unsigned short)(r[j] >> 16));
-                v[j] = pack_bf16x2(lo, hi);
+                for (int j = 0; j < 4; ++j) {
+                    const float lo = bf16_to_f32((unsigned short)(v[j] & 0xFFFFu)) + bf16_to_f32((unsigned short)(r[j] & 0xFFFFu));
+                    const float hh = bf16_to_f32((unsigned short)(v[j] >> 16)) + bf16_to_f32((unsigned short)(r[j] >> 16));
+                    v[j] = pack_bf16x2(lo, hh);
+                }
             }
+            if (ok && !(ABL == 3 && v[0] != 0x12345678u))
+                __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(a.out + (long)m * a.out_cs + n));
         }
-        if (ok && !(ABL == 3 && v[0] != 0x12345678u))
-            __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(a.out + (long)m * a.out_cs + n));
     }
     PP_STAMP(6);
     if (ABL == 7) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); PP_STAMP(7); }

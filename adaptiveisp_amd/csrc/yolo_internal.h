@@ -14,6 +14,9 @@ struct ConvArgs {
     int B, H, W, Cin, Cout, Ho, Wo, ks, stride, pad, act;
     int M;            // B*Ho*Wo
     int mtiles, ntiles;
+    // division by Ho*Wo and by Wo as multiply-high + shift (exact for 0 <= n < 2^31; sh < 0: divisor is 1)
+    unsigned magic_hw, magic_w;
+    int sh_hw, sh_w;
 };
 
 hipError_t launch_conv(ConvArgs a, hipStream_t s);                    // register-staged (yolo_conv.hip)

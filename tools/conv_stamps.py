@@ -25,9 +25,10 @@ for (H, W, cin, cout, k, s) in [(92, 160, 128, 256, 3, 1), (46, 80, 256, 512, 3,
     assert L.adayolo_debug_stamps(buf.ctypes.data, n * 8) == 0
     t = buf.reshape(n, 8).astype(np.float64)
     t0 = t[:, 0].min()
-    names = ["row state", "prologue DMA + wait", "k-loop", "tail + epilogue math + LDS", "barrier", "store issue", "store drain"]
+    names = ["weight rows + kernel args", "row decode + prologue DMA + wait", "k-loop", "tail + epilogue (math, residual, store issue)", "store drain"]
+    t = t[:, [0, 1, 2, 3, 6, 7]]
     d = np.diff(t, axis=1)
-    print(f"{H}x{W} {cin}->{cout}: {nwg} workgroups, kernel span {(t[:, 7].max() - t0):.0f} ticks; first-round start spread {np.percentile(t[:, 0] - t0, 50):.0f} (median)")
+    print(f"{H}x{W} {cin}->{cout}: {nwg} workgroups, kernel span {(t[:, 5].max() - t0):.0f} ticks; first-round start spread {np.percentile(t[:, 0] - t0, 50):.0f} (median)")
     for i, nm in enumerate(names):
         print(f"   {nm:28s} median {np.median(d[:, i]):8.0f}  p90 {np.percentile(d[:, i], 90):8.0f} ticks")
-    print(f"   whole workgroup             median {np.median(t[:, 7] - t[:, 0]):8.0f} ticks; start times (ticks since first): p50 {np.percentile(t[:,0]-t0,50):.0f} p99 {np.percentile(t[:,0]-t0,99):.0f}")
+    print(f"   whole workgroup             median {np.median(t[:, 5] - t[:, 0]):8.0f} ticks; start times (ticks since first): p50 {np.percentile(t[:,0]-t0,50):.0f} p99 {np.percentile(t[:,0]-t0,99):.0f}")
