@@ -84,8 +84,10 @@ __global__ __launch_bounds__(kThreads) void k_conv_igemm_dma(const ConvArgs a) {
         qa[i] = slot ^ ((r >> 1) & 7);                        // k-chunk this lane fetches for that row
         const int m = m0 + r;
         if (m < a.M) {
-            const int b = m / (a.Ho * a.Wo), rem = m - b * (a.Ho * a.Wo);
-            const int ho = rem / a.Wo, wo = rem - ho * a.Wo;
+            const int b = a.sh_hw < 0 ? m : (int)(__umulhi((unsigned)m, a.magic_hw) >> a.sh_hw);   // multiply-high division
+            const int rem = m - b * (a.Ho * a.Wo);
+            const int ho = a.sh_w < 0 ? rem : (int)(__umulhi((unsigned)rem, a.magic_w) >> a.sh_w);
+            const int wo = rem - ho * a.Wo;
             hi0[i] = ho * a.stride - a.pad;
             wi0[i] = wo * a.stride - a.pad;
             abase[i] = (long)b * a.H * a.W * a.in_cs;

@@ -11,6 +11,11 @@
 //   * v_mfma_f32_32x32x16_bf16: half the MFMA instructions for the same flops and the same LDS traffic;
 //     with the (row>>1)&7 XOR key the 32-row fragment reads are bank-conflict-free.
 #include "yolo_internal.h"
+#ifdef ADAYOLO_PLAIN_STORES   // A/B switch (measurement): keep the output lines in the XCD L2 instead of streaming them
+#define ADAYOLO_STORE(v, p) (*(p) = (v))
+#else
+#define ADAYOLO_STORE(v, p) __builtin_nontemporal_store((v), (p))
+#endif
 
 namespace adayolo {
 namespace dma2 {
@@ -93,12 +98,17 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void k_conv_igemm_dma32(const C
         unsigned mask = 0;
         long off = 0;
         if (m < a.M) {
-            const int b = m / (a.Ho * a.Wo), rem = m - b * (a.Ho * a.Wo);
-            const int ho = rem / a.Wo, wo = rem - ho * a.Wo;
+            // m -> (image, row, column) by multiply-high (ConvArgs::magic_*): two runtime divisions per row cost more
+            // than the whole k-loop of a 1x1 layer's tile otherwise
+            const int b = a.sh_hw < 0 ? m : (int)(__umulhi((unsigned)m, a.magic_hw) >> a.sh_hw);
+            const int rem = m - b * (a.Ho * a.Wo);
+            const int ho = a.sh_w < 0 ? rem : (int)(__umulhi((unsigned)rem, a.magic_w) >> a.sh_w);
+            const int wo = rem - ho * a.Wo;
             const int hi0 = ho * a.stride - a.pad, wi0 = wo * a.stride - a.pad;
+            unsigned vw = 0;                                   // tap validity is separable: rows x columns
+            for (int kw = 0; kw < a.ks; ++kw) vw |= (unsigned)(wi0 + kw >= 0 && wi0 + kw < a.W) << kw;
             for (int kh = 0; kh < a.ks; ++kh)
-                for (int kw = 0; kw < a.ks; ++kw)
-                    if (hi0 + kh >= 0 && hi0 + kh < a.H && wi0 + kw >= 0 && wi0 + kw < a.W) mask |= 1u << (kh * a.ks + kw);
+                if (hi0 + kh >= 0 && hi0 + kh < a.H) mask |= vw << (kh * a.ks);
             off = ((long)b * a.H * a.W + (long)hi0 * a.W + wi0) * a.in_cs + 8 * q;
         }
         amask[i] = mask;
@@ -261,7 +271,7 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void k_conv_igemm_dma32(const C
             }
         }
         if (ABL == 7 && v[0] != 0x12345678u) continue;        // ablation: everything but the global stores
-        __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(a.out + (long)m * a.out_cs + n));
+        ADAYOLO_STORE(v, reinterpret_cast<u32x4*>(a.out + (long)m * a.out_cs + n));
     }
 }
 

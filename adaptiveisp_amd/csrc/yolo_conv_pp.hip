@@ -22,6 +22,11 @@
 //
 // Restrictions (the launcher falls back otherwise): Cin % 64 == 0, Cout % 256 == 0.
 #include "yolo_internal.h"
+#ifdef ADAYOLO_PLAIN_STORES   // A/B switch (measurement): keep the output lines in the XCD L2 instead of streaming them
+#define ADAYOLO_STORE(v, p) (*(p) = (v))
+#else
+#define ADAYOLO_STORE(v, p) __builtin_nontemporal_store((v), (p))
+#endif
 
 namespace adayolo {
 namespace pp {
@@ -336,7 +341,7 @@ __global__ __launch_bounds__(512) void k_conv_pp(const ConvArgs a) {
                 }
             }
             if (ok && !(ABL == 3 && v[0] != 0x12345678u))
-                __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(a.out + (long)m * a.out_cs + n));
+                ADAYOLO_STORE(v, reinterpret_cast<u32x4*>(a.out + (long)m * a.out_cs + n));
         }
     }
     PP_STAMP(6);

@@ -51,6 +51,8 @@ def parse():
     ap.add_argument("--width", type=int, default=1280)
     ap.add_argument("--schedule", default="mixed", choices=sorted(SCHEDULES))
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
+    ap.add_argument("--no-pipeline", action="store_true", help="one stream: the detector of a batch starts only after "
+                    "its own ISP episode (no overlap of consecutive batches)")
     ap.add_argument("--retune", action="store_true", help="re-measure the per-layer conv variants instead of loading "
                     "adaptiveisp_amd/yolo/tuning/*.json")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -74,14 +76,52 @@ def build_workload(a, dev):
     s0 = torch.zeros(a.batch, cfg.num_state_dim, device=dev)
     sched = SCHEDULES[a.schedule]
 
-    def step():
+    def isp_chain():
         x, st = x0, s0
         with torch.no_grad():
             for k in sched:
                 (x, st, _, _), _, _ = agent((x, z, st), 1.0, selected_filter_id=k)
+        return x
+
+    def step():
+        x = isp_chain()
+        with torch.no_grad():
             return engine(x)
 
+    step.isp_chain = isp_chain
     return step, engine, agent, x0, sched
+
+
+def build_pipeline(step, engine, x0):
+    """Two-stage software pipeline over consecutive batches, captured as two hipGraphs (even / odd): one replay runs
+    the ISP episode of batch i+1 (latency-bound: pooling, policy heads, one filter kernel per RL step) on one stream
+    BESIDE the detector forward of batch i (MFMA-bound) on another. Every replay still does one whole ISP pass and
+    one whole detector pass; the hand-over tensor is double-buffered. Returns (prime, run): `prime()` fills the
+    pipeline (ISP of the first batch, untimed), `run()` advances it by one step."""
+    xbuf = [torch.empty_like(x0), torch.empty_like(x0)]
+    side = torch.cuda.Stream()
+    graphs = []
+    for p in range(2):
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            cur = torch.cuda.current_stream()
+            side.wait_stream(cur)
+            with torch.cuda.stream(side), torch.no_grad():
+                engine(xbuf[1 - p])                      # detector of the batch the previous replay retouched
+            xbuf[p].copy_(step.isp_chain())              # ISP episode of the next batch
+            cur.wait_stream(side)
+        graphs.append(g)
+    state = {"i": 0}
+
+    def prime():
+        xbuf[1].copy_(step.isp_chain())
+        state["i"] = 0
+
+    def run():
+        graphs[state["i"] & 1].replay()
+        state["i"] += 1
+
+    return prime, run
 
 
 def time_isp_kernels(x0, sched, iters=10):
@@ -231,7 +271,7 @@ def main():
         torch.cuda.synchronize()
 
     run = step
-    graphed = False
+    graphed = pipelined = False
     step()                                   # eager warm-up: lazy module init, MIOpen/rocBLAS plans
     torch.cuda.synchronize()
     if not a.no_graph:
@@ -245,6 +285,17 @@ def main():
             with torch.cuda.graph(graph):
                 step()
             run, graphed = graph.replay, True
+            if not a.no_pipeline:
+                try:
+                    prime, prun = build_pipeline(step, engine, x0)
+                    prime()
+                    prun(); prun()
+                    torch.cuda.synchronize()
+                    run, pipelined = prun, True
+                except Exception as e:
+                    print(f"[bench] two-stream pipeline unavailable ({type(e).__name__}: {e}); single-stream graph",
+                          file=sys.stderr)
+                    torch.cuda.synchronize()
         except Exception as e:          # stays on the HIP kernels either way; only the launch mechanism differs
             print(f"[bench] hipGraph capture unavailable ({type(e).__name__}: {e}); launching eagerly", file=sys.stderr)
             torch.cuda.synchronize()
@@ -271,7 +322,9 @@ def main():
                                f"{[NAMES[k] for k in sched]} (teacher-forced, policy/heads evaluated every step) + YOLOv3 "
                                f"forward @{a.width}x{engine.Hp} bf16 (random-init weights)",
                    "per_gpu_batch": a.batch, "global_batch": a.batch * world, "parallelism": f"replicas x{world}",
-                   "launch": "hipGraph replay" if graphed else "eager"},
+                   "launch": ("hipGraph replay, 2-stage pipeline: ISP episode of batch i+1 beside the detector of batch i "
+                              "(two streams; every step = one full ISP pass + one full detector pass)") if pipelined
+                   else ("hipGraph replay" if graphed else "eager")},
     }
     if rank == 0 and not a.no_detail:
         d = time_dominant_conv(engine, x0)
