@@ -100,10 +100,13 @@ def build_pipeline(step, engine, x0):
     pipeline (ISP of the first batch, untimed), `run()` advances it by one step."""
     xbuf = [torch.empty_like(x0), torch.empty_like(x0)]
     side = torch.cuda.Stream()
+    # both stages on ordinary-priority streams: a high-priority stream for the ISP chain was measured 26 % SLOWER
+    # (1039 vs 1407 images/s) — its NLM workgroups then pre-empt the detector's at every CU hand-over
+    hp = torch.cuda.Stream()
     graphs = []
     for p in range(2):
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
+        with torch.cuda.graph(g, stream=hp):
             cur = torch.cuda.current_stream()
             side.wait_stream(cur)
             with torch.cuda.stream(side), torch.no_grad():
