@@ -274,6 +274,7 @@ def main():
         torch.cuda.synchronize()
 
     run = step
+    single_run = None
     graphed = pipelined = False
     step()                                   # eager warm-up: lazy module init, MIOpen/rocBLAS plans
     torch.cuda.synchronize()
@@ -288,6 +289,7 @@ def main():
             with torch.cuda.graph(graph):
                 step()
             run, graphed = graph.replay, True
+            single_run = graph.replay
             if not a.no_pipeline:
                 try:
                     prime, prun = build_pipeline(step, engine, x0)
@@ -329,6 +331,18 @@ def main():
                               "(two streams; every step = one full ISP pass + one full detector pass)") if pipelined
                    else ("hipGraph replay" if graphed else "eager")},
     }
+    if rank == 0 and pipelined and single_run is not None and not a.no_detail:
+        # the same K steps without the cross-batch overlap (one stream: each detector pass waits for its own ISP episode)
+        for _ in range(a.warmup):
+            single_run()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(a.steps):
+            single_run()
+        torch.cuda.synchronize()
+        dt1 = time.perf_counter() - t1
+        line["single_stream"] = {"value": round(a.batch * a.steps / dt1, 2), "unit": "images/sec", "n_gpus": 1,
+                                 "ms_per_step": round(dt1 / a.steps * 1e3, 3)}
     if rank == 0 and not a.no_detail:
         d = time_dominant_conv(engine, x0)
         line["roofline"] = {"bound": "mfma", "kernel": CONV_KERNEL_NAMES.get(d["variant"], f"conv variant {d['variant']}"),
