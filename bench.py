@@ -148,6 +148,10 @@ def time_isp_kernels(x0, sched, iters=10):
         ms = e0.elapsed_time(e1) / n
         gbs = 24.0 * B * H * W / (ms * 1e-3) / 1e9
         res[NAMES[op]] = {"ms": round(ms, 4), "GBps": round(gbs, 1), "frac_hbm": round(gbs / HBM_PEAK_GBS, 3)}
+        if op == 4:        # NLM is bound by the fp32 VALU, not HBM: 4.6 kflop/px in the reference's arithmetic
+            tf = 4.6e3 * B * H * W / (ms * 1e-3) / 1e12
+            res[NAMES[op]].update({"bound": "fp32 valu", "ref_arith_TFLOPs": round(tf, 1), "peak_TFLOPs": 157.3,
+                                   "frac_valu": round(tf / 157.3, 3)})
     return res
 
 

@@ -237,3 +237,27 @@ def test_autograd_through_filter_modules(golden):
     with pytest.raises(NotImplementedError):
         x = img.clone().requires_grad_(True)
         F.ExposureFilter(cfg).forward(x, specified_parameter=torch.zeros(2, 1, device=dev()))[0].sum().backward()
+
+
+def test_fullsize_4k_properties(oracle_mod):
+    """BASELINE config 5 sizes (4 x 2160 x 3840, denoise + sharpen heavy): size-independent properties, plus an exact
+    oracle comparison on a crop that contains a tile corner of every kernel."""
+    from adaptiveisp_amd import _lib
+    torch.manual_seed(5)
+    B, H, W = 2, 2160, 3840                                   # two of the four images: 0.8 GB of fp32 per tensor pair
+    x = (torch.rand(B, 3, H, W, device=dev()) ** 2.2 * 0.5)
+    one = torch.ones(B, 1, device=dev())
+    # sharpen with factor 1 is the identity (adjust_sharpness: img*1 + blur*0), NLM of a constant image is that constant
+    torch.testing.assert_close(_lib.process(OPS["Shr"], x, one), x, rtol=0, atol=0)
+    c = torch.full((1, 3, H, W), 0.25, device=dev())
+    torch.testing.assert_close(_lib.process(OPS["NLM"], c, torch.full((1, 1), 0.4, device=dev())), c, rtol=1e-6, atol=1e-7)
+    # sharpen(f) on the whole frame vs the oracle on a crop whose stencil footprint lies inside the crop
+    f = torch.tensor([[2.5], [0.3]], device=dev())
+    y = _lib.process(OPS["Shr"], x, f)
+    y0, x0, ch, cw = 1000, 2000, 96, 160
+    crop = x[:, :, y0 - 1:y0 + ch + 1, x0 - 1:x0 + cw + 1].contiguous().cpu().numpy()
+    ref = oracle_mod.forward(crop, oracle_mod.OPS["SHARPEN"], f.cpu().numpy(), clip=True)[:, :, 1:-1, 1:-1]
+    np.testing.assert_allclose(y[:, :, y0:y0 + ch, x0:x0 + cw].cpu().numpy(), ref, rtol=1e-5, atol=2e-6)
+    assert float(y.min()) >= 0.0 and float(y.max()) <= 1.0
+    p = _lib.pool64(x)
+    torch.testing.assert_close(p, torch.nn.functional.adaptive_avg_pool2d(x, 64), rtol=1e-5, atol=1e-6)

@@ -118,3 +118,28 @@ def test_no_cpu_fallback():
     f = F.ExposureFilter(cfg)
     with pytest.raises(_lib.AdaispError):
         f.process(torch.rand(1, 3, 8, 8), torch.zeros(1, 1))
+
+
+def test_config1_plumbing_640_three_steps(oracle_mod):
+    """BASELINE config 1: a single 640x640 synthetic frame through three teacher-forced ISP steps on the CPU (the
+    oracle stands in for the kernels, `_engine.cpu_agent`): every step equals the oracle's filter applied with the
+    parameters the heads regressed, states advance, pixels stay in [0,1]."""
+    import numpy as np
+    import torch
+    from _engine import cpu_agent
+    from adaptiveisp_amd.config import cfg
+    agent = cpu_agent(cfg)
+    rng = np.random.default_rng(1234)
+    x = torch.from_numpy((rng.random((1, 3, 640, 640)) ** 2.2 * 0.5).astype(np.float32))
+    z = torch.from_numpy(rng.random((1, cfg.z_dim)).astype(np.float32))
+    st = torch.zeros(1, cfg.num_state_dim)
+    ops = {0: oracle_mod.OPS["EXPOSURE"], 9: oracle_mod.OPS["WB"], 5: oracle_mod.OPS["TONE"]}
+    with torch.no_grad():
+        for step, k in enumerate((0, 9, 5)):
+            (y, st2, _, pen), dbg, _ = agent((x, z, st), 1.0, selected_filter_id=k)
+            p = dbg["filter_debug_info"][k]["filter_parameters"].reshape(1, -1).numpy()
+            ref = oracle_mod.forward(x.numpy(), ops[k], p, clip=True)
+            np.testing.assert_array_equal(y.numpy(), ref)
+            assert float(st2[0, 2]) == step + 1 and float(st2[0, 3 + k]) == 1.0 and int(dbg["selected_filter"][0]) == k
+            assert float(y.min()) >= 0.0 and float(y.max()) <= 1.0 and torch.isfinite(pen).all()
+            x, st = y, st2
