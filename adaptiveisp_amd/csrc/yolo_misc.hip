@@ -13,7 +13,12 @@ __device__ __forceinline__ unsigned short f2bf(float f) {
     u += 0x7FFFu + ((u >> 16) & 1u);
     return (unsigned short)(u >> 16);
 }
-__device__ __forceinline__ unsigned pack2(float lo, float hi) { return (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16); }
+typedef __attribute__((ext_vector_type(2))) __bf16 hw_bf16x2;
+typedef __attribute__((ext_vector_type(2))) float hw_f32x2;
+// round-to-nearest-even pair conversion on the hardware unit (v_cvt_pk_bf16_f32) instead of ~8 integer VALU ops
+__device__ __forceinline__ unsigned pack2(float lo, float hi) {
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(hw_f32x2{lo, hi}, hw_bf16x2));
+}
 __device__ __forceinline__ float bf2f(unsigned short h) { return __uint_as_float(((unsigned)h) << 16); }
 __device__ __forceinline__ float silu(float x) {
     return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504088896341f * x));
