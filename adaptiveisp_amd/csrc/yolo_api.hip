@@ -56,7 +56,8 @@ int adayolo_conv_fwd_variant(const void* in, int in_cstride, const void* weight,
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (variant == 0) variant = ADAYOLO_DEFAULT_VARIANT;
     hipError_t e = hipErrorInvalidValue;
-    if (variant >= 50) e = launch_conv_pp(a, s, variant);                  // Cin % 64 == 0 and Cout % 256 == 0 only; falls through otherwise
+    if (variant >= 60) e = launch_conv_pp128(a, s, variant);               // Cin % 64 == 0 and Cout % 128 == 0 only
+    else if (variant >= 50) e = launch_conv_pp(a, s, variant);                  // Cin % 64 == 0 and Cout % 256 == 0 only; falls through otherwise
     else if (variant >= 35 && variant <= 39) e = launch_conv_dma2(a, s, variant);   // ablation builds
     else if (variant >= 40) e = launch_conv_small(a, s, variant);            // 3x3, Cin 32/64 only; falls through otherwise
     else if (variant >= 30) e = launch_conv_patch(a, s, variant);       // 3x3 stride-1 only; falls through otherwise

@@ -1,0 +1,331 @@
+// Conv + bias + SiLU (+ residual) — implicit GEMM, 256 px x 128 ch tile, two wave groups in ping-pong, 3-deep ring.
+//
+// Sibling of yolo_conv_pp.hip for the layers it cannot serve well: Cout = 128 (its tile is 256 channels wide) and
+// small pixel counts where 256x256 tiles leave half the CUs idle (8x23x40 px: 116 tiles; here 232). Same ideas —
+// waves 0-3 / 4-7 staggered by one barrier so that one wave of each SIMD issues MFMAs while the other reads
+// fragments, LDS-DMA issued in the MFMA sections behind counted waits — with a different decomposition:
+//
+//   * wave grid 4 (px) x 2 (ch): wave tile 64 px x 64 ch (four 32x32 accumulators), the channel half is the
+//     ping-pong group. Per k-tile (BK = 64) a wave reads 8 activation + 8 weight fragments for 16 MFMAs (a
+//     2 x 4 grid with 128 x 32 wave tiles would need 20): LDS read + DMA write time stays below the MFMA time;
+//   * a k-tile is TWO phases of 8 MFMAs (channel fragment 0, then 1). The activation fragments are read in P1's load
+//     section, both weight fragments of the phase pair — W1 of this k-tile and W0 of the NEXT — in P2's: 8 reads per
+//     load section; three weight register sets rotate;
+//   * with two phases per k-tile a 2-buffer ring leaves one phase of DMA latency, so the ring is 3 k-tiles deep
+//     (3 x 48 KB). Slots are units of what one load section reads: A (4 DMA instructions per wave), W0, W1 (1 each):
+//         MFMA section of P1(t): issues W1(t+2), W0(t+3)  then s_waitcnt vmcnt(8)
+//         MFMA section of P2(t): issues A(t+3)            then s_waitcnt vmcnt(10)
+//     i.e. everything issued three phases ago is retired, and is first read two phases later (the distance the
+//     stagger needs): issue -> read = 5 phases. A slot is re-staged at least one phase after its last read.
+//
+// Restrictions (the launcher falls back otherwise): Cin % 64 == 0, Cout % 128 == 0.
+#include "yolo_internal.h"
+
+namespace adayolo {
+namespace pp128 {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+
+__device__ __attribute__((aligned(16))) unsigned int g_zero16[4] = {0u, 0u, 0u, 0u};
+
+__device__ __forceinline__ float bf16_to_f32(unsigned short h) { return __uint_as_float(((unsigned)h) << 16); }
+__device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {      // round-to-nearest-even: v_cvt_pk_bf16_f32
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{lo, hi}, bf16x2));
+}
+__device__ __forceinline__ float silu(float x) {
+    return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504088896341f * x));
+}
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
+__device__ __forceinline__ void dma16(unsigned long long gaddr, void* l) {
+    __builtin_amdgcn_global_load_lds((gbl_ptr_t)gaddr, (lds_ptr_t)l, 16, 0, 0);
+}
+__device__ __forceinline__ unsigned long long sel(bool ok, unsigned long long p, unsigned long long z) {
+    const unsigned long long m = ok ? ~0ull : 0ull;
+    return (p & m) | (z & ~m);
+}
+__device__ __forceinline__ void barrier() {
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_barrier" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+}
+template <int N>
+__device__ __forceinline__ void wait_vm() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+constexpr int BM = 256, BN = 128, BK = 64;
+constexpr int kRow = BK * 2;                  // bytes per tile row
+constexpr int kATile = BM * kRow;             // 32 KB
+constexpr int kBuf = (BM + BN) * kRow;        // one k-tile: 48 KB
+constexpr int kRing = 3 * kBuf;               // 144 KB
+constexpr int kEpiPitch = 144;                // bytes per pixel row of a wave's private epilogue region (64 ch + pad)
+constexpr int kSmem = kRing + BN * 4;         // + bias; the epilogue (8 x 64 x 144 B = 72 KB) overlays the finished ring
+
+struct KPos {                                 // wave-uniform position of a k-tile
+    int c0, kh, kw, tap;
+    long aoff, woff;
+};
+
+// ABL: 0 real kernel, 5 no DMA instructions in the k-loop, 6 no epilogue (measurement builds)
+template <int ABL>
+__global__ __launch_bounds__(512) void k_conv_pp128(const ConvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float* bias_s = reinterpret_cast<float*>(smem + kRing);
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave & 3, wn = wave >> 2;             // wn is also the ping-pong group
+    const int lid = xcd_remap(blockIdx.x, a.mtiles * a.ntiles);
+    const int m0 = (lid / a.ntiles) * BM, n0 = (lid % a.ntiles) * BN;
+    const unsigned long long zaddr = (unsigned long long)(const void*)g_zero16;
+
+    // ---- per-row DMA state: one DMA instruction moves 8 tile rows. Activations: 32 instructions per k-tile, this
+    //      wave issues the four of rows [32*wave, 32*wave + 32). Weights: unit W0 = rows [0,32) + [64,96) (channel
+    //      fragment 0 of both groups), W1 = the other 64 rows; one instruction per wave and unit.
+    const int slot = lane & 7, rsub = lane >> 3;
+    unsigned long long arow[4], wrow[2];
+    unsigned amask[4];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int r = (wave >> 2) * 64 + u * 32 + (wave & 3) * 8 + rsub;
+        const int q = slot ^ ((r >> 1) & 7);
+        wrow[u] = (unsigned long long)(a.w + (long)(n0 + r) * (a.ks * a.ks * a.Cin) + 8 * q);
+    }
+    const int wlds0 = kATile + ((wave >> 2) * 64 + (wave & 3) * 8) * kRow;       // unit W0; W1 = + 32 rows
+    const int alds0 = wave * 32 * kRow;                                          // + 8 rows per instruction
+    auto decode_rows = [&]() {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = wave * 32 + i * 8 + rsub;
+            const int q = slot ^ ((r >> 1) & 7);
+            const int m = m0 + r;
+            unsigned mask = 0;
+            long off = 0;
+            if (m < a.M) {
+                const int b = a.sh_hw < 0 ? m : (int)(__umulhi((unsigned)m, a.magic_hw) >> a.sh_hw);
+                const int rem = m - b * (a.Ho * a.Wo);
+                const int ho = a.sh_w < 0 ? rem : (int)(__umulhi((unsigned)rem, a.magic_w) >> a.sh_w);
+                const int wo = rem - ho * a.Wo;
+                const int hi0 = ho * a.stride - a.pad, wi0 = wo * a.stride - a.pad;
+                unsigned vw = 0;                               // tap validity is separable: rows x columns
+                for (int kw = 0; kw < a.ks; ++kw) vw |= (unsigned)(wi0 + kw >= 0 && wi0 + kw < a.W) << kw;
+                for (int kh = 0; kh < a.ks; ++kh)
+                    if (hi0 + kh >= 0 && hi0 + kh < a.H) mask |= vw << (kh * a.ks);
+                off = ((long)b * a.H * a.W + (long)hi0 * a.W + wi0) * a.in_cs + 8 * q;
+            }
+            amask[i] = mask;
+            arow[i] = (unsigned long long)(a.in + off);
+        }
+    };
+    const int cpt = a.Cin / BK;
+    const int nK = a.ks * a.ks * cpt;
+
+    auto advance = [&](KPos& p) {
+        p.c0 += BK;
+        if (p.c0 >= a.Cin) {
+            p.c0 = 0; ++p.tap; ++p.kw;
+            if (p.kw == a.ks) { p.kw = 0; ++p.kh; }
+        }
+        p.aoff = 2 * (((long)p.kh * a.W + p.kw) * a.in_cs + p.c0);
+        p.woff = 2 * ((long)p.tap * a.Cin + p.c0);
+    };
+    auto stage_a1 = [&](int i, unsigned char* buf, const KPos& p, bool live) {
+        if (ABL == 5 && !live) return;
+        const bool ok = live && ((amask[i] >> p.tap) & 1u);
+        dma16(sel(ok, arow[i] + p.aoff, zaddr), buf + alds0 + i * 8 * kRow);
+    };
+    auto stage_w1 = [&](int u, unsigned char* buf, const KPos& p, bool live) {
+        if (ABL == 5 && !live) return;
+        dma16(sel(live, wrow[u] + p.woff, zaddr), buf + wlds0 + u * 32 * kRow);
+    };
+    auto stage_a = [&](unsigned char* buf, const KPos& p, bool live) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) stage_a1(i, buf, p, live);
+    };
+
+    // ---- prologue, in the steady-state issue order: W0(0); A(0); W1(0), W0(1); A(1); W1(1), W0(2); A(2)
+    KPos q0{0, 0, 0, 0, 0, 0};
+    KPos q1 = q0; advance(q1);
+    KPos q2 = q1; advance(q2);
+    if (wave == 0 && lane < 32) dma16((unsigned long long)(a.bias + n0) + 16 * lane, bias_s);   // 512 B: half a wave
+    stage_w1(0, smem, q0, true);
+    decode_rows();
+    stage_a(smem, q0, true);
+    stage_w1(1, smem, q0, true);
+    stage_w1(0, smem + kBuf, q1, 1 < nK);
+    stage_a(smem + kBuf, q1, 1 < nK);
+    stage_w1(1, smem + kBuf, q1, 1 < nK);
+    stage_w1(0, smem + 2 * kBuf, q2, 2 < nK);
+    stage_a(smem + 2 * kBuf, q2, 2 < nK);
+    wait_vm<10>();                                       // W0(0), A(0), W1(0), W0(1) landed (this wave's share)
+    barrier();
+
+    f32x16 acc[2][2];                                    // [channel frag][pixel frag]
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[ni][mi][e] = 0.0f;
+
+    // fragment addressing (32x32x16): lane -> tile row (lane & 31), 16-byte k-chunk 2*kk + (lane >> 5), XOR key
+    const int frow = lane & 31, fq = lane >> 5, key = (frow >> 1) & 7;
+    const int abase = (wm * 64 + frow) * kRow, wbase = kATile + (wn * 64 + frow) * kRow;
+    int koff[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) koff[kk] = ((2 * kk + fq) ^ key) << 4;
+
+    bf16x8 af[2][4], wx[4], wy[4], wz[4];
+    auto read_a = [&](const unsigned char* buf) {
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+                af[mi][kk] = *reinterpret_cast<const bf16x8*>(buf + abase + mi * 32 * kRow + koff[kk]);
+    };
+    auto read_w = [&](const unsigned char* buf, int ni, bf16x8 (&w)[4]) {
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+            w[kk] = *reinterpret_cast<const bf16x8*>(buf + wbase + ni * 32 * kRow + koff[kk]);
+    };
+    // MFMA section: 8 MFMAs, the phase's DMA instructions issued behind the 1st, 3rd, 5th and 7th, then the counted wait
+    auto mma = [&](int ni, const bf16x8 (&w)[4], auto&& stage, int npieces) {
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) {
+                acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[kk], af[mi][kk], acc[ni][mi], 0, 0, 0);
+                const int n = 2 * kk + mi;
+                if ((n & 1) == 0 && (n >> 1) < npieces) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    stage(n >> 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        __builtin_amdgcn_s_setprio(0);
+    };
+
+    read_w(smem, 0, wx);                                 // W0 of k-tile 0
+    if (wn == 1) barrier();                              // stagger group 1 by one barrier
+
+    KPos p2 = q2, p3 = q2;                               // p2: k-tile t+2, p3: k-tile t+3 (advanced inside the loop)
+    // one k-tile: `b0` its buffer, `b1` / `b2` the buffers of k-tiles t+1 / t+2 (t+3 lands in b0 again)
+    auto ktile = [&](unsigned char* b0, unsigned char* b1, unsigned char* b2, int t, bf16x8 (&w0)[4], bf16x8 (&w1)[4],
+                     bf16x8 (&wnx)[4]) {
+        const bool live2 = ABL != 5 && t + 2 < nK, live3 = ABL != 5 && t + 3 < nK;
+        advance(p3);                                      // -> k-tile t+3
+        // P1: channel fragment 0
+        read_a(b0);
+        barrier();
+        mma(0, w0, [&](int j) { if (j == 0) stage_w1(1, b2, p2, live2); else stage_w1(0, b0, p3, live3); }, 2);
+        wait_vm<8>();
+        barrier();
+        // P2: channel fragment 1; the load section also fetches W0 of the NEXT k-tile
+        read_w(b0, 1, w1);
+        read_w(b1, 0, wnx);
+        barrier();
+        mma(1, w1, [&](int j) { stage_a1(j, b0, p3, live3); }, 4);
+        wait_vm<10>();
+        barrier();
+        p2 = p3;
+    };
+    unsigned char* B0 = smem;
+    unsigned char* B1 = smem + kBuf;
+    unsigned char* B2 = smem + 2 * kBuf;
+    for (int t = 0; t < nK; t += 3) {
+        ktile(B0, B1, B2, t, wx, wy, wz);
+        if (t + 1 < nK) ktile(B1, B2, B0, t + 1, wz, wx, wy);
+        if (t + 2 < nK) ktile(B2, B0, B1, t + 2, wy, wz, wx);
+    }
+    asm volatile("" ::"v"(wx[0]), "v"(wy[0]), "v"(wz[0]));
+    if (wn == 0) barrier();                              // pairs with group 1's last barrier
+    wait_vm<0>();                                        // the tail's zero-fill DMAs target the ring the epilogue overlays
+    barrier();
+    if (ABL == 6) {
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) asm volatile("" ::"v"(acc[ni][mi]));
+        return;
+    }
+
+    // ---- epilogue: wave-private LDS transpose (see yolo_conv_pp.hip), 32 px x 64 ch at a time, 128-byte row segments
+    unsigned char* my = smem + wave * (64 * kEpiPitch);
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int qd = 0; qd < 4; ++qd) {
+                const int nl = wn * 64 + ni * 32 + 8 * qd + 4 * (lane >> 5);
+                const float4 b4 = *reinterpret_cast<const float4*>(bias_s + nl);
+                const float bv[4] = {b4.x, b4.y, b4.z, b4.w};
+                float v[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    v[i] = acc[ni][mi][4 * qd + i] + bv[i];
+                    if (a.act == ADAYOLO_ACT_SILU) v[i] = silu(v[i]);
+                }
+                *reinterpret_cast<u32x2*>(my + (mi * 32 + (lane & 31)) * kEpiPitch + (ni * 32 + 8 * qd + 4 * (lane >> 5)) * 2) =
+                    u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+            }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // same wave wrote and reads: in-order LDS, no barrier
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int row = mi * 32 + it * 8 + (lane >> 3), chunk = lane & 7;
+            const int m = m0 + wm * 64 + row, n = n0 + wn * 64 + chunk * 8;
+            const bool ok = m < a.M;
+            u32x4 v = *reinterpret_cast<const u32x4*>(my + row * kEpiPitch + chunk * 16);
+            if (a.res && ok) {
+                const u32x4 r = *reinterpret_cast<const u32x4*>(a.res + (long)m * a.res_cs + n);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float lo = bf16_to_f32((unsigned short)(v[j] & 0xFFFFu)) + bf16_to_f32((unsigned short)(r[j] & 0xFFFFu));
+                    const float hh = bf16_to_f32((unsigned short)(v[j] >> 16)) + bf16_to_f32((unsigned short)(r[j] >> 16));
+                    v[j] = pack_bf16x2(lo, hh);
+                }
+            }
+            if (ok) __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(a.out + (long)m * a.out_cs + n));
+        }
+    }
+}
+
+template <int ABL>
+static hipError_t launch(ConvArgs a, hipStream_t s) {
+    static_assert(kSmem <= 160 * 1024, "LDS budget");
+    auto kern = k_conv_pp128<ABL>;
+    static bool configured = false;
+    if (!configured) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, kSmem);
+        if (e != hipSuccess) return e;
+        configured = true;
+    }
+    a.mtiles = (a.M + BM - 1) / BM;
+    a.ntiles = a.Cout / BN;
+    hipLaunchKernelGGL(kern, dim3(a.mtiles * a.ntiles), dim3(512), kSmem, s, a);
+    return hipGetLastError();
+}
+
+}  // namespace pp128
+
+// variant 60 = the kernel, 65 / 66 = measurement builds. hipErrorInvalidValue -> caller falls back.
+hipError_t launch_conv_pp128(ConvArgs a, hipStream_t s, int variant) {
+    if (a.Cin % 64 || a.Cout % 128) return hipErrorInvalidValue;
+    if (variant == 65) return pp128::launch<5>(a, s);
+    if (variant == 66) return pp128::launch<6>(a, s);
+    return pp128::launch<0>(a, s);
+}
+
+}  // namespace adayolo

@@ -24,7 +24,8 @@ hipError_t launch_conv_dma(ConvArgs a, hipStream_t s, int variant);   // LDS-DMA
 hipError_t launch_conv_dma2(ConvArgs a, hipStream_t s, int variant);  // lean-address 32x32 MFMA ring (yolo_conv_dma2.hip)
 hipError_t launch_conv_patch(ConvArgs a, hipStream_t s, int variant); // 3x3 s1, input patch resident in LDS (yolo_conv_patch.hip)
 hipError_t launch_conv_small(ConvArgs a, hipStream_t s, int variant);
-hipError_t launch_conv_pp(ConvArgs a, hipStream_t s, int variant);    // 256x256 ping-pong wave groups (yolo_conv_pp.hip) // 3x3, Cin 32/64, whole K resident (yolo_conv_small.hip)
+hipError_t launch_conv_pp(ConvArgs a, hipStream_t s, int variant);
+hipError_t launch_conv_pp128(ConvArgs a, hipStream_t s, int variant); // 256x128 ping-pong, 3-deep ring (yolo_conv_pp128.hip)    // 256x256 ping-pong wave groups (yolo_conv_pp.hip) // 3x3, Cin 32/64, whole K resident (yolo_conv_small.hip)
 hipError_t launch_stem(const float* img, const float* w, const float* bias, void* out, int out_cs, int B, int H,
                        int W, int Hp, int pad_top, float pad_value, int act, hipStream_t s);
 hipError_t launch_upsample2x(const void* in, int in_cs, void* out, int out_cs, int B, int H, int W, int C,

@@ -175,7 +175,7 @@ class YoloEngine:
         self.views = view
 
     # ------------------------------------------------------------------------------------------
-    TUNE_CANDIDATES = (2, 5, 12, 13, 18, 19, 22, 24, 26, 27, 30, 31, 32, 33, 40, 41, 50)
+    TUNE_CANDIDATES = (2, 5, 12, 13, 18, 19, 22, 24, 26, 27, 30, 31, 32, 33, 40, 41, 50, 60)
 
     def _plans(self):
         return [self.plan]
@@ -213,8 +213,10 @@ class YoloEngine:
                             continue                             # patch-resident kernels serve 3x3 stride-1 only
                         if 40 <= v < 50 and not (args[13] == 3 and args[11] in (32, 64)):
                             continue                             # whole-K-resident kernels: 3x3 with Cin 32 / 64
-                        if v >= 50 and (args[11] % 64 or args[12] % 256):
+                        if 50 <= v < 60 and (args[11] % 64 or args[12] % 256):
                             continue                             # ping-pong kernel: Cin % 64 == 0, Cout % 256 == 0
+                        if v >= 60 and (args[11] % 64 or args[12] % 128):
+                            continue                             # 256x128 ping-pong kernel: Cin % 64 == 0, Cout % 128 == 0
                         args[16] = v
                         fn(*args, st)
                         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -36,7 +36,7 @@ CONV_KERNEL_NAMES = {1: "k_conv_igemm<128,128,2,2>", 2: "dma::k_conv_igemm_dma<1
                      19: "dma2::k_conv_igemm_dma32<128,256,2,4,3,0,32,1>", 22: "dma2::k_conv_igemm_dma32<128,64,4,1,4,0,32,1>",
                      24: "dma2::k_conv_igemm_dma32<256,128,4,2,4,0,32,1>",
                      26: "dma2::k_conv_igemm_dma32<128,256,2,4,3,0,32,4>", 27: "dma2::k_conv_igemm_dma32<256,128,4,2,3,0,32,4>",
-                     50: "pp::k_conv_pp<0>",
+                     50: "pp::k_conv_pp<0>", 60: "pp128::k_conv_pp128<0>",
                      40: "smallk::k_conv3x3_small<..., 256|128 px>", 41: "smallk::k_conv3x3_small<..., 128|64 px>", 30: "patch::k_conv3x3_patch<128,256,2>", 31: "patch::k_conv3x3_patch<64,256,2>",
                      32: "patch::k_conv3x3_patch<128,128,3>", 33: "patch::k_conv3x3_patch<64,128,3>"}
 
