@@ -21,10 +21,15 @@ from .yolo.checkpoint import save_isp_checkpoint
 
 class Trainer:
     def __init__(self, cfg, agent, value, detector, loss_fn, replay, batch_size, lr=3e-5, epochs=800, save_dir=None,
-                 use_truncated=True, max_bri=0.9, rank=0, world=1):
+                 use_truncated=True, max_bri=0.9, rank=0, world=1, sync_bn=False):
         """`detector(x)` returns the three raw head maps with autograd to x (frozen reward model in train mode with
         BN in eval, train.py:236-243). `epochs` -> max_iter_step = epochs*1000//batch_size as train.py:156 (the global
-        batch: per-rank batch x world)."""
+        batch: per-rank batch x world). `sync_bn`: under data parallelism, compute the BatchNorm statistics of the
+        agent / value CNNs (agent.py:40,51; value.py:22,34 run in train mode) over the GLOBAL batch with
+        torch.nn.SyncBatchNorm — the single-GPU batch-64 semantics of the reference — instead of per rank."""
+        if sync_bn and world > 1:
+            agent = torch.nn.SyncBatchNorm.convert_sync_batchnorm(agent)
+            value = torch.nn.SyncBatchNorm.convert_sync_batchnorm(value)
         self.cfg, self.agent, self.value, self.detector, self.loss_fn = cfg, agent, value, detector, loss_fn
         self.replay, self.batch_size, self.save_dir = replay, int(batch_size), save_dir
         self.use_truncated, self.max_bri, self.rank, self.world = use_truncated, max_bri, rank, world
