@@ -15,10 +15,13 @@ from .nms import non_max_suppression
 
 
 def run_eval(agent, detector, batches, cfg, steps=5, conf_thres=0.001, iou_thres=0.6, max_det=300, single_cls=False,
-             pipeline=None, records_path=None, nc=80, nms_fn=None):
+             pipeline=None, records_path=None, nc=80, nms_fn=None, param_dir=None):
     """Returns dict(mp, mr, map50, map75, map, seen, nt, ap_class, ap, records). `detector(x)` -> [B, N, 5+nc]
     decoded predictions (YoloEngine or the module tree in eval mode). `pipeline`: optional list of forced filter ids
-    per step (val_adaptiveisp.py:292, --pipeline)."""
+    per step (val_adaptiveisp.py:292, --pipeline). `param_dir`: write one JSON per batch (named after its first image) with
+    the chosen filter ids and image 0's regressed parameters per step, as `--save_param` does (:296-301,324-327)."""
+    import collections
+    import json
     from ..util import get_initial_states, get_noise
     dev = next(agent.parameters()).device
     iouv = torch.linspace(0.5, 0.95, 10, device=dev)
@@ -32,14 +35,24 @@ def run_eval(agent, detector, batches, cfg, steps=5, conf_thres=0.001, iou_thres
         noises = torch.from_numpy(np.array([get_noise(nb, cfg.z_type, cfg.z_dim) for _ in range(steps)])).to(dev)
         states = torch.from_numpy(get_initial_states(nb, cfg.num_state_dim, len(agent.filters))).to(dev)
         retouch, ids = im, []
+        params = collections.OrderedDict(pipeline=[])
         with torch.no_grad():
             for i in range(steps):
                 pipe = None if pipeline is None else pipeline[i]
                 (retouch, states, _, _), dbg, _ = agent((retouch, noises[i], states), 1.0, None, pipe)
                 ids.append([int(v) for v in dbg["selected_filter"].detach().cpu().tolist()])
+                if param_dir:
+                    k = ids[-1][0]
+                    params[filter_names[k]] = dbg["filter_debug_info"][k]["filter_parameters"].detach().cpu().numpy().tolist()
+                    params["pipeline"].append(k)
                 if states[0][STATE_STOPPED_DIM] > 0:
                     break
             preds = detector(retouch)
+        if param_dir:
+            os.makedirs(param_dir, exist_ok=True)
+            stem = os.path.splitext(os.path.split(str(paths[0]))[1])[0]
+            with open(os.path.join(param_dir, stem + ".json"), "w") as f:
+                json.dump(params, f, sort_keys=False, indent=4)
         for b in range(nb):
             row = ["-1"] * steps
             for i, step_ids in enumerate(ids):

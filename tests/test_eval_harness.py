@@ -116,7 +116,10 @@ def test_run_eval_on_cpu_with_oracle(oracle_mod, tmp_path):
     rec = tmp_path / "records.txt"
     res = run_eval(agent, detector, [(imgs, targets, ["a.png", "b.png"], [((64, 96), ((1.0, 1.0), (0.0, 0.0)))] * 2)],
                    cfg, steps=3, conf_thres=0.001, iou_thres=0.6, nc=3, records_path=str(rec),
-                   nms_fn=_oracle_nms_fn(oracle_mod, 300))
+                   nms_fn=_oracle_nms_fn(oracle_mod, 300), param_dir=str(tmp_path / "param_results"))
+    import json
+    pj = json.loads((tmp_path / "param_results" / "a.json").read_text())
+    assert len(pj["pipeline"]) == 3 and all(res["filter_names"][k] in pj for k in pj["pipeline"])
     assert res["seen"] == 2 and res["nt"].tolist() == [1, 1, 1]
     assert res["map50"] > 0.99 and 0.0 < res["mp"] <= 1.0
     lines = rec.read_text().strip().split("\n")
