@@ -122,62 +122,45 @@ __global__ __launch_bounds__(1024) void k_trunk_conv(const float* __restrict__ i
 }
 
 // ---- fc1 of every head: hidden[b][h][j] = lrelu(b1[h][j] + feats[src(h)][b][:] . w1[h][j][:]) ------------
-// Workgroup = 4 neurons of one head x the whole batch. The four waves split the 4096-long reduction, so every
-// feature vector is fetched once per 4 neurons (not once per neuron) and each lane has only D/4/64/4 = 4 trips,
-// two of them in flight; partial sums meet in LDS.
+// Workgroup = 4 neurons of one head x the whole batch, ONE WAVE PER NEURON: a lane strides the 4096-long dot product
+// (16 float4 of the weight row, re-used for every image of the batch), the wave reduces with shuffles and lane 0
+// writes the result. No LDS and no workgroup barrier: an earlier form that split one dot product over the four
+// waves and met in LDS gave run-to-run different sums when its workgroups started beside large-LDS workgroups of
+// another stream (tools/chain_stress5.py); this form keeps every sum inside one wave. The four waves of a block read
+// the same feature rows (L1 hits).
 constexpr int FC_MAXB = 8;
 constexpr int FC_NPB = 4;
 
 __global__ __launch_bounds__(256) void k_fc1(const float* __restrict__ feats, const int32_t* __restrict__ head_src,
                                              const float* __restrict__ w1, const float* __restrict__ b1,
                                              float* __restrict__ hidden, int B, int D, int NH, int HID) {
-    __shared__ float part[4][FC_NPB * FC_MAXB];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int n0 = blockIdx.x * FC_NPB;                        // first neuron (over NH*HID); HID % FC_NPB == 0
-    const int h = n0 / HID;
-    const float* fb = feats + (long)head_src[h] * B * D;
-    const int q4 = D / 16;                                     // float4 per wave-quarter of the reduction
+    const int neuron = blockIdx.x * FC_NPB + wave;             // over NH*HID; HID % FC_NPB == 0
+    const int h = neuron / HID;
+    const float4* fb = reinterpret_cast<const float4*>(feats + (long)head_src[h] * B * D);
+    const float4* wr = reinterpret_cast<const float4*>(w1 + (long)neuron * D);
+    const int nq = D / 4;                                      // float4 per row
     for (int b0 = 0; b0 < B; b0 += FC_MAXB) {
         const int nb = min(FC_MAXB, B - b0);
-        float acc[FC_NPB][FC_MAXB];
+        float acc[FC_MAXB];
 #pragma unroll
-        for (int n = 0; n < FC_NPB; ++n)
-#pragma unroll
-            for (int i = 0; i < FC_MAXB; ++i) acc[n][i] = 0.0f;
-#pragma unroll 2
-        for (int k = wave * q4 + lane; k < (wave + 1) * q4; k += 64) {
-            float4 wv[FC_NPB];
-#pragma unroll
-            for (int n = 0; n < FC_NPB; ++n) wv[n] = reinterpret_cast<const float4*>(w1 + (long)(n0 + n) * D)[k];
+        for (int i = 0; i < FC_MAXB; ++i) acc[i] = 0.0f;
+        for (int k = lane; k < nq; k += 64) {
+            const float4 wv = wr[k];
 #pragma unroll
             for (int i = 0; i < FC_MAXB; ++i) {
-                if (i < nb) {
-                    const float4 f = reinterpret_cast<const float4*>(fb + (long)(b0 + i) * D)[k];
-#pragma unroll
-                    for (int n = 0; n < FC_NPB; ++n)
-                        acc[n][i] = fmaf(wv[n].x, f.x, fmaf(wv[n].y, f.y, fmaf(wv[n].z, f.z, fmaf(wv[n].w, f.w, acc[n][i]))));
-                }
+                const int row = b0 + (i < nb ? i : nb - 1);       // always a valid row: no divergent loads; extra sums unused
+                const float4 f = fb[(long)row * nq + k];
+                acc[i] = fmaf(wv.x, f.x, fmaf(wv.y, f.y, fmaf(wv.z, f.z, fmaf(wv.w, f.w, acc[i]))));
             }
         }
 #pragma unroll
-        for (int n = 0; n < FC_NPB; ++n)
+        for (int i = 0; i < FC_MAXB; ++i) {
+            float v = acc[i];
 #pragma unroll
-            for (int i = 0; i < FC_MAXB; ++i) {
-                float v = acc[n][i];
-#pragma unroll
-                for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-                if (lane == 0) part[wave][n * FC_MAXB + i] = v;
-            }
-        __syncthreads();
-        if (threadIdx.x < FC_NPB * FC_MAXB) {
-            const int n = threadIdx.x / FC_MAXB, i = threadIdx.x - n * FC_MAXB;
-            if (i < nb) {
-                const float v = (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
-                const int neuron = n0 + n;
-                hidden[((long)(b0 + i) * NH + h) * HID + neuron - h * HID] = lrelu02(v + b1[neuron]);
-            }
+            for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+            if (lane == 0 && i < nb) hidden[((long)(b0 + i) * NH + h) * HID + neuron - h * HID] = lrelu02(v + b1[neuron]);
         }
-        __syncthreads();
     }
 }
 

@@ -26,3 +26,25 @@ def test_pipelined_replay_equals_sequential_step():
         torch.cuda.synchronize()
         assert torch.equal(engine.pred, ref)
     assert torch.isfinite(ref).all() and ref.shape[0] == 2
+
+
+def test_full_size_chain_is_bit_reproducible_beside_the_detector():
+    """Regression: with the detector's big-LDS workgroups running on a second stream, an earlier LDS + barrier form of
+    the policy's fc1 kernel produced run-to-run different sums (tools/chain_stress5.py). The ISP episode must come out
+    bit-identical every time, alone or beside the detector, and so must the detector."""
+    sys.path.insert(0, ROOT)
+    import bench
+    bench.TUNE_CACHE = os.path.join(ROOT, "adaptiveisp_amd", "yolo", "tuning", "mi355x.json")
+    a = argparse.Namespace(batch=8, height=720, width=1280, schedule="mixed", retune=False)
+    step, engine, agent, x0, sched = bench.build_workload(a, torch.device("cuda:0"))
+    xref = step.isp_chain().clone()
+    pref = step().clone()
+    side = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    for i in range(25):
+        with torch.cuda.stream(side), torch.no_grad():
+            pred = engine(xref)
+        x = step.isp_chain()
+        torch.cuda.synchronize()
+        assert torch.equal(x, xref), f"ISP episode differs in run {i}"
+        assert torch.equal(pred, pref), f"detector output differs in run {i}"
