@@ -15,6 +15,7 @@ bias + SiLU + residual epilogue:
 There is no eager fallback: without libadayolo.so / a HIP device this raises.
 """
 import ctypes
+import os
 
 import torch
 
@@ -51,7 +52,11 @@ def _pack_conv(w, b, pad_cout_to=None):
 
 
 class YoloEngine:
-    def __init__(self, model: DetectionModel, batch, height, width, device="cuda:0"):
+    def __init__(self, model: DetectionModel, batch, height, width, device="cuda:0", head_chunks=None):
+        """`head_chunks`: run the stem and the first down-sampling conv depth-first over this many batch chunks, so the
+        stem's output (the largest tensor of the network: 482 MB for 8 x 736 x 1280 x 32 bf16) is consumed while it is
+        still in the 256 MB Infinity Cache. Measured: -0.1 ms per forward with 2 chunks when launched eagerly, no gain
+        under hipGraph replay (4.09 vs 4.12 ms) — default 1 (off); ADAYOLO_HEAD_CHUNKS overrides."""
         if width % 32:
             raise ValueError(f"image width {width} must be a multiple of 32 (reference: check_img_size)")
         self.L = _lib.load()
@@ -66,6 +71,13 @@ class YoloEngine:
         self._keep = []          # tensors referenced by raw pointers in the plan
         self.plan = []
         self._build(model)
+        if head_chunks is None and os.environ.get("ADAYOLO_HEAD_CHUNKS"):
+            head_chunks = int(os.environ["ADAYOLO_HEAD_CHUNKS"])
+        if head_chunks is None:
+            head_chunks = 1
+        if self.B % head_chunks:
+            raise ValueError(f"head_chunks={head_chunks} does not divide the batch {self.B}")
+        self.head_chunks = int(head_chunks)
 
     # ------------------------------------------------------------------------------------------
     def _new(self, H, W, C):
@@ -251,14 +263,29 @@ class YoloEngine:
         img = img.contiguous()
         with torch.cuda.device(self.dev):
             st = _lib.stream_ptr()
-            for kind, fn, args in self.plan:
-                if kind == "stem":
-                    w, b, out = self._stem
-                    rc = self.L.adayolo_stem_fwd(ctypes.c_void_p(img.data_ptr()), ctypes.c_void_p(w.data_ptr()),
-                                                 ctypes.c_void_p(b.data_ptr()), ctypes.c_void_p(out.ptr), out.cs,
-                                                 self.B, self.H, self.W, self.Hp, self.pad_top, LETTERBOX_VALUE, 32, st)
-                else:
-                    rc = fn(*args, st)
+            w, b, out = self._stem
+            nc = self.head_chunks if (len(self.plan) > 1 and self.plan[0][0] == "stem" and self.plan[1][0] == "conv") else 1
+            Bc = self.B // nc
+            for c in range(nc):                                   # [stem, first conv] per batch chunk
+                rc = self.L.adayolo_stem_fwd(ctypes.c_void_p(img.data_ptr() + c * Bc * 3 * self.H * self.W * 4),
+                                             ctypes.c_void_p(w.data_ptr()), ctypes.c_void_p(b.data_ptr()),
+                                             ctypes.c_void_p(out.ptr + c * Bc * self.Hp * self.W * out.cs * 2), out.cs,
+                                             Bc, self.H, self.W, self.Hp, self.pad_top, LETTERBOX_VALUE, 32, st)
+                if rc != 0:
+                    _lib.check(rc, "adayolo stem")
+                if nc > 1:
+                    _, fn, args = self.plan[1]
+                    a = list(args)
+                    H, W, s = a[9], a[10], a[14]
+                    Ho, Wo = (H - 1) // s + 1, (W - 1) // s + 1
+                    a[0] = ctypes.c_void_p(a[0].value + c * Bc * H * W * a[1] * 2)
+                    a[6] = ctypes.c_void_p(a[6].value + c * Bc * Ho * Wo * a[7] * 2)
+                    a[8] = Bc
+                    rc = fn(*a, st)
+                    if rc != 0:
+                        _lib.check(rc, "adayolo conv")
+            for kind, fn, args in self.plan[(2 if nc > 1 else 1):]:
+                rc = fn(*args, st)
                 if rc != 0:
                     _lib.check(rc, f"adayolo {kind}")
         return self.pred
