@@ -92,6 +92,16 @@ int adayolo_stem_fwd_act(const float* img, const float* weight, const float* bia
                        static_cast<hipStream_t>(stream)) == hipSuccess ? ADAYOLO_OK : ADAYOLO_ELAUNCH;
 }
 
+int adayolo_stem_down_fwd(const float* img, const float* w_stem, const float* b_stem, const void* w_down,
+                          const float* b_down, void* out, int out_cstride, int B, int H, int W, int Hp, int pad_top,
+                          float pad_value, void* stream) {
+    if (!img || !w_stem || !b_stem || !w_down || !b_down || !out) return ADAYOLO_EINVAL;
+    if (B <= 0 || H <= 0 || W <= 0 || Hp < H || pad_top < 0 || pad_top + H > Hp) return ADAYOLO_EINVAL;
+    if ((Hp & 1) || (W & 1) || out_cstride % 8 || out_cstride < 64 || B > 65535) return ADAYOLO_ESHAPE;
+    return launch_stem_down(img, w_stem, b_stem, w_down, b_down, out, out_cstride, B, H, W, Hp, pad_top, pad_value,
+                            static_cast<hipStream_t>(stream)) == hipSuccess ? ADAYOLO_OK : ADAYOLO_ELAUNCH;
+}
+
 static bool ok8(int C, int cs) { return C > 0 && C % 8 == 0 && cs % 8 == 0 && cs >= C; }
 
 int adayolo_silu_fwd(const void* pre, int pre_cstride, const void* residual, int res_cstride, void* out,

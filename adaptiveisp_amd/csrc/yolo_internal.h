@@ -28,6 +28,8 @@ hipError_t launch_conv_pp(ConvArgs a, hipStream_t s, int variant);
 hipError_t launch_conv_pp128(ConvArgs a, hipStream_t s, int variant); // 256x128 ping-pong, 3-deep ring (yolo_conv_pp128.hip)    // 256x256 ping-pong wave groups (yolo_conv_pp.hip) // 3x3, Cin 32/64, whole K resident (yolo_conv_small.hip)
 hipError_t launch_stem(const float* img, const float* w, const float* bias, void* out, int out_cs, int B, int H,
                        int W, int Hp, int pad_top, float pad_value, int act, hipStream_t s);
+hipError_t launch_stem_down(const float* img, const float* w0, const float* b0, const void* w1, const float* b1, void* out,
+                            int out_cs, int B, int H, int W, int Hp, int pad_top, float pad_value, hipStream_t s);
 hipError_t launch_upsample2x(const void* in, int in_cs, void* out, int out_cs, int B, int H, int W, int C,
                              hipStream_t s);
 hipError_t launch_detect_decode(const void* raw, int raw_cs, float* pred, int pred_rows, int row_offset,

@@ -1,0 +1,205 @@
+// Fused detector head: letterbox + stem Conv(3->32, k3 s1) + SiLU + first down-sampling Conv(32->64, k3 s2) + SiLU.
+//
+// The stem's output is the largest tensor of the network (8 x 736 x 1280 x 32 bf16 = 482 MB): written once and read once,
+// it makes the stem (170 us) and the first conv (240 us) HBM-bound at ~3 TB/s. Here it never leaves the CU: a
+// workgroup owns an 8 x 16 tile of the SECOND conv's output, computes the 17 x 33 stem pixels under it into LDS
+// (10 % of them are recomputed by a neighbour) and runs the 3x3 stride-2 conv from there.
+//   A  image patch 19 x 35 x 3 fp32 -> LDS (letterbox value / zero padding resolved here, like k_stem)
+//   B  stem conv on the patch: K = 27 padded to 32 = one v_mfma_f32_16x16x32_bf16 step per 16 pixels and channel half
+//      (weights in registers, same row permutation as k_stem so that a lane owns 8 consecutive channels), bias + SiLU,
+//      bf16, 16-byte chunks XOR-swizzled by the pixel index; stem pixels outside the frame are the second conv's zero pad
+//   C  second conv: K = 9 taps x 32 ch = 18 steps of v_mfma_f32_32x32x16_bf16; a wave owns 64 px x 32 ch, its 72
+//      weight registers are loaded once; activation fragments are gathered from the stem patch (stride-2 pixel walk)
+//   D  bias + SiLU + bf16, transposed through LDS, 128 contiguous bytes per pixel
+// Numerics: the same roundings as the two separate kernels (image and stem output rounded to bf16, fp32 accumulation).
+#include "yolo_internal.h"
+
+namespace adayolo {
+namespace sd {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+
+__device__ __forceinline__ unsigned pack2(float lo, float hi) {
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{lo, hi}, bf16x2));
+}
+__device__ __forceinline__ float silu(float x) {
+    return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504088896341f * x));
+}
+
+constexpr int TY = 8, TX = 16;                       // output tile of the second conv
+constexpr int SH = 2 * TY + 1, SW = 2 * TX + 1;      // stem pixels under it: 17 x 33
+constexpr int IH = SH + 2, IW = SW + 2;              // image pixels under those: 19 x 35
+constexpr int NSP = SH * SW;                         // 561
+constexpr int kImgBytes = ((3 * IH * IW * 4 + 15) / 16) * 16;
+constexpr int kPatchBytes = NSP * 64;                // 32 ch bf16 per stem pixel; the 128 px x 128 B output tile overlays it
+constexpr int kSmem = kImgBytes + kPatchBytes;
+
+__global__ __launch_bounds__(256) void k_stem_down(const float* __restrict__ img, const float* __restrict__ w0,
+                                                   const float* __restrict__ b0, const unsigned short* __restrict__ w1,
+                                                   const float* __restrict__ b1, unsigned short* __restrict__ out,
+                                                   int out_cs, int H, int W, int Hp, int pad_top, float pad_value) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float* tile = reinterpret_cast<float*>(smem);
+    unsigned char* patch = smem + kImgBytes;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int b = blockIdx.z, ox0 = blockIdx.x * TX, oy0 = blockIdx.y * TY;
+    const int Ho = Hp >> 1, Wo = W >> 1;
+    const int fy0 = 2 * oy0 - 1, fx0 = 2 * ox0 - 1;              // frame coordinates of stem-patch pixel (0, 0)
+
+    // ---- second-conv weights of this wave's 32 channels: 18 k-steps x 16 B per lane, issued first (L2 hits)
+    const int chf = wave & 1, pxh = wave >> 1;
+    bf16x8 wfr[18];
+    {
+        const unsigned short* wr = w1 + (long)(32 * chf + (lane & 31)) * 288 + (lane >> 5) * 8;
+#pragma unroll
+        for (int j = 0; j < 18; ++j) wfr[j] = *reinterpret_cast<const bf16x8*>(wr + (j >> 1) * 32 + (j & 1) * 16);
+    }
+
+    // ---- A: image patch (frame rows fy0-1 .. , cols fx0-1 ..)
+    const long plane = (long)H * W;
+    const float* src = img + (long)b * 3 * plane;
+    for (int i = tid; i < 3 * IH * IW; i += 256) {
+        const int c = i / (IH * IW), r = i - c * (IH * IW);
+        const int ly = r / IW, lx = r - ly * IW;
+        const int gy = fy0 - 1 + ly, gx = fx0 - 1 + lx;
+        float v = 0.0f;                                   // the stem conv's zero padding outside the letterboxed frame
+        if (gy >= 0 && gy < Hp && gx >= 0 && gx < W) {
+            const int sy = gy - pad_top;
+            v = (sy >= 0 && sy < H) ? src[c * plane + (long)sy * W + gx] : pad_value;
+        }
+        tile[i] = v;
+    }
+
+    // ---- stem weights as two MFMA A fragments (rows permuted: row 4g+i of fragment t = channel 8g + 4t + i)
+    const int g = lane >> 4, p = lane & 15;
+    bf16x8 wf[2];
+    int off[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int k = 8 * g + e;
+        const int tap = k / 3, c = k - tap * 3, kh = tap / 3, kw = tap - kh * 3;
+        off[e] = (k < 27) ? (c * IH + kh) * IW + kw : 0;
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int ch = 8 * (p >> 2) + 4 * t + (p & 3);
+        float h[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int k = 8 * g + e;
+            h[e] = (k < 27) ? w0[ch * 27 + k] : 0.0f;
+        }
+        const u32x4 pk = {pack2(h[0], h[1]), pack2(h[2], h[3]), pack2(h[4], h[5]), pack2(h[6], h[7])};
+        wf[t] = __builtin_bit_cast(bf16x8, pk);
+    }
+    float bv[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) bv[i] = b0[8 * g + i];
+    __syncthreads();
+
+    // ---- B: stem conv on the patch, 16 pixels per step
+    for (int grp = wave; grp < (NSP + 15) / 16; grp += 4) {
+        const int P = grp * 16 + p;
+        const int Pc = P < NSP ? P : NSP - 1;
+        const int sy = Pc / SW, sx = Pc - sy * SW;
+        const float* t0 = tile + sy * IW + sx;
+        float a[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) a[e] = (8 * g + e < 27) ? t0[off[e]] : 0.0f;
+        const u32x4 pk = {pack2(a[0], a[1]), pack2(a[2], a[3]), pack2(a[4], a[5]), pack2(a[6], a[7])};
+        const bf16x8 af = __builtin_bit_cast(bf16x8, pk);
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        const f32x4 d0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[0], af, z, 0, 0, 0);
+        const f32x4 d1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[1], af, z, 0, 0, 0);
+        const int fy = fy0 + sy, fx = fx0 + sx;
+        const bool inside = fy >= 0 && fy < Hp && fx >= 0 && fx < W;       // else: the second conv's zero padding
+        u32x4 o = {0u, 0u, 0u, 0u};
+        if (inside) {
+            float v[8];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { v[i] = silu(d0[i] + bv[i]); v[4 + i] = silu(d1[i] + bv[4 + i]); }
+            o = u32x4{pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7])};
+        }
+        if (P < NSP) *reinterpret_cast<u32x4*>(patch + P * 64 + ((g ^ ((P >> 1) & 3)) << 4)) = o;
+    }
+    __syncthreads();
+
+    // ---- C: second conv from the patch. Wave: channel fragment chf (32 ch), pixel half pxh (4 output rows x 16)
+    f32x16 acc[2];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[mi][e] = 0.0f;
+    const int fr = lane & 31, fq = lane >> 5;
+    int pbase[2];                                          // patch pixel index of tap (0,0) for this lane's two pixels
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+        const int oyl = 4 * pxh + 2 * mi + (fr >> 4), oxl = fr & 15;
+        pbase[mi] = (2 * oyl) * SW + 2 * oxl;
+    }
+#pragma unroll
+    for (int j = 0; j < 18; ++j) {
+        const int tap = j >> 1, half = j & 1, kh = tap / 3, kw = tap - kh * 3;
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+            const int P = pbase[mi] + kh * SW + kw;
+            const bf16x8 af = *reinterpret_cast<const bf16x8*>(patch + P * 64 + (((2 * half + fq) ^ ((P >> 1) & 3)) << 4));
+            acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wfr[j], af, acc[mi], 0, 0, 0);
+        }
+    }
+    __syncthreads();                                       // every wave is done with the patch: overlay the output tile
+
+    // ---- D: bias + SiLU + bf16 -> LDS [128 px][64 ch] (16-byte chunks swizzled by the pixel) -> 128-byte rows
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+        const int q = (4 * pxh + 2 * mi + (fr >> 4)) * 16 + (fr & 15);
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) {
+            const int cl = 32 * chf + 8 * qd + 4 * fq;                     // 4 consecutive channels
+            const float4 b4 = *reinterpret_cast<const float4*>(b1 + cl);
+            const float bb[4] = {b4.x, b4.y, b4.z, b4.w};
+            float v[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = silu(acc[mi][4 * qd + i] + bb[i]);
+            *reinterpret_cast<u32x2*>(patch + q * 128 + ((((cl >> 3)) ^ (q & 7)) << 4) + (cl & 4) * 2) =
+                u32x2{pack2(v[0], v[1]), pack2(v[2], v[3])};
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int idx = it * 256 + tid, q = idx >> 3, chunk = idx & 7;
+        const int oy = oy0 + (q >> 4), ox = ox0 + (q & 15);
+        if (oy < Ho && ox < Wo) {
+            const u32x4 v = *reinterpret_cast<const u32x4*>(patch + q * 128 + ((chunk ^ (q & 7)) << 4));
+            __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(out + (((long)b * Ho + oy) * Wo + ox) * out_cs + chunk * 8));
+        }
+    }
+}
+
+}  // namespace sd
+
+hipError_t launch_stem_down(const float* img, const float* w0, const float* b0, const void* w1, const float* b1, void* out,
+                            int out_cs, int B, int H, int W, int Hp, int pad_top, float pad_value, hipStream_t s) {
+    static bool configured = false;
+    if (!configured) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(sd::k_stem_down),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, sd::kSmem);
+        if (e != hipSuccess) return e;
+        configured = true;
+    }
+    const int Ho = Hp / 2, Wo = W / 2;
+    dim3 grid((Wo + sd::TX - 1) / sd::TX, (Ho + sd::TY - 1) / sd::TY, B);
+    hipLaunchKernelGGL(sd::k_stem_down, grid, dim3(256), sd::kSmem, s, img, w0, b0, static_cast<const unsigned short*>(w1), b1,
+                       static_cast<unsigned short*>(out), out_cs, H, W, Hp, pad_top, pad_value);
+    return hipGetLastError();
+}
+
+}  // namespace adayolo

@@ -75,6 +75,14 @@ class YoloEngine:
             head_chunks = int(os.environ["ADAYOLO_HEAD_CHUNKS"])
         if head_chunks is None:
             head_chunks = 1
+        # fused stem + first down-sampling conv (yolo_stem_down.hip): available when layer 1 is Conv(32->64, k3, s2) + SiLU
+        self._head_down, self.fuse_head = None, False
+        if len(self.ops) > 1 and self.ops[0]["kind"] == "stem" and self.ops[1]["kind"] == "conv":
+            o = self.ops[1]
+            if (o["k"], o["s"], o["act"], o["cout"], o["src"].C, o["res"]) == (3, 2, _lib.ACT_SILU, 64, 32, None) and \
+                    o["src"] is self._stem[2]:
+                self._head_down = o
+                self.fuse_head = os.environ.get("ADAYOLO_FUSE_HEAD", "1") == "1"
         if self.B % head_chunks:
             raise ValueError(f"head_chunks={head_chunks} does not divide the batch {self.B}")
         self.head_chunks = int(head_chunks)
@@ -264,6 +272,19 @@ class YoloEngine:
         with torch.cuda.device(self.dev):
             st = _lib.stream_ptr()
             w, b, out = self._stem
+            if self.fuse_head:
+                d = self._head_down
+                rc = self.L.adayolo_stem_down_fwd(ctypes.c_void_p(img.data_ptr()), ctypes.c_void_p(w.data_ptr()),
+                                                  ctypes.c_void_p(b.data_ptr()), ctypes.c_void_p(d["w"].data_ptr()),
+                                                  ctypes.c_void_p(d["b"].data_ptr()), ctypes.c_void_p(d["dst"].ptr), d["dst"].cs,
+                                                  self.B, self.H, self.W, self.Hp, self.pad_top, LETTERBOX_VALUE, st)
+                if rc != 0:
+                    _lib.check(rc, "adayolo stem_down")
+                for kind, fn, args in self.plan[2:]:
+                    rc = fn(*args, st)
+                    if rc != 0:
+                        _lib.check(rc, f"adayolo {kind}")
+                return self.pred
             nc = self.head_chunks if (len(self.plan) > 1 and self.plan[0][0] == "stem" and self.plan[1][0] == "conv") else 1
             Bc = self.B // nc
             for c in range(nc):                                   # [stem, first conv] per batch chunk

@@ -136,3 +136,31 @@ def test_engine_vs_reference_model(golden, shape):
         assert (r.cpu() - rr).abs().max().item() <= 3e-2 * scale, "raw head maps (bf16 engine vs fp32 reference)"
     rel = ((pred.cpu() - ref_pred).abs() / (ref_pred.abs() + 1.0)).max().item()
     assert rel < 2e-2, rel
+
+
+@pytest.mark.parametrize("B,H,W", [(2, 64, 96), (1, 72, 128), (1, 200, 224)])
+def test_fused_stem_down_matches_the_two_kernels(B, H, W):
+    """adayolo_stem_down_fwd (stem output kept in LDS) against adayolo_stem_fwd + adayolo_conv_fwd, and the whole engine
+    with the fused head against the engine without it."""
+    import os
+    from _synth import synth_yolo_state_dict, test_image
+    from adaptiveisp_amd.yolo import YoloEngine, yolov3
+    det = yolov3()
+    det.load_state_dict(synth_yolo_state_dict(det, seed=2))
+    det.eval()
+    x = torch.from_numpy(test_image(B, H, W, seed=71, special=False)).to(DEV)
+    os.environ["ADAYOLO_FUSE_HEAD"] = "0"
+    try:
+        plain = YoloEngine(det, B, H, W, device=DEV)
+    finally:
+        os.environ.pop("ADAYOLO_FUSE_HEAD", None)
+    fused = YoloEngine(det, B, H, W, device=DEV)
+    assert fused.fuse_head and not plain.fuse_head
+    ref = plain(x).clone()
+    l1_ref = plain.views[1].tensor().float().clone()
+    out = fused(x)
+    torch.cuda.synchronize()
+    l1 = fused.views[1].tensor().float()
+    assert (l1 - l1_ref).abs().max() <= 2e-2 * max(1.0, l1_ref.abs().max().item())
+    assert (l1 != l1_ref).float().mean() < 0.02            # same roundings: only a different fp32 summation order
+    assert (out - ref).abs().max() <= 5e-2 * max(1.0, ref.abs().max().item())
