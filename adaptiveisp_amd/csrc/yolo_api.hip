@@ -94,12 +94,15 @@ int adayolo_stem_fwd_act(const float* img, const float* weight, const float* bia
 
 int adayolo_stem_down_fwd(const float* img, const float* w_stem, const float* b_stem, const void* w_down,
                           const float* b_down, void* out, int out_cstride, int B, int H, int W, int Hp, int pad_top,
-                          float pad_value, void* stream) {
+                          float pad_value, const void* w_next, const float* b_next, void* out_next, int out_next_cstride,
+                          void* stream) {
     if (!img || !w_stem || !b_stem || !w_down || !b_down || !out) return ADAYOLO_EINVAL;
+    if (w_next && (!b_next || !out_next)) return ADAYOLO_EINVAL;
+    if (w_next && (out_next_cstride % 8 || out_next_cstride < 32)) return ADAYOLO_ESHAPE;
     if (B <= 0 || H <= 0 || W <= 0 || Hp < H || pad_top < 0 || pad_top + H > Hp) return ADAYOLO_EINVAL;
     if ((Hp & 1) || (W & 1) || out_cstride % 8 || out_cstride < 64 || B > 65535) return ADAYOLO_ESHAPE;
     return launch_stem_down(img, w_stem, b_stem, w_down, b_down, out, out_cstride, B, H, W, Hp, pad_top, pad_value,
-                            static_cast<hipStream_t>(stream)) == hipSuccess ? ADAYOLO_OK : ADAYOLO_ELAUNCH;
+                            w_next, b_next, out_next, out_next_cstride, static_cast<hipStream_t>(stream)) == hipSuccess ? ADAYOLO_OK : ADAYOLO_ELAUNCH;
 }
 
 static bool ok8(int C, int cs) { return C > 0 && C % 8 == 0 && cs % 8 == 0 && cs >= C; }

@@ -29,7 +29,8 @@ hipError_t launch_conv_pp128(ConvArgs a, hipStream_t s, int variant); // 256x128
 hipError_t launch_stem(const float* img, const float* w, const float* bias, void* out, int out_cs, int B, int H,
                        int W, int Hp, int pad_top, float pad_value, int act, hipStream_t s);
 hipError_t launch_stem_down(const float* img, const float* w0, const float* b0, const void* w1, const float* b1, void* out,
-                            int out_cs, int B, int H, int W, int Hp, int pad_top, float pad_value, hipStream_t s);
+                            int out_cs, int B, int H, int W, int Hp, int pad_top, float pad_value, const void* w2,
+                            const float* b2, void* out2, int out2_cs, hipStream_t s);
 hipError_t launch_upsample2x(const void* in, int in_cs, void* out, int out_cs, int B, int H, int W, int C,
                              hipStream_t s);
 hipError_t launch_detect_decode(const void* raw, int raw_cs, float* pred, int pred_rows, int row_offset,

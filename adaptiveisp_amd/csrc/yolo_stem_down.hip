@@ -11,6 +11,7 @@
 //   C  second conv: K = 9 taps x 32 ch = 18 steps of v_mfma_f32_32x32x16_bf16; a wave owns 64 px x 32 ch, its 72
 //      weight registers are loaded once; activation fragments are gathered from the stem patch (stride-2 pixel walk)
 //   D  bias + SiLU + bf16, transposed through LDS, 128 contiguous bytes per pixel
+//   E  (optional) the following 1x1 conv (Bottleneck.cv1, 64 -> 32) + SiLU from the output tile while it is in LDS
 // Numerics: the same roundings as the two separate kernels (image and stem output rounded to bf16, fp32 accumulation).
 #include "yolo_internal.h"
 
@@ -43,7 +44,9 @@ constexpr int kSmem = kImgBytes + kPatchBytes;
 __global__ __launch_bounds__(256) void k_stem_down(const float* __restrict__ img, const float* __restrict__ w0,
                                                    const float* __restrict__ b0, const unsigned short* __restrict__ w1,
                                                    const float* __restrict__ b1, unsigned short* __restrict__ out,
-                                                   int out_cs, int H, int W, int Hp, int pad_top, float pad_value) {
+                                                   int out_cs, int H, int W, int Hp, int pad_top, float pad_value,
+                                                   const unsigned short* __restrict__ w2, const float* __restrict__ b2,
+                                                   unsigned short* __restrict__ out2, int out2_cs) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float* tile = reinterpret_cast<float*>(smem);
     unsigned char* patch = smem + kImgBytes;
@@ -182,12 +185,52 @@ __global__ __launch_bounds__(256) void k_stem_down(const float* __restrict__ img
             __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(out + (((long)b * Ho + oy) * Wo + ox) * out_cs + chunk * 8));
         }
     }
+    if (!w2) return;
+
+    // ---- E (optional): the 1x1 conv that follows in yolov3.yaml (Bottleneck.cv1: 64 -> 32) + SiLU, straight from the
+    //      output tile in LDS: wave w takes pixels 32w .. 32w+31, K = 64 = 4 MFMA steps; its result goes through the
+    //      8 KB behind the tile and leaves as 64-byte pixel rows.
+    f32x16 h;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) h[e] = 0.0f;
+    {
+        const int q = 32 * wave + fr;
+        const unsigned short* wr = w2 + (long)fr * 64 + fq * 8;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const bf16x8 wv = *reinterpret_cast<const bf16x8*>(wr + kk * 16);
+            const bf16x8 av = *reinterpret_cast<const bf16x8*>(patch + q * 128 + (((2 * kk + fq) ^ (q & 7)) << 4));
+            h = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wv, av, h, 0, 0, 0);
+        }
+        unsigned char* t2 = patch + 128 * 128;                             // [128 px][32 ch] bf16, chunks swizzled by the pixel
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) {
+            const int cl = 8 * qd + 4 * fq;
+            const float4 b4 = *reinterpret_cast<const float4*>(b2 + cl);
+            const float bb[4] = {b4.x, b4.y, b4.z, b4.w};
+            float v[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = silu(h[4 * qd + i] + bb[i]);
+            *reinterpret_cast<u32x2*>(t2 + q * 64 + (((cl >> 3) ^ (q & 3)) << 4) + (cl & 4) * 2) = u32x2{pack2(v[0], v[1]), pack2(v[2], v[3])};
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                 // the wave reads back only what it wrote
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int q2 = 32 * wave + it * 16 + (lane >> 2), chunk = lane & 3;
+            const int oy = oy0 + (q2 >> 4), ox = ox0 + (q2 & 15);
+            if (oy < Ho && ox < Wo) {
+                const u32x4 v = *reinterpret_cast<const u32x4*>(t2 + q2 * 64 + ((chunk ^ (q2 & 3)) << 4));
+                __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(out2 + (((long)b * Ho + oy) * Wo + ox) * out2_cs + chunk * 8));
+            }
+        }
+    }
 }
 
 }  // namespace sd
 
 hipError_t launch_stem_down(const float* img, const float* w0, const float* b0, const void* w1, const float* b1, void* out,
-                            int out_cs, int B, int H, int W, int Hp, int pad_top, float pad_value, hipStream_t s) {
+                            int out_cs, int B, int H, int W, int Hp, int pad_top, float pad_value, const void* w2,
+                            const float* b2, void* out2, int out2_cs, hipStream_t s) {
     static bool configured = false;
     if (!configured) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(sd::k_stem_down),
@@ -198,7 +241,8 @@ hipError_t launch_stem_down(const float* img, const float* w0, const float* b0, 
     const int Ho = Hp / 2, Wo = W / 2;
     dim3 grid((Wo + sd::TX - 1) / sd::TX, (Ho + sd::TY - 1) / sd::TY, B);
     hipLaunchKernelGGL(sd::k_stem_down, grid, dim3(256), sd::kSmem, s, img, w0, b0, static_cast<const unsigned short*>(w1), b1,
-                       static_cast<unsigned short*>(out), out_cs, H, W, Hp, pad_top, pad_value);
+                       static_cast<unsigned short*>(out), out_cs, H, W, Hp, pad_top, pad_value,
+                       static_cast<const unsigned short*>(w2), b2, static_cast<unsigned short*>(out2), out2_cs);
     return hipGetLastError();
 }
 

@@ -35,7 +35,7 @@ def load():
     L.adayolo_detect_decode.argtypes = [vp, ci, vp, ci, ci, vp, cf, ci, ci, ci, ci, ci, vp]
     cl = ctypes.c_long
     L.adayolo_stem_fwd_act.argtypes = [vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, cf, ci, ci, vp]
-    L.adayolo_stem_down_fwd.argtypes = [vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, cf, vp]
+    L.adayolo_stem_down_fwd.argtypes = [vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, cf, vp, vp, vp, ci, vp]
     L.adayolo_stem_down_fwd.restype = ci
     L.adayolo_silu_fwd.argtypes = [vp, ci, vp, ci, vp, ci, cl, ci, vp]
     L.adayolo_silu_bwd.argtypes = [vp, ci, vp, ci, vp, ci, vp, ci, ci, cl, ci, vp]

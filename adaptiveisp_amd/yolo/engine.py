@@ -76,13 +76,18 @@ class YoloEngine:
         if head_chunks is None:
             head_chunks = 1
         # fused stem + first down-sampling conv (yolo_stem_down.hip): available when layer 1 is Conv(32->64, k3, s2) + SiLU
-        self._head_down, self.fuse_head = None, False
+        self._head_down, self._head_next, self.fuse_head = None, None, False
         if len(self.ops) > 1 and self.ops[0]["kind"] == "stem" and self.ops[1]["kind"] == "conv":
             o = self.ops[1]
             if (o["k"], o["s"], o["act"], o["cout"], o["src"].C, o["res"]) == (3, 2, _lib.ACT_SILU, 64, 32, None) and \
                     o["src"] is self._stem[2]:
                 self._head_down = o
                 self.fuse_head = os.environ.get("ADAYOLO_FUSE_HEAD", "1") == "1"
+                n = self.ops[2] if len(self.ops) > 2 else None       # Bottleneck.cv1 of layer 2: 1x1, 64 -> 32
+                if n is not None and n["kind"] == "conv" and n["src"] is o["dst"] and n["res"] is None and \
+                        (n["k"], n["s"], n["act"], n["cout"], n["src"].C) == (1, 1, _lib.ACT_SILU, 32, 64) and \
+                        self.plan[2][0] == "conv" and os.environ.get("ADAYOLO_FUSE_HEAD_NEXT", "1") == "1":
+                    self._head_next = n
         if self.B % head_chunks:
             raise ValueError(f"head_chunks={head_chunks} does not divide the batch {self.B}")
         self.head_chunks = int(head_chunks)
@@ -273,14 +278,17 @@ class YoloEngine:
             st = _lib.stream_ptr()
             w, b, out = self._stem
             if self.fuse_head:
-                d = self._head_down
+                d, n = self._head_down, self._head_next
                 rc = self.L.adayolo_stem_down_fwd(ctypes.c_void_p(img.data_ptr()), ctypes.c_void_p(w.data_ptr()),
                                                   ctypes.c_void_p(b.data_ptr()), ctypes.c_void_p(d["w"].data_ptr()),
                                                   ctypes.c_void_p(d["b"].data_ptr()), ctypes.c_void_p(d["dst"].ptr), d["dst"].cs,
-                                                  self.B, self.H, self.W, self.Hp, self.pad_top, LETTERBOX_VALUE, st)
+                                                  self.B, self.H, self.W, self.Hp, self.pad_top, LETTERBOX_VALUE,
+                                                  ctypes.c_void_p(n["w"].data_ptr()) if n else None,
+                                                  ctypes.c_void_p(n["b"].data_ptr()) if n else None,
+                                                  ctypes.c_void_p(n["dst"].ptr) if n else None, n["dst"].cs if n else 0, st)
                 if rc != 0:
                     _lib.check(rc, "adayolo stem_down")
-                for kind, fn, args in self.plan[2:]:
+                for kind, fn, args in self.plan[(3 if n else 2):]:
                     rc = fn(*args, st)
                     if rc != 0:
                         _lib.check(rc, f"adayolo {kind}")

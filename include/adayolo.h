@@ -77,10 +77,13 @@ int adayolo_stem_fwd(const float* img, const float* weight, const float* bias, v
  * adayolo_stem_fwd fused with the first down-sampling block of yolov3.yaml (layer 1: Conv(32->64, k3 s2) + SiLU):
  * planar fp32 image in, NHWC bf16 [B, Hp/2, W/2, 64] out; the 32-channel stem output stays in LDS.
  * w_stem fp32 [32][3][3][3], w_down bf16 [64][3][3][32] (BN folded), biases fp32. Hp and W even.
+ * Optionally (w_next != NULL) also the 1x1 conv that follows (layer 2's Bottleneck.cv1: 64 -> 32, w_next bf16 [32][64])
+ * + SiLU, computed from the output tile while it is in LDS: out_next NHWC bf16 [B, Hp/2, W/2, 32].
  */
 int adayolo_stem_down_fwd(const float* img, const float* w_stem, const float* b_stem, const void* w_down,
                           const float* b_down, void* out, int out_cstride, int B, int H, int W, int Hp, int pad_top,
-                          float pad_value, void* stream);
+                          float pad_value, const void* w_next, const float* b_next, void* out_next, int out_next_cstride,
+                          void* stream);
 
 /* adayolo_stem_fwd with the activation selectable (ADAYOLO_ACT_NONE keeps the pre-activation for training). */
 int adayolo_stem_fwd_act(const float* img, const float* weight, const float* bias, void* out, int out_cstride,

@@ -154,13 +154,24 @@ def test_fused_stem_down_matches_the_two_kernels(B, H, W):
         plain = YoloEngine(det, B, H, W, device=DEV)
     finally:
         os.environ.pop("ADAYOLO_FUSE_HEAD", None)
+    os.environ["ADAYOLO_FUSE_HEAD_NEXT"] = "0"
+    try:
+        two = YoloEngine(det, B, H, W, device=DEV)          # stem + down fused, the 1x1 that follows launched separately
+    finally:
+        os.environ.pop("ADAYOLO_FUSE_HEAD_NEXT", None)
     fused = YoloEngine(det, B, H, W, device=DEV)
-    assert fused.fuse_head and not plain.fuse_head
+    assert fused.fuse_head and fused._head_next is not None and two.fuse_head and two._head_next is None
+    assert not plain.fuse_head
     ref = plain(x).clone()
     l1_ref = plain.views[1].tensor().float().clone()
-    out = fused(x)
-    torch.cuda.synchronize()
-    l1 = fused.views[1].tensor().float()
-    assert (l1 - l1_ref).abs().max() <= 2e-2 * max(1.0, l1_ref.abs().max().item())
-    assert (l1 != l1_ref).float().mean() < 0.02            # same roundings: only a different fp32 summation order
-    assert (out - ref).abs().max() <= 5e-2 * max(1.0, ref.abs().max().item())
+    h2_ref = plain.ops[2]["dst"].tensor().float().clone()
+    for eng in (two, fused):
+        out = eng(x)
+        torch.cuda.synchronize()
+        l1 = eng.views[1].tensor().float()
+        assert (l1 - l1_ref).abs().max() <= 2e-2 * max(1.0, l1_ref.abs().max().item())
+        assert (l1 != l1_ref).float().mean() < 0.02        # same roundings: only a different fp32 summation order
+        h2 = eng.ops[2]["dst"].tensor().float()
+        assert (h2 - h2_ref).abs().max() <= 2e-2 * max(1.0, h2_ref.abs().max().item())
+        assert (h2 != h2_ref).float().mean() < 0.04
+        assert (out - ref).abs().max() <= 5e-2 * max(1.0, ref.abs().max().item())
