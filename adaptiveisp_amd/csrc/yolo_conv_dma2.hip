@@ -11,6 +11,7 @@
 //   * v_mfma_f32_32x32x16_bf16: half the MFMA instructions for the same flops and the same LDS traffic;
 //     with the (row>>1)&7 XOR key the 32-row fragment reads are bank-conflict-free.
 #include "yolo_internal.h"
+#include <type_traits>
 #ifdef ADAYOLO_PLAIN_STORES   // A/B switch (measurement): keep the output lines in the XCD L2 instead of streaming them
 #define ADAYOLO_STORE(v, p) (*(p) = (v))
 #else
@@ -109,9 +110,12 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void k_conv_igemm_dma32(const C
             const int wo = rem - ho * a.Wo;
             const int hi0 = ho * a.stride - a.pad, wi0 = wo * a.stride - a.pad;
             unsigned vw = 0;                                   // tap validity is separable: rows x columns
-            for (int kw = 0; kw < a.ks; ++kw) vw |= (unsigned)(wi0 + kw >= 0 && wi0 + kw < a.W) << kw;
-            for (int kh = 0; kh < a.ks; ++kh)
-                if (hi0 + kh >= 0 && hi0 + kh < a.H) mask |= vw << (kh * a.ks);
+            // ks is 1 or 3 (checked at the ABI): three straight-line taps, no loop
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) vw |= (unsigned)(kw < a.ks && wi0 + kw >= 0 && wi0 + kw < a.W) << kw;
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh)
+                mask |= (kh < a.ks && hi0 + kh >= 0 && hi0 + kh < a.H) ? vw << (kh * a.ks) : 0u;
             off = ((long)b * a.H * a.W + (long)hi0 * a.W + wi0) * a.in_cs + 8 * q;
         }
         amask[i] = mask;
@@ -235,26 +239,26 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void k_conv_igemm_dma32(const C
 
     // ---- epilogue: D[row = channel][col = pixel]; lane holds channels (e&3) + 8*(e>>2) + 4*(lane>>5) -------
     unsigned short* Cs = reinterpret_cast<unsigned short*>(smem);
+    auto convert = [&](auto silu_tag) {
+        constexpr bool kSilu = decltype(silu_tag)::value;
 #pragma unroll
-    for (int ni = 0; ni < NI; ++ni) {
+        for (int ni = 0; ni < NI; ++ni) {
 #pragma unroll
-        for (int qd = 0; qd < 4; ++qd) {
-            const int nl = wn * TN + ni * 32 + 8 * qd + 4 * (lane >> 5);     // 4 consecutive channels
-            const float4 b4 = *reinterpret_cast<const float4*>(bias_s + nl);
-            const float bv[4] = {b4.x, b4.y, b4.z, b4.w};
+            for (int qd = 0; qd < 4; ++qd) {
+                const int nl = wn * TN + ni * 32 + 8 * qd + 4 * (lane >> 5);     // 4 consecutive channels
+                const float4 b4 = *reinterpret_cast<const float4*>(bias_s + nl);
 #pragma unroll
-            for (int mi = 0; mi < MI; ++mi) {
-                float v[4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    v[i] = acc[ni][mi][4 * qd + i] + bv[i];
-                    if (a.act == ADAYOLO_ACT_SILU) v[i] = silu(v[i]);
+                for (int mi = 0; mi < MI; ++mi) {
+                    unsigned lo, hi;
+                    bias_act_pack4<kSilu>(acc[ni][mi][4 * qd], acc[ni][mi][4 * qd + 1], acc[ni][mi][4 * qd + 2], acc[ni][mi][4 * qd + 3], b4, lo, hi);
+                    const int ml = wm * TM + mi * 32 + (lane & 31);
+                    *reinterpret_cast<u32x2*>(Cs + ml * CP + nl) = u32x2{lo, hi};
                 }
-                const int ml = wm * TM + mi * 32 + (lane & 31);
-                *reinterpret_cast<u32x2*>(Cs + ml * CP + nl) = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
             }
         }
-    }
+    };
+    if (a.act == ADAYOLO_ACT_SILU) convert(std::true_type{});   // two copies: the activation is not a per-element select
+    else convert(std::false_type{});
     __syncthreads();
     constexpr int CPR = BN / 8;
     // fixed trip count -> fully unrolled, so all residual loads / LDS reads are in flight before the first store

@@ -20,6 +20,7 @@
 //
 // Restrictions (the launcher falls back otherwise): Cin % 64 == 0, Cout % 128 == 0.
 #include "yolo_internal.h"
+#include <type_traits>
 
 namespace adayolo {
 namespace pp128 {
@@ -118,9 +119,12 @@ __global__ __launch_bounds__(512) void k_conv_pp128(const ConvArgs a) {
                 const int wo = rem - ho * a.Wo;
                 const int hi0 = ho * a.stride - a.pad, wi0 = wo * a.stride - a.pad;
                 unsigned vw = 0;                               // tap validity is separable: rows x columns
-                for (int kw = 0; kw < a.ks; ++kw) vw |= (unsigned)(wi0 + kw >= 0 && wi0 + kw < a.W) << kw;
-                for (int kh = 0; kh < a.ks; ++kh)
-                    if (hi0 + kh >= 0 && hi0 + kh < a.H) mask |= vw << (kh * a.ks);
+                // ks is 1 or 3 (checked at the ABI): three straight-line taps, no loop
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw) vw |= (unsigned)(kw < a.ks && wi0 + kw >= 0 && wi0 + kw < a.W) << kw;
+#pragma unroll
+                for (int kh = 0; kh < 3; ++kh)
+                    mask |= (kh < a.ks && hi0 + kh >= 0 && hi0 + kh < a.H) ? vw << (kh * a.ks) : 0u;
                 off = ((long)b * a.H * a.W + (long)hi0 * a.W + wi0) * a.in_cs + 8 * q;
             }
             amask[i] = mask;
@@ -262,42 +266,69 @@ __global__ __launch_bounds__(512) void k_conv_pp128(const ConvArgs a) {
 
     // ---- epilogue: wave-private LDS transpose (see yolo_conv_pp.hip), 32 px x 64 ch at a time, 128-byte row segments
     unsigned char* my = smem + wave * (64 * kEpiPitch);
-#pragma unroll
-    for (int mi = 0; mi < 2; ++mi) {
+    // see yolo_conv_pp.hip: compile-time activation / residual copies, bias and pointers hoisted, batched reads and stores
+    auto epilogue = [&](auto silu_tag, auto res_tag) {
+        constexpr bool kSilu = decltype(silu_tag)::value, kRes = decltype(res_tag)::value;
+        typedef __attribute__((ext_vector_type(2))) float f32x2v;
+        float4 bq[2][4];
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
-            for (int qd = 0; qd < 4; ++qd) {
-                const int nl = wn * 64 + ni * 32 + 8 * qd + 4 * (lane >> 5);
-                const float4 b4 = *reinterpret_cast<const float4*>(bias_s + nl);
-                const float bv[4] = {b4.x, b4.y, b4.z, b4.w};
-                float v[4];
+            for (int qd = 0; qd < 4; ++qd)
+                bq[ni][qd] = *reinterpret_cast<const float4*>(bias_s + wn * 64 + ni * 32 + 8 * qd + 4 * (lane >> 5));
+        const int chunk = lane & 7, r0 = lane >> 3;
+        const int mrow = m0 + wm * 64 + r0, n = n0 + wn * 64 + chunk * 8;
+        unsigned short* const op = a.out + (long)mrow * a.out_cs + n;
+        const unsigned short* const rp = kRes ? a.res + (long)mrow * a.res_cs + n : nullptr;
+        const long ostep = 8L * a.out_cs, rstep = kRes ? 8L * a.res_cs : 0;
+        unsigned char* const wr = my + (lane & 31) * kEpiPitch + 8 * (lane >> 5);
+        const unsigned char* const rd = my + r0 * kEpiPitch + chunk * 16;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    v[i] = acc[ni][mi][4 * qd + i] + bv[i];
-                    if (a.act == ADAYOLO_ACT_SILU) v[i] = silu(v[i]);
-                }
-                *reinterpret_cast<u32x2*>(my + (mi * 32 + (lane & 31)) * kEpiPitch + (ni * 32 + 8 * qd + 4 * (lane >> 5)) * 2) =
-                    u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
-            }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // same wave wrote and reads: in-order LDS, no barrier
+        for (int mi = 0; mi < 2; ++mi) {
+            u32x4 v[4], r[4];
+            bool ok[4];
 #pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            const int row = mi * 32 + it * 8 + (lane >> 3), chunk = lane & 7;
-            const int m = m0 + wm * 64 + row, n = n0 + wn * 64 + chunk * 8;
-            const bool ok = m < a.M;
-            u32x4 v = *reinterpret_cast<const u32x4*>(my + row * kEpiPitch + chunk * 16);
-            if (a.res && ok) {
-                const u32x4 r = *reinterpret_cast<const u32x4*>(a.res + (long)m * a.res_cs + n);
+            for (int it = 0; it < 4; ++it) ok[it] = mrow + 8 * (4 * mi + it) < a.M;
+            if (kRes) {                                          // in flight while this group's SiLUs are computed
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float lo = bf16_to_f32((unsigned short)(v[j] & 0xFFFFu)) + bf16_to_f32((unsigned short)(r[j] & 0xFFFFu));
-                    const float hh = bf16_to_f32((unsigned short)(v[j] >> 16)) + bf16_to_f32((unsigned short)(r[j] >> 16));
-                    v[j] = pack_bf16x2(lo, hh);
+                for (int it = 0; it < 4; ++it) {
+                    r[it] = u32x4{0u, 0u, 0u, 0u};
+                    if (ok[it]) r[it] = *reinterpret_cast<const u32x4*>(rp + (4 * mi + it) * rstep);
                 }
             }
-            if (ok) __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(a.out + (long)m * a.out_cs + n));
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                for (int qd = 0; qd < 4; ++qd) {
+                    unsigned lo, hi;
+                    bias_act_pack4<kSilu>(acc[ni][mi][4 * qd], acc[ni][mi][4 * qd + 1], acc[ni][mi][4 * qd + 2], acc[ni][mi][4 * qd + 3],
+                                          bq[ni][qd], lo, hi);
+                    *reinterpret_cast<u32x2*>(wr + mi * 32 * kEpiPitch + (ni * 32 + 8 * qd) * 2) = u32x2{lo, hi};
+                }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // same wave wrote and reads: in-order LDS, no barrier
+#pragma unroll
+            for (int it = 0; it < 4; ++it) v[it] = *reinterpret_cast<const u32x4*>(rd + (mi * 32 + it * 8) * kEpiPitch);
+            if (kRes) {
+#pragma unroll
+                for (int it = 0; it < 4; ++it)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const f32x2v x = f32x2v{__uint_as_float(v[it][j] << 16), __uint_as_float(v[it][j] & 0xFFFF0000u)} +
+                                         f32x2v{__uint_as_float(r[it][j] << 16), __uint_as_float(r[it][j] & 0xFFFF0000u)};
+                        v[it][j] = pack_bf16x2(x.x, x.y);
+                    }
+            }
+#pragma unroll
+            for (int it = 0; it < 4; ++it)
+                if (ok[it]) __builtin_nontemporal_store(v[it], reinterpret_cast<u32x4*>(op + (4 * mi + it) * ostep));
         }
+    };
+    if (a.act == ADAYOLO_ACT_SILU) {
+        if (a.res) epilogue(std::true_type{}, std::true_type{});
+        else epilogue(std::true_type{}, std::false_type{});
+    } else {
+        if (a.res) epilogue(std::false_type{}, std::true_type{});
+        else epilogue(std::false_type{}, std::false_type{});
     }
 }
 

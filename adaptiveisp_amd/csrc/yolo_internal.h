@@ -19,6 +19,27 @@ struct ConvArgs {
     int sh_hw, sh_w;
 };
 
+// Epilogue math on channel pairs: packed fp32 (v_pk_add/mul_f32 do two channels per issue slot; the two transcendentals
+// stay per element) — the conv epilogues are VALU-bound on exactly this (128 SiLUs per lane in the 256x256 kernel).
+typedef float f32x2_pk __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2_pk silu_pk(f32x2_pk x) {
+    const f32x2_pk u = x * -1.44269504088896341f;
+    f32x2_pk e = {__builtin_amdgcn_exp2f(u.x), __builtin_amdgcn_exp2f(u.y)};
+    e = e + 1.0f;
+    const f32x2_pk r = {__builtin_amdgcn_rcpf(e.x), __builtin_amdgcn_rcpf(e.y)};
+    return x * r;
+}
+// four consecutive channels: + bias, SiLU (compile-time), round to bf16 (v_cvt_pk_bf16_f32) -> two packed words
+template <bool SILU>
+__device__ __forceinline__ void bias_act_pack4(float a0, float a1, float a2, float a3, const float4 b, unsigned& lo, unsigned& hi) {
+    typedef __bf16 bf16x2_pk __attribute__((ext_vector_type(2)));
+    f32x2_pk x0 = f32x2_pk{a0, a1} + f32x2_pk{b.x, b.y};
+    f32x2_pk x1 = f32x2_pk{a2, a3} + f32x2_pk{b.z, b.w};
+    if (SILU) { x0 = silu_pk(x0); x1 = silu_pk(x1); }
+    lo = __builtin_bit_cast(unsigned, __builtin_convertvector(x0, bf16x2_pk));
+    hi = __builtin_bit_cast(unsigned, __builtin_convertvector(x1, bf16x2_pk));
+}
+
 hipError_t launch_conv(ConvArgs a, hipStream_t s);                    // register-staged (yolo_conv.hip)
 hipError_t launch_conv_dma(ConvArgs a, hipStream_t s, int variant);   // LDS-DMA ring (yolo_conv_dma.hip)
 hipError_t launch_conv_dma2(ConvArgs a, hipStream_t s, int variant);  // lean-address 32x32 MFMA ring (yolo_conv_dma2.hip)

@@ -125,10 +125,10 @@ __global__ __launch_bounds__(256) void k_stem_down(const float* __restrict__ img
         const bool inside = fy >= 0 && fy < Hp && fx >= 0 && fx < W;       // else: the second conv's zero padding
         u32x4 o = {0u, 0u, 0u, 0u};
         if (inside) {
-            float v[8];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) { v[i] = silu(d0[i] + bv[i]); v[4 + i] = silu(d1[i] + bv[4 + i]); }
-            o = u32x4{pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7])};
+            unsigned o0, o1, o2, o3;
+            bias_act_pack4<true>(d0[0], d0[1], d0[2], d0[3], float4{bv[0], bv[1], bv[2], bv[3]}, o0, o1);
+            bias_act_pack4<true>(d1[0], d1[1], d1[2], d1[3], float4{bv[4], bv[5], bv[6], bv[7]}, o2, o3);
+            o = u32x4{o0, o1, o2, o3};
         }
         if (P < NSP) *reinterpret_cast<u32x4*>(patch + P * 64 + ((g ^ ((P >> 1) & 3)) << 4)) = o;
     }
@@ -167,12 +167,9 @@ __global__ __launch_bounds__(256) void k_stem_down(const float* __restrict__ img
         for (int qd = 0; qd < 4; ++qd) {
             const int cl = 32 * chf + 8 * qd + 4 * fq;                     // 4 consecutive channels
             const float4 b4 = *reinterpret_cast<const float4*>(b1 + cl);
-            const float bb[4] = {b4.x, b4.y, b4.z, b4.w};
-            float v[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) v[i] = silu(acc[mi][4 * qd + i] + bb[i]);
-            *reinterpret_cast<u32x2*>(patch + q * 128 + ((((cl >> 3)) ^ (q & 7)) << 4) + (cl & 4) * 2) =
-                u32x2{pack2(v[0], v[1]), pack2(v[2], v[3])};
+            unsigned lo, hi;
+            bias_act_pack4<true>(acc[mi][4 * qd], acc[mi][4 * qd + 1], acc[mi][4 * qd + 2], acc[mi][4 * qd + 3], b4, lo, hi);
+            *reinterpret_cast<u32x2*>(patch + q * 128 + ((((cl >> 3)) ^ (q & 7)) << 4) + (cl & 4) * 2) = u32x2{lo, hi};
         }
     }
     __syncthreads();
@@ -207,11 +204,9 @@ __global__ __launch_bounds__(256) void k_stem_down(const float* __restrict__ img
         for (int qd = 0; qd < 4; ++qd) {
             const int cl = 8 * qd + 4 * fq;
             const float4 b4 = *reinterpret_cast<const float4*>(b2 + cl);
-            const float bb[4] = {b4.x, b4.y, b4.z, b4.w};
-            float v[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) v[i] = silu(h[4 * qd + i] + bb[i]);
-            *reinterpret_cast<u32x2*>(t2 + q * 64 + (((cl >> 3) ^ (q & 3)) << 4) + (cl & 4) * 2) = u32x2{pack2(v[0], v[1]), pack2(v[2], v[3])};
+            unsigned lo, hi;
+            bias_act_pack4<true>(h[4 * qd], h[4 * qd + 1], h[4 * qd + 2], h[4 * qd + 3], b4, lo, hi);
+            *reinterpret_cast<u32x2*>(t2 + q * 64 + (((cl >> 3) ^ (q & 3)) << 4) + (cl & 4) * 2) = u32x2{lo, hi};
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                 // the wave reads back only what it wrote
 #pragma unroll
