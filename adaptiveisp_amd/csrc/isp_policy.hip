@@ -121,6 +121,94 @@ __global__ __launch_bounds__(1024) void k_trunk_conv(const float* __restrict__ i
     }
 }
 
+// ---- trunk conv on the fp32 matrix cores ----------------------------------------------------------------------
+// The same layer as an implicit GEMM D[co][px] = W[co][k] . X[k][px], k = ci*16 + kh*4 + kw, on
+// v_mfma_f32_16x16x4_f32 (fp32 products, fp32 accumulation). A wave owns a 16 co x 16 px tile and a slice of the
+// input channels; a lane feeds one weight row (A) and one pixel column (B). One input channel = 16 k = four MFMAs:
+// lane quarter q = lane >> 4 owns kernel row kh = q and loads its four taps — a float4 of the weight row and four
+// neighbouring input pixels — and MFMA j pairs tap kw = j of all four quarters, so neither operand passes through
+// LDS. Up to 16 waves split the input channels (8 per wave per round) and meet in LDS, summed in slice order
+// (deterministic). The 16x16 tile is what spreads the deep layers over the chip: the last layer is 128 px x 256 co
+// = 256 tiles (64 with 32x32 tiles, whose K = 2048 then serialises 16k matrix cycles on one CU); every layer of the
+// trunk comes to ~4k matrix cycles per CU. Weights and, between two RL steps, the activations come from HBM or
+// another XCD's writes (~1-2 us per dependent access), so a wave issues ALL loads of a round before its first MFMA.
+// (k_trunk_conv — 64 x 8 scalar-weight FMAs per lane, 64 KB of staged weights per workgroup — is kept for the shapes
+// this form does not take.)
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+constexpr int TM_U = 8;                                         // input channels per round (all loads before the first MFMA)
+
+__global__ __launch_bounds__(1024) void k_trunk_mfma(const float* __restrict__ in, const float* __restrict__ states,
+                                                     int n_state, const float* __restrict__ w,
+                                                     const float* __restrict__ bias, float* __restrict__ out, int B,
+                                                     int Cin, int Hin, int Cout, int KS) {
+    __shared__ float part[15 * 4 * 64];                         // slices 1..15 (slice 0 keeps its registers)
+    const int Ho = Hin >> 1, HW = Hin * Hin;
+    const int g = blockIdx.z, co0 = blockIdx.y * 16;
+    const int lane = threadIdx.x & 63, ks = threadIdx.x >> 6;
+    const int col = lane & 15, q = lane >> 4;
+    const int npix = B * Ho * Ho;
+    const int idx = blockIdx.x * 16 + col;
+    const bool live = idx < npix;
+    const int pid = live ? idx : npix - 1;
+    const int b = pid / (Ho * Ho), r = pid - b * Ho * Ho, oy = r / Ho, ox = r - oy * Ho;
+    const int n_img = states ? 3 : Cin;
+    const float* ib = states ? in + (long)b * 3 * HW : in + ((long)g * B + b) * Cin * HW;
+    const float* wrow = w + ((long)g * Cout + co0 + col) * Cin * 16 + 4 * q;
+    // this lane's kernel row kh = q and its four taps: clamped addresses (every load is legal and unconditional), the
+    // zero padding is a multiply by 0/1 afterwards (a select would be turned into a branch around the load + vmcnt(0))
+    const int iy = 2 * oy - 1 + q, ix0 = 2 * ox - 1;
+    const float fy = (iy >= 0 && iy < Hin) ? 1.0f : 0.0f;
+    const int rowoff = min(max(iy, 0), Hin - 1) * Hin;
+    int cx[4];
+    float fm[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        cx[t] = rowoff + min(max(ix0 + t, 0), Hin - 1);
+        fm[t] = (ix0 + t >= 0 && ix0 + t < Hin) ? fy : 0.0f;
+    }
+    // a state channel (first layer, ci >= 3) is a constant plane: the same scalar for every tap inside the frame
+    // (enrich_image_input, util.py:58-63)
+    const float* sb = states ? states + b * n_state - 3 : in;
+    const int cpw = Cin / KS;                                   // input channels per wave, a multiple of TM_U (launcher)
+    f32x4_t acc = {0.0f, 0.0f, 0.0f, 0.0f};
+    for (int c0 = ks * cpw; c0 < (ks + 1) * cpw; c0 += TM_U) {
+        float4 wa[TM_U];
+        float xb[TM_U][4];
+#pragma unroll
+        for (int u = 0; u < TM_U; ++u) {
+            const int ci = c0 + u;
+            wa[u] = *reinterpret_cast<const float4*>(wrow + ci * 16);
+            const bool plane = ci < n_img;
+            const float* p = plane ? ib + (long)ci * HW : sb + ci;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) xb[u][t] = p[plane ? cx[t] : 0] * fm[t];
+        }
+#pragma unroll
+        for (int u = 0; u < TM_U; ++u) {
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[u].x, xb[u][0], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[u].y, xb[u][1], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[u].z, xb[u][2], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[u].w, xb[u][3], acc, 0, 0, 0);
+        }
+    }
+    if (KS > 1) {
+        if (ks != 0) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) part[((ks - 1) * 4 + e) * 64 + lane] = acc[e];
+        }
+        __syncthreads();
+        if (ks != 0) return;
+        for (int k = 1; k < KS; ++k)                            // fixed order: deterministic
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[e] += part[((k - 1) * 4 + e) * 64 + lane];
+    }
+    if (!live) return;
+    // D[row = co][col = px]: lane holds px = col and rows 4 * q + e
+    float* ob = out + (((long)g * B + b) * Cout + co0 + 4 * q) * Ho * Ho + r;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) ob[(long)e * Ho * Ho] = lrelu02(acc[e] + bias[g * Cout + co0 + 4 * q + e]);
+}
+
 // ---- fc1 of every head: hidden[b][h][j] = lrelu(b1[h][j] + feats[src(h)][b][:] . w1[h][j][:]) ------------
 // Workgroup = 4 neurons of one head x the whole batch, ONE WAVE PER NEURON: a lane strides the 4096-long dot product
 // (16 float4 of the weight row, re-used for every image of the batch), the wave reduces with shuffles and lane 0
@@ -291,6 +379,15 @@ __global__ __launch_bounds__(1024) void k_finish(adaisp_policy_finish_args a) {
 hipError_t launch_policy_conv(const float* in, const float* states, int n_state, const float* w, const float* bias,
                               float* out, int G, int B, int Cin, int Hin, int Cout, hipStream_t s) {
     const int Ho = Hin / 2;
+    {   // matrix-core form: one round of TM_U input channels per wave where 16 waves suffice
+        int ks = Cin / TM_U;
+        if (ks > 16) ks = 16;
+        if (ks >= 1 && Cout % 16 == 0 && Cin % (ks * TM_U) == 0 && (!states || Cin >= 3)) {
+            dim3 grid((B * Ho * Ho + 15) / 16, Cout / 16, G);
+            hipLaunchKernelGGL(k_trunk_mfma, grid, dim3(64 * ks), 0, s, in, states, n_state, w, bias, out, B, Cin, Hin, Cout, ks);
+            return hipGetLastError();
+        }
+    }
     int KS = Cin / 8;                                   // ~8 input channels per wave
     if (KS < 1) KS = 1;
     if (KS > 16) KS = 16;
