@@ -16,6 +16,7 @@ OP_CONTRAST, OP_SATPLUS, OP_WNB, OP_WB, OP_USM, OP_SHARPEN_V2, OP_COLOR = 6, 7, 
 MAX_PARAMS = 24
 CLIP01 = 1
 NLM_EXACT = 2      # NLM patch sums in the reference's running-sum order (slower); default is the separable kernel
+NLM_SEP_V1 = 4     # the compiler-scheduled form of the separable kernel (cross-check / measurement)
 ABI_VERSION = 3
 
 EXPORTS = ("adaisp_forward", "adaisp_process", "adaisp_backward_params", "adaisp_pool64", "adaisp_demosaic", "adaisp_num_params",
@@ -82,7 +83,7 @@ def _img_shape(img):
     return int(img.shape[0]), int(img.shape[2]), int(img.shape[3])
 
 
-def process(op, img, params, clip=False, out=None, nlm_exact=False):
+def process(op, img, params, clip=False, out=None, nlm_exact=False, nlm_v1=False):
     """adaisp_process: one host-known op for the whole batch. params [B,n] (regressed)."""
     L = load()
     img = _dev_f32(img, "img")
@@ -92,7 +93,8 @@ def process(op, img, params, clip=False, out=None, nlm_exact=False):
         out = torch.empty_like(img)
     with torch.cuda.device(img.device):
         rc = L.adaisp_process(int(op), img.data_ptr(), out.data_ptr(), params.data_ptr(), params.shape[1], B, H, W,
-                              (CLIP01 if clip else 0) | (NLM_EXACT if nlm_exact else 0), _stream())
+                              (CLIP01 if clip else 0) | (NLM_EXACT if nlm_exact else 0) | (NLM_SEP_V1 if nlm_v1 else 0),
+                              _stream())
     _check(rc, "adaisp_process")
     return out
 

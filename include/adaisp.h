@@ -51,6 +51,7 @@ enum adaisp_op {
 #define ADAISP_CLIP01 1u /* clamp the result to [0,1]: Filter.forward's final clip, isp/filters.py:125 */
 #define ADAISP_NLM_EXACT 2u /* NLM: add the 25 patch terms in the reference's single running-sum order
                                (isp/denoise.py:60-63) instead of the default 5x5 separable association; ~3.5x slower */
+#define ADAISP_NLM_SEP_V1 4u /* NLM: the compiler-scheduled form of the separable kernel (measurement / cross-check) */
 
 /* error codes */
 #define ADAISP_OK          0
