@@ -6,7 +6,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from adaptiveisp_amd.yolo import _lib
 L = _lib.load()
 B = 8
-for (H, W, cin, cout, k, s) in [(92, 160, 128, 256, 3, 1), (46, 80, 256, 512, 3, 1), (92, 160, 256, 128, 1, 1), (23, 40, 512, 1024, 3, 1), (184, 320, 64, 128, 3, 1), (368, 640, 32, 64, 3, 1), (736, 1280, 32, 64, 3, 2), (368, 640, 64, 128, 3, 2)]:
+SHAPES = [tuple(int(v) for v in t.split(',')) for t in sys.argv[2].split(';')] if len(sys.argv) > 2 else None
+for (H, W, cin, cout, k, s) in SHAPES or [(92, 160, 128, 256, 3, 1), (46, 80, 256, 512, 3, 1), (92, 160, 256, 128, 1, 1), (23, 40, 512, 1024, 3, 1), (184, 320, 64, 128, 3, 1), (368, 640, 32, 64, 3, 1), (736, 1280, 32, 64, 3, 2), (368, 640, 64, 128, 3, 2)]:
     g = torch.Generator(device="cpu").manual_seed(0)
     x = torch.randn(B, H, W, cin, generator=g).to(torch.bfloat16).cuda()
     w = (torch.randn(cout, k, k, cin, generator=g) / (k * k * cin) ** 0.5).to(torch.bfloat16).cuda()
