@@ -233,14 +233,24 @@ __global__ __launch_bounds__(256) void k_fc1(const float* __restrict__ feats, co
         float acc[FC_MAXB];
 #pragma unroll
         for (int i = 0; i < FC_MAXB; ++i) acc[i] = 0.0f;
-        for (int k = lane; k < nq; k += 64) {
-            const float4 wv = wr[k];
+        auto dot = [&](int k, const float4 wv) {
 #pragma unroll
             for (int i = 0; i < FC_MAXB; ++i) {
                 const int row = b0 + (i < nb ? i : nb - 1);       // always a valid row: no divergent loads; extra sums unused
                 const float4 f = fb[(long)row * nq + k];
                 acc[i] = fmaf(wv.x, f.x, fmaf(wv.y, f.y, fmaf(wv.z, f.z, fmaf(wv.w, f.w, acc[i]))));
             }
+        };
+        if (nq == 16 * 64) {
+            // the trunk's 4096 features: the 16 weight loads of the row (HBM misses, ~2 us each when taken one by one)
+            // are issued before the first FMA
+            float4 wv[16];
+#pragma unroll
+            for (int it = 0; it < 16; ++it) wv[it] = wr[lane + 64 * it];
+#pragma unroll
+            for (int it = 0; it < 16; ++it) dot(lane + 64 * it, wv[it]);
+        } else {
+            for (int k = lane; k < nq; k += 64) dot(k, wr[k]);
         }
 #pragma unroll
         for (int i = 0; i < FC_MAXB; ++i) {
@@ -268,7 +278,50 @@ __global__ __launch_bounds__(1024) void k_finish(adaisp_policy_finish_args a) {
     // lanes stride the hidden dimension, shuffle reduction
     {
         const int lane = t & 63, wv = t >> 6;
-        for (int r = wv; r < a.num_rows + F; r += 16) {
+        const int nrows = a.num_rows + F;
+        constexpr int RPW = 6, KPL = 4;                 // rows per wave, hidden elements per lane held in registers
+        if (nrows <= 16 * RPW && HID <= 64 * KPL) {
+            // every load of the wave's rows is issued before the first use: two dependent rounds (row -> filter index,
+            // then weights and hidden activations) instead of two per row
+            int fidx[RPW];
+#pragma unroll
+            for (int i = 0; i < RPW; ++i) {
+                const int r = min(wv + 16 * i, nrows - 1);
+                fidx[i] = r >= a.num_rows ? F : a.row_filter[r];
+            }
+            float wv_[RPW][KPL], hv_[RPW][KPL];
+#pragma unroll
+            for (int i = 0; i < RPW; ++i) {
+                const int r = min(wv + 16 * i, nrows - 1);
+                const bool is_sel = r >= a.num_rows;
+                const float* wrow = is_sel ? a.w_sel + (long)(r - a.num_rows) * HID : a.w_filter + (long)r * HID;
+                const float* h = hb + (long)fidx[i] * HID;
+#pragma unroll
+                for (int j = 0; j < KPL; ++j) {
+                    const int k = min(lane + 64 * j, HID - 1);
+                    wv_[i][j] = wrow[k];
+                    hv_[i][j] = h[k];
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < RPW; ++i) {
+                const int r = wv + 16 * i;
+                float acc = 0.0f;
+#pragma unroll
+                for (int j = 0; j < KPL; ++j)
+                    if (lane + 64 * j < HID) acc = fmaf(wv_[i][j], hv_[i][j], acc);     // same order as the loop form
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+                if (lane == 0 && r < nrows) {
+                    const bool is_sel = r >= a.num_rows;
+                    const int rr = is_sel ? r - a.num_rows : r;
+                    acc += is_sel ? a.b_sel[rr] : a.b_filter[rr];
+                    if (is_sel) logit[rr] = acc;
+                    else raw[fidx[i] * ADAISP_MAX_PARAMS + a.row_slot[rr]] = acc;
+                }
+            }
+        } else
+        for (int r = wv; r < nrows; r += 16) {
             const bool is_sel = r >= a.num_rows;
             const int rr = is_sel ? r - a.num_rows : r;
             const int f = is_sel ? F : a.row_filter[rr];
@@ -312,21 +365,43 @@ __global__ __launch_bounds__(1024) void k_finish(adaisp_policy_finish_args a) {
     }
 
     // selector: softmax + 1e-37, exploration mix, renormalise, entropy, sample / argmax / forced (agent.py:126-149)
-    if (t == 0) {
+    // The transcendental parts (10 expf, 10 logf, 20 divisions: ~3k dependent instructions when one thread does them)
+    // run one filter per lane; every SUM stays a sequential loop of one thread in the reference's order, so the values
+    // are bit-identical to the single-thread form.
+    __shared__ float sc[4];
+    __shared__ float entl[ADAISP_POLICY_MAX_FILTERS];
+    if (t < F) {
         float mx = logit[0];
         for (int k = 1; k < F; ++k) mx = fmaxf(mx, logit[k]);
+        pdf[t] = expf(logit[t] - mx);
+    }
+    __syncthreads();
+    if (t == 0) {
         float sum = 0.0f;
-        for (int k = 0; k < F; ++k) { pdf[k] = expf(logit[k] - mx); sum += pdf[k]; }
+        for (int k = 0; k < F; ++k) sum += pdf[k];
+        sc[0] = sum;
+    }
+    __syncthreads();
+    if (t < F) {
+        float p = pdf[t] / sc[0] + 1e-37f;
+        pdf[t] = p * a.one_minus_exploration + a.exploration_over_f;
+    }
+    __syncthreads();
+    if (t == 0) {
         float tot = 0.0f;
-        for (int k = 0; k < F; ++k) {
-            float p = pdf[k] / sum + 1e-37f;
-            p = p * a.one_minus_exploration + a.exploration_over_f;
-            pdf[k] = p;
-            tot += p;
-        }
-        tot += 1e-30f;
+        for (int k = 0; k < F; ++k) tot += pdf[k];
+        sc[1] = tot + 1e-30f;
+    }
+    __syncthreads();
+    if (t < F) {
+        const float p = pdf[t] / sc[1];
+        pdf[t] = p;
+        entl[t] = -p * logf(p);
+    }
+    __syncthreads();
+    if (t == 0) {
         float ent = 0.0f;
-        for (int k = 0; k < F; ++k) { pdf[k] = pdf[k] / tot; ent += -pdf[k] * logf(pdf[k]); }
+        for (int k = 0; k < F; ++k) ent += entl[k];
         // pdf_sample: pdf / (sum + 1e-36); index = #{k : cdf_exclusive_k < u} - 1
         float s2 = 0.0f;
         for (int k = 0; k < F; ++k) s2 += pdf[k];
