@@ -180,9 +180,117 @@ __global__ __launch_bounds__(256) void k_detect_decode(const unsigned short* __r
     }
 }
 
+// Tiled form (default when the layout allows it). The element-per-lane kernel above spends ~40 of its ~70
+// instructions per element on two integer divisions and stores 4 bytes per lane: 90 us for the 92x160 map. Here a
+// workgroup takes 64 cells of one image. Their raw rows (all anchors, raw_cs bf16 each) are one contiguous block: read
+// with 16-byte loads and scattered into LDS in OUTPUT order ([anchor][cell][channel], bf16), so that each anchor's
+// 64 x no outputs — one contiguous run of the prediction tensor — are produced four at a time from one ds_read_b64
+// with no index arithmetic: sigmoid, float4 store. The four box channels of every cell are computed first (one thread
+// per cell and anchor, fp32 into LDS) and patched into the 7-in-85 runs that touch them.
+constexpr int DC = 32;                          // cells per workgroup (18 KB of LDS: 8 workgroups per CU)
+__global__ __launch_bounds__(256) void k_detect_decode_tiled(const unsigned short* __restrict__ raw, int raw_cs,
+                                                             float* __restrict__ pred, int pred_rows, int row_offset,
+                                                             const float* __restrict__ anchors_px, float det_stride,
+                                                             int ny, int nx, int na, int no) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
+    unsigned short* l16 = reinterpret_cast<unsigned short*>(dsm);          // [na][DC][no]
+    typedef float f32x4v __attribute__((ext_vector_type(4)));
+    const int ncell = ny * nx;
+    const int cell0 = blockIdx.x * DC;
+    const int nc = min(DC, ncell - cell0);
+    const long b = blockIdx.y;
+    const int used = na * no;                                  // bf16 channels per cell that matter
+    const int cpr = (used + 7) / 8;                            // 16-byte chunks per row
+    const float inv_cpr = 1.0f / (float)cpr, inv_no = 1.0f / (float)no, inv_nx = 1.0f / (float)nx;
+    const unsigned char* src = reinterpret_cast<const unsigned char*>(raw + (b * ncell + cell0) * raw_cs);
+    // four 16-byte loads in flight per thread before the first one is used (the raw maps were streamed out by the
+    // head convs: every load is an HBM round trip, and one per loop trip made this phase 8 serial round trips)
+    for (int q0 = threadIdx.x; q0 < nc * cpr; q0 += 4 * 256) {
+        uint4 vv[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int q = min(q0 + i * 256, nc * cpr - 1);
+            const int r = (int)(((float)q + 0.5f) * inv_cpr), c0 = (q - r * cpr) * 8;    // q / cpr by reciprocal (q < 2^16)
+            vv[i] = *reinterpret_cast<const uint4*>(src + (long)r * raw_cs * 2 + c0 * 2);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int q = q0 + i * 256;
+            if (q >= nc * cpr) break;
+            const int r = (int)(((float)q + 0.5f) * inv_cpr), c0 = (q - r * cpr) * 8;
+            const unsigned w[4] = {vv[i].x, vv[i].y, vv[i].z, vv[i].w};
+            int an = (int)(((float)c0 + 0.5f) * inv_no);
+            int j = c0 - an * no;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                if (c0 + u < used) l16[(an * DC + r) * no + j] = (unsigned short)(w[u >> 1] >> ((u & 1) * 16));
+                ++j;
+                const int wr = j == no;
+                j = wr ? 0 : j; an += wr;
+            }
+        }
+    }
+    __syncthreads();
+    // box channels (x, y, w, h) of every cell and anchor -> fp32 in LDS, one thread each; the main pass patches them in
+    float* boxf = reinterpret_cast<float*>(dsm + (size_t)na * DC * no * 2);        // [na][DC][4]
+    for (int idx = threadIdx.x; idx < na * nc; idx += 256) {
+        const int an = (int)(((float)idx + 0.5f) / (float)nc), cl = idx - an * nc;
+        const int cell = cell0 + cl;
+        const int y = (int)(((float)cell + 0.5f) * inv_nx), x = cell - y * nx;
+        const unsigned short* lp = l16 + (an * DC + cl) * no;
+        float sg[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) sg[u] = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504088896341f * bf2f(lp[u])));
+        float* bo = boxf + (an * DC + cl) * 4;
+        bo[0] = (sg[0] * 2.0f + ((float)x - 0.5f)) * det_stride;
+        bo[1] = (sg[1] * 2.0f + ((float)y - 0.5f)) * det_stride;
+        bo[2] = (sg[2] * 2.0f) * (sg[2] * 2.0f) * anchors_px[2 * an];
+        bo[3] = (sg[3] * 2.0f) * (sg[3] * 2.0f) * anchors_px[2 * an + 1];
+    }
+    __syncthreads();
+    const int total = nc * no;                                 // a multiple of 4 (launcher: DC * no and ny * nx * no are)
+    for (int an = 0; an < na; ++an) {
+        float* dst = pred + (b * pred_rows + row_offset + (long)an * ncell + cell0) * no;     // 16-byte aligned (launcher)
+        const unsigned char* la = dsm + (long)an * DC * no * 2;
+        for (int e4 = threadIdx.x; 4 * e4 < total; e4 += 256) {
+            const uint2 p = *reinterpret_cast<const uint2*>(la + 8 * e4);
+            const float t[4] = {__uint_as_float(p.x << 16), __uint_as_float(p.x & 0xFFFF0000u),
+                                __uint_as_float(p.y << 16), __uint_as_float(p.y & 0xFFFF0000u)};
+            f32x4v o;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) o[u] = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504088896341f * t[u]));
+            const int cl = (int)(((float)(4 * e4) + 0.5f) * inv_no), j0 = 4 * e4 - cl * no;
+            if (j0 < 4 || j0 + 3 >= no) {                      // 7 of every `no` lanes: the run touches box channels
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int wrp = j0 + u >= no;
+                    const int j = j0 + u - (wrp ? no : 0);
+                    if (j < 4) o[u] = boxf[(an * DC + cl + wrp) * 4 + j];
+                }
+            }
+            __builtin_nontemporal_store(o, reinterpret_cast<f32x4v*>(dst + 4 * e4));
+        }
+    }
+}
+
 hipError_t launch_detect_decode(const void* raw, int raw_cs, float* pred, int pred_rows, int row_offset,
                                 const float* anchors_px, float det_stride, int B, int ny, int nx, int na, int no,
                                 hipStream_t s) {
+    {
+        // tiled form: raw rows 16-byte aligned, every anchor's output run 16-byte aligned (no is odd for COCO, so the
+        // row counts in front of it have to be multiples of 4), tile within the static LDS limit
+        const int cpr = (na * no + 7) / 8;
+        const size_t lds = (size_t)na * DC * no * 2 + (size_t)na * DC * 16;     // bf16 tile + fp32 box values
+        const bool rows_ok = raw_cs % 8 == 0 && cpr * 8 <= raw_cs && (reinterpret_cast<uintptr_t>(raw) & 15) == 0;
+        const bool out_ok = (reinterpret_cast<uintptr_t>(pred) & 15) == 0 && ((long)pred_rows * no) % 4 == 0 &&
+                            ((long)row_offset * no) % 4 == 0 && ((long)ny * nx * no) % 4 == 0 && (DC * no) % 4 == 0;
+        if (rows_ok && out_ok && lds <= 64 * 1024 && DC * cpr < 65536 && na * DC < 65536) {
+            hipLaunchKernelGGL(k_detect_decode_tiled, dim3((ny * nx + DC - 1) / DC, B), dim3(256), lds, s,
+                               static_cast<const unsigned short*>(raw), raw_cs, pred, pred_rows, row_offset, anchors_px,
+                               det_stride, ny, nx, na, no);
+            return hipGetLastError();
+        }
+    }
     const int per_map = ny * nx * no;
     int bx = (per_map + 255) / 256;
     if (bx > 1024) bx = 1024;

@@ -111,6 +111,28 @@ def test_stem_upsample_decode():
     assert not pred[:, :20].any() and not pred[:, 20 + na * ny * nx:].any()
 
 
+@pytest.mark.parametrize("ny,nx,rows,off", [(9, 12, 400, 40), (23, 40, 2800, 36), (5, 7, 120, 3), (16, 16, 768, 0)])
+def test_detect_decode_tiled_and_fallback(ny, nx, rows, off):
+    """Detect.forward eval branch (yolov3/models/yolo.py:56-76): the tiled kernel (64 cells per workgroup, float4 stores;
+    partial last tile) and the element-per-lane fallback (5x7: output runs not 16-byte aligned)."""
+    from adaptiveisp_amd.yolo import _lib
+    L = _lib.load()
+    B, na, no = 2, 3, 85
+    g = torch.Generator().manual_seed(ny * 100 + nx)
+    raw = (torch.randn(B, ny, nx, 256, generator=g) * 2).to(torch.bfloat16).to(DEV)
+    anc = torch.tensor([[10., 13.], [16., 30.], [33., 23.]], device=DEV)
+    pred = torch.full((B, rows, no), -7.0, device=DEV)
+    _lib.check(L.adayolo_detect_decode(ctypes.c_void_p(raw.data_ptr()), 256, ctypes.c_void_p(pred.data_ptr()), rows, off,
+                                       ctypes.c_void_p(anc.data_ptr()), 16.0, B, ny, nx, na, no, _lib.stream_ptr()), "dec")
+    t = raw[..., :255].float().view(B, ny, nx, na, no).permute(0, 3, 1, 2, 4).sigmoid()
+    yv, xv = torch.meshgrid(torch.arange(ny, device=DEV).float(), torch.arange(nx, device=DEV).float(), indexing="ij")
+    grid = torch.stack((xv, yv), 2).view(1, 1, ny, nx, 2) - 0.5
+    ref = torch.cat(((t[..., :2] * 2 + grid) * 16.0, (t[..., 2:4] * 2) ** 2 * anc.view(1, na, 1, 1, 2), t[..., 4:]), -1)
+    n = na * ny * nx
+    torch.testing.assert_close(pred[:, off:off + n], ref.reshape(B, -1, no), rtol=1e-5, atol=1e-5)
+    assert (pred[:, :off] == -7.0).all() and (pred[:, off + n:] == -7.0).all()
+
+
 @pytest.mark.parametrize("shape", [(1, 64, 96), (2, 80, 96)])
 def test_engine_vs_reference_model(golden, shape):
     from _synth import synth_yolo_state_dict, test_image
