@@ -444,19 +444,32 @@ __global__ __launch_bounds__(kThreads) void k_nlm_fwd(const float* __restrict__ 
 
     float* y2f = reinterpret_cast<float*>(y2);
     float* cb2f = reinterpret_cast<float*>(cb2);
-    for (int q = tid; q < YROWS * SP; q += kThreads) {
-        const int ly = q / SP, lx = q - ly * SP;
-        const int gy = wrap(y0 + ly - HY, H), gx = wrap(x0 - 2 - SR + lx, W);
-        const long g = (long)gy * W + gx;
-        const float r = clamp01(in[g]), gg = clamp01(in[g + plane]), bb = clamp01(in[g + 2 * plane]);
-        const float yv = (0.299f * r + 0.587f * gg) + 0.114f * bb;
-        if (ly < Y2ROWS) y2f[(ly * SP + lx) * 2] = yv;
-        if (ly >= HALF) y2f[((ly - HALF) * SP + lx) * 2 + 1] = yv;
-        const int cy = ly - PR;
-        if (cy >= 0 && cy < CROWS) {
-            crg[cy * SP + lx] = v2f{r, gg};
-            if (cy < B2ROWS) cb2f[(cy * SP + lx) * 2] = bb;
-            if (cy >= HALF) cb2f[((cy - HALF) * SP + lx) * 2 + 1] = bb;
+    // staging: 4 positions = 12 loads in flight per thread (one position per trip is 14 serial memory round trips)
+    for (int q0 = tid; q0 < YROWS * SP; q0 += 4 * kThreads) {
+        float rr[4], gg4[4], bb4[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int q = min(q0 + i * kThreads, YROWS * SP - 1);
+            const int ly = q / SP, lx = q - ly * SP;
+            const int gy = wrap(y0 + ly - HY, H), gx = wrap(x0 - 2 - SR + lx, W);
+            const long g = (long)gy * W + gx;
+            rr[i] = in[g]; gg4[i] = in[g + plane]; bb4[i] = in[g + 2 * plane];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int q = q0 + i * kThreads;
+            if (q >= YROWS * SP) break;
+            const int ly = q / SP, lx = q - ly * SP;
+            const float r = clamp01(rr[i]), gg = clamp01(gg4[i]), bb = clamp01(bb4[i]);
+            const float yv = (0.299f * r + 0.587f * gg) + 0.114f * bb;
+            if (ly < Y2ROWS) y2f[(ly * SP + lx) * 2] = yv;
+            if (ly >= HALF) y2f[((ly - HALF) * SP + lx) * 2 + 1] = yv;
+            const int cy = ly - PR;
+            if (cy >= 0 && cy < CROWS) {
+                crg[cy * SP + lx] = v2f{r, gg};
+                if (cy < B2ROWS) cb2f[(cy * SP + lx) * 2] = bb;
+                if (cy >= HALF) cb2f[((cy - HALF) * SP + lx) * 2 + 1] = bb;
+            }
         }
     }
     __syncthreads();
