@@ -68,16 +68,30 @@ __global__ __launch_bounds__(256) void k_stem_down(const float* __restrict__ img
     // ---- A: image patch (frame rows fy0-1 .. , cols fx0-1 ..)
     const long plane = (long)H * W;
     const float* src = img + (long)b * 3 * plane;
-    for (int i = tid; i < 3 * IH * IW; i += 256) {
-        const int c = i / (IH * IW), r = i - c * (IH * IW);
-        const int ly = r / IW, lx = r - ly * IW;
-        const int gy = fy0 - 1 + ly, gx = fx0 - 1 + lx;
-        float v = 0.0f;                                   // the stem conv's zero padding outside the letterboxed frame
-        if (gy >= 0 && gy < Hp && gx >= 0 && gx < W) {
+    // all 8 loads of a thread are issued before the first LDS write: clamped (always legal) addresses, pinned by an
+    // empty asm, then the letterbox value / zero padding by select (a select straight on the load is compiled into a
+    // branch around it and serialises eight memory round trips)
+    {
+        constexpr int NI = (3 * IH * IW + 255) / 256;
+        float v[NI], m[NI], padc[NI];
+#pragma unroll
+        for (int it = 0; it < NI; ++it) {
+            const int i = min(tid + 256 * it, 3 * IH * IW - 1);
+            const int c = i / (IH * IW), r = i - c * (IH * IW);
+            const int ly = r / IW, lx = r - ly * IW;
+            const int gy = fy0 - 1 + ly, gx = fx0 - 1 + lx;
             const int sy = gy - pad_top;
-            v = (sy >= 0 && sy < H) ? src[c * plane + (long)sy * W + gx] : pad_value;
+            const bool inframe = gy >= 0 && gy < Hp && gx >= 0 && gx < W;
+            const bool inimg = inframe && sy >= 0 && sy < H;
+            v[it] = src[c * plane + (long)min(max(sy, 0), H - 1) * W + min(max(gx, 0), W - 1)];
+            m[it] = inimg ? 1.0f : 0.0f;
+            padc[it] = (inframe && !inimg) ? pad_value : 0.0f;   // zero outside the letterboxed frame (the conv's padding)
         }
-        tile[i] = v;
+#pragma unroll
+        for (int it = 0; it < NI; ++it) asm volatile("" : "+v"(v[it]));      // the loads above stay unconditional
+#pragma unroll
+        for (int it = 0; it < NI; ++it)
+            if (tid + 256 * it < 3 * IH * IW) tile[tid + 256 * it] = m[it] != 0.0f ? v[it] : padc[it];
     }
 
     // ---- stem weights as two MFMA A fragments (rows permuted: row 4g+i of fragment t = channel 8g + 4t + i)
