@@ -178,6 +178,13 @@ __global__ __launch_bounds__(512) void k_conv_pp(const ConvArgs a) {
         const int i = 2 * h + j;
         dma16(sel(live, wrow[i] + p.woff, zaddr), buf + wlds[i]);
     };
+    // the same two pieces with the source address computed ahead of time (in the load section: ~10 SALU/VALU
+    // instructions per piece that otherwise sit between two MFMAs of the issuing wave and overrun the 32-cycle slot)
+    auto addr_a1 = [&](int h, int j, const KPos& p, bool live) {
+        const int i = 2 * h + j;
+        return sel(live && ((amask[i] >> p.tap) & 1u), arow[i] + p.aoff, zaddr);
+    };
+    auto addr_w1 = [&](int h, int j, const KPos& p, bool live) { return sel(live, wrow[2 * h + j] + p.woff, zaddr); };
     auto stage_a = [&](int h, unsigned char* buf, const KPos& p, bool live) { stage_a1(h, 0, buf, p, live); stage_a1(h, 1, buf, p, live); };
     auto stage_w = [&](int h, unsigned char* buf, const KPos& p, bool live) { stage_w1(h, 0, buf, p, live); stage_w1(h, 1, buf, p, live); };
 
@@ -231,7 +238,8 @@ __global__ __launch_bounds__(512) void k_conv_pp(const ConvArgs a) {
     };
     // MFMA section of one phase: 8 MFMAs with the phase's two LDS-DMA pieces issued in their shadow, then the counted
     // wait that retires the half-tile issued three phases ago (readable from the load section two phases on)
-    auto mma = [&](int ni, int half, const bf16x8 (&w)[4], auto&& stage) {
+    auto mma = [&](int ni, int half, const bf16x8 (&w)[4], unsigned long long g0, unsigned char* d0, unsigned long long g1,
+                   unsigned char* d1) {
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
@@ -242,7 +250,7 @@ __global__ __launch_bounds__(512) void k_conv_pp(const ConvArgs a) {
                 const int n = 2 * kk + mi;
                 if (n == 0 || n == 3) {              // one DMA instruction behind the 1st and the 4th MFMA
                     __builtin_amdgcn_sched_barrier(0);
-                    stage(n == 0 ? 0 : 1);
+                    if (ABL != 5) dma16(n == 0 ? g0 : g1, n == 0 ? d0 : d1);
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
@@ -259,30 +267,35 @@ __global__ __launch_bounds__(512) void k_conv_pp(const ConvArgs a) {
     // set whose W1 died in P3)
     auto ktile = [&](unsigned char* cur, unsigned char* oth, int t, bf16x8 (&w0)[4], bf16x8 (&w1)[4]) {
         const bool live1 = (ABL != 1 && ABL != 5) && t + 1 < nK, live2 = (ABL != 1 && ABL != 5) && t + 2 < nK;
-        // P1: quadrant (px half 0, ch half 0)
-        auto s1 = [&](int j) { stage_w1(1, j, oth, p1, live1); };
-        auto s2 = [&](int j) { stage_a1(1, j, oth, p1, live1); };
-        auto s3 = [&](int j) { stage_w1(0, j, cur, p2, live2); };
-        auto s4 = [&](int j) { stage_a1(0, j, cur, p2, live2); };
+        // P1: quadrant (px half 0, ch half 0); stages W1(t+1)
+        unsigned long long g0, g1;
         read_a(cur, 0);
+        g0 = addr_w1(1, 0, p1, live1); g1 = addr_w1(1, 1, p1, live1);
+        asm volatile("" : "+v"(g0), "+v"(g1));          // (pins the address math to this side of the barrier)
         barrier();
-        mma(0, 0, w0, s1);
+        mma(0, 0, w0, g0, oth + wlds[2], g1, oth + wlds[3]);
         barrier();
-        // P2: (px 0, ch 1)
+        // P2: (px 0, ch 1); stages A1(t+1)
         read_w(cur, 1, w1);
+        g0 = addr_a1(1, 0, p1, live1); g1 = addr_a1(1, 1, p1, live1);
+        asm volatile("" : "+v"(g0), "+v"(g1));
         barrier();
-        mma(1, 0, w1, s2);
+        mma(1, 0, w1, g0, oth + alds[2], g1, oth + alds[3]);
         barrier();
-        // P3: (px 1, ch 1)
+        // P3: (px 1, ch 1); stages W0(t+2)
         advance(p2);
         read_a(cur, 1);
+        g0 = addr_w1(0, 0, p2, live2); g1 = addr_w1(0, 1, p2, live2);
+        asm volatile("" : "+v"(g0), "+v"(g1));
         barrier();
-        mma(1, 1, w1, s3);
+        mma(1, 1, w1, g0, cur + wlds[0], g1, cur + wlds[1]);
         barrier();
-        // P4: (px 1, ch 0); the load section fetches W0 of the NEXT k-tile
+        // P4: (px 1, ch 0); the load section fetches W0 of the NEXT k-tile; stages A0(t+2)
         read_w(oth, 0, w1);
+        g0 = addr_a1(0, 0, p2, live2); g1 = addr_a1(0, 1, p2, live2);
+        asm volatile("" : "+v"(g0), "+v"(g1));
         barrier();
-        mma(0, 1, w0, s4);
+        mma(0, 1, w0, g0, cur + alds[0], g1, cur + alds[1]);
         barrier();
         p1 = p2;
     };

@@ -203,7 +203,9 @@ __global__ __launch_bounds__(512) void k_conv_pp128(const ConvArgs a) {
             w[kk] = *reinterpret_cast<const bf16x8*>(buf + wbase + ni * 32 * kRow + koff[kk]);
     };
     // MFMA section: 8 MFMAs, the phase's DMA instructions issued behind the 1st, 3rd, 5th and 7th, then the counted wait
-    auto mma = [&](int ni, const bf16x8 (&w)[4], auto&& stage, int npieces) {
+    // source addresses are computed in the load section in front (see yolo_conv_pp.hip): between two MFMAs only
+    // s_mov m0 + the DMA instruction remain
+    auto mma = [&](int ni, const bf16x8 (&w)[4], const unsigned long long (&g)[4], unsigned char* const (&d)[4], int npieces) {
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk)
@@ -213,7 +215,7 @@ __global__ __launch_bounds__(512) void k_conv_pp128(const ConvArgs a) {
                 const int n = 2 * kk + mi;
                 if ((n & 1) == 0 && (n >> 1) < npieces) {
                     __builtin_amdgcn_sched_barrier(0);
-                    stage(n >> 1);
+                    if (ABL != 5) dma16(g[n >> 1], d[n >> 1]);
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
@@ -229,17 +231,33 @@ __global__ __launch_bounds__(512) void k_conv_pp128(const ConvArgs a) {
                      bf16x8 (&wnx)[4]) {
         const bool live2 = ABL != 5 && t + 2 < nK, live3 = ABL != 5 && t + 3 < nK;
         advance(p3);                                      // -> k-tile t+3
-        // P1: channel fragment 0
+        // P1: channel fragment 0; stages W1(t+2), W0(t+3)
         read_a(b0);
-        barrier();
-        mma(0, w0, [&](int j) { if (j == 0) stage_w1(1, b2, p2, live2); else stage_w1(0, b0, p3, live3); }, 2);
+        {
+            unsigned long long g[4] = {sel(live2, wrow[1] + p2.woff, zaddr), sel(live3, wrow[0] + p3.woff, zaddr), 0, 0};
+            unsigned char* const d[4] = {b2 + wlds0 + 32 * kRow, b0 + wlds0, nullptr, nullptr};
+            asm volatile("" : "+v"(g[0]), "+v"(g[1]));
+            barrier();
+            mma(0, w0, g, d, 2);
+        }
         wait_vm<8>();
         barrier();
-        // P2: channel fragment 1; the load section also fetches W0 of the NEXT k-tile
+        // P2: channel fragment 1; the load section also fetches W0 of the NEXT k-tile; stages A(t+3)
         read_w(b0, 1, w1);
         read_w(b1, 0, wnx);
-        barrier();
-        mma(1, w1, [&](int j) { stage_a1(j, b0, p3, live3); }, 4);
+        {
+            unsigned long long g[4];
+            unsigned char* d[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                g[j] = sel(live3 && ((amask[j] >> p3.tap) & 1u), arow[j] + p3.aoff, zaddr);
+                d[j] = b0 + alds0 + j * 8 * kRow;
+            }
+            asm volatile("" : "+v"(g[0]), "+v"(g[1]), "+v"(g[2]), "+v"(g[3]));
+            barrier();
+            unsigned char* const dc[4] = {d[0], d[1], d[2], d[3]};
+            mma(1, w1, g, dc, 4);
+        }
         wait_vm<10>();
         barrier();
         p2 = p3;
