@@ -6,6 +6,7 @@
 // weight taps of its output channels, then runs the 9 x Cin/16 MFMA steps back to back from LDS and stores.
 // Several workgroups per CU hide the single load latency. HBM traffic = input once (+halo) + output once.
 #include "yolo_internal.h"
+#include <type_traits>
 
 namespace adayolo {
 namespace smallk {
@@ -153,26 +154,26 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv3x3_small(const ConvArgs a
     __syncthreads();                                       // all fragment reads done: LDS becomes the output tile
 
     unsigned short* Cs = reinterpret_cast<unsigned short*>(smem);
+    auto convert = [&](auto silu_tag) {                     // compile-time activation, packed fp32 math (yolo_internal.h)
+        constexpr bool kSilu = decltype(silu_tag)::value;
 #pragma unroll
-    for (int ni = 0; ni < NI; ++ni) {
+        for (int ni = 0; ni < NI; ++ni) {
 #pragma unroll
-        for (int qd = 0; qd < 4; ++qd) {
-            const int nl = wn * TN + ni * 32 + 8 * qd + 4 * (lane >> 5);
-            const float4 b4 = *reinterpret_cast<const float4*>(bias_s + nl);
-            const float bv[4] = {b4.x, b4.y, b4.z, b4.w};
+            for (int qd = 0; qd < 4; ++qd) {
+                const int nl = wn * TN + ni * 32 + 8 * qd + 4 * (lane >> 5);
+                const float4 b4 = *reinterpret_cast<const float4*>(bias_s + nl);
 #pragma unroll
-            for (int mi = 0; mi < MI; ++mi) {
-                float v[4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    v[i] = acc[ni][mi][4 * qd + i] + bv[i];
-                    if (a.act == ADAYOLO_ACT_SILU) v[i] = silu(v[i]);
+                for (int mi = 0; mi < MI; ++mi) {
+                    unsigned lo, hi;
+                    bias_act_pack4<kSilu>(acc[ni][mi][4 * qd], acc[ni][mi][4 * qd + 1], acc[ni][mi][4 * qd + 2], acc[ni][mi][4 * qd + 3], b4, lo, hi);
+                    const int ml = wm * TM + mi * 32 + (lane & 31);
+                    *reinterpret_cast<u32x2*>(Cs + ml * CP + nl) = u32x2{lo, hi};
                 }
-                const int ml = wm * TM + mi * 32 + (lane & 31);
-                *reinterpret_cast<u32x2*>(Cs + ml * CP + nl) = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
             }
         }
-    }
+    };
+    if (a.act == ADAYOLO_ACT_SILU) convert(std::true_type{});
+    else convert(std::false_type{});
     __syncthreads();
     constexpr int CPR = BN / 8;
     // fixed trip count -> fully unrolled, so all residual loads / LDS reads are in flight before the first store
@@ -192,7 +193,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv3x3_small(const ConvArgs a
                 v[j] = pack_bf16x2(lo, hi);
             }
         }
-        *reinterpret_cast<u32x4*>(a.out + m * a.out_cs + n) = v;
+        __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(a.out + m * a.out_cs + n));
     }
 }
 
