@@ -52,9 +52,12 @@ def train_iteration(cfg, agent, value, detector, loss_fn, imgs, z, states, label
     from . import dist as adist
     from .yolo.loss import batched_per_sample_loss as per_sample_loss
     (retouch, new_states, surrogate, penalty), _, _ = agent((imgs, z, states), progress)
+    from .yolo.loss import assign_labels
     with torch.no_grad():
-        l_in = per_sample_loss(loss_fn, detector(imgs), labels)
-    l_re = per_sample_loss(loss_fn, detector(retouch), labels)
+        p_in = detector(imgs)
+        assigned = assign_labels(loss_fn, p_in, labels)      # same labels, same map shapes for both batches
+        l_in = per_sample_loss(loss_fn, p_in, labels, assigned)
+    l_re = per_sample_loss(loss_fn, detector(retouch), labels, assigned)
     old_value = value(imgs, states)
     new_value = value(retouch, new_states)
     out = td_losses(cfg, l_in, l_re, penalty, surrogate, new_states, old_value, new_value,

@@ -123,7 +123,20 @@ def per_sample_loss(loss_fn, preds, labels):
     return torch.stack(rows).view(B, 1)
 
 
-def batched_per_sample_loss(loss_fn, preds, labels):
+def assign_labels(loss_fn, preds, labels):
+    """Target assignment of a labelled batch (depends on the labels and the SHAPES of the head maps only, not on their
+    values): computed once per training iteration and shared by the loss of the input batch and of the retouched one."""
+    dev = preds[0].device
+    rows = []
+    for b, lb in enumerate(labels):
+        t = torch.as_tensor(lb).clone().to(dev).float()
+        t[:, 0] = b
+        rows.append(t)
+    targets = torch.cat(rows, 0) if rows else torch.zeros((0, 6), device=dev)
+    return loss_fn.assign(preds, targets)
+
+
+def batched_per_sample_loss(loss_fn, preds, labels, assigned=None):
     """The same [B,1] per-image losses as `per_sample_loss` in ONE batched pass (the reference loops over the samples
     in Python, train.py:184-196: 2*B loss evaluations of ~150 tiny launches each per iteration). Every reduction the
     per-sample call does over "its" batch of one becomes a per-image segment reduction here:
@@ -131,13 +144,12 @@ def batched_per_sample_loss(loss_fn, preds, labels):
       lobj_b = mean over image b's (na, ny, nx) cells of BCE, weighted by the layer balance."""
     dev = preds[0].device
     B = preds[0].shape[0]
-    rows = []
-    for b, lb in enumerate(labels):
-        t = torch.as_tensor(lb).clone().to(dev).float()
-        t[:, 0] = b
-        rows.append(t)
-    targets = torch.cat(rows, 0) if rows else torch.zeros((0, 6), device=dev)
-    assigned = loss_fn.assign(preds, targets)
+    if assigned is None:
+        assigned = assign_labels(loss_fn, preds, labels)
+    pw = getattr(loss_fn, "_pw_cache", None)                 # the two pos_weight scalars as device tensors, made once
+    if pw is None or pw[0].device != dev:
+        pw = (torch.tensor([loss_fn.hyp["cls_pw"]], device=dev), torch.tensor([loss_fn.hyp["obj_pw"]], device=dev))
+        loss_fn._pw_cache = pw
     lbox = torch.zeros(B, device=dev)
     lobj = torch.zeros(B, device=dev)
     lcls = torch.zeros(B, device=dev)
@@ -157,11 +169,9 @@ def batched_per_sample_loss(loss_fn, preds, labels):
             if loss_fn.nc > 1:
                 t = torch.full_like(pcls, loss_fn.cn)
                 t[range(n), m["cls"]] = loss_fn.cp
-                bce = F.binary_cross_entropy_with_logits(pcls, t, reduction="none",
-                                                         pos_weight=torch.tensor([loss_fn.hyp["cls_pw"]], device=dev))
+                bce = F.binary_cross_entropy_with_logits(pcls, t, reduction="none", pos_weight=pw[0])
                 lcls = lcls + torch.zeros(B, device=dev).index_add_(0, bidx, bce.sum(1)) * inv / loss_fn.nc
-        obj = F.binary_cross_entropy_with_logits(pi[..., 4], tobj, reduction="none",
-                                                 pos_weight=torch.tensor([loss_fn.hyp["obj_pw"]], device=dev))
+        obj = F.binary_cross_entropy_with_logits(pi[..., 4], tobj, reduction="none", pos_weight=pw[1])
         lobj = lobj + obj.mean(dim=(1, 2, 3)) * loss_fn.balance[i]
     total = lbox * loss_fn.hyp["box"] + lobj * loss_fn.hyp["obj"] + lcls * loss_fn.hyp["cls"]
     return total.view(B, 1)
