@@ -74,3 +74,10 @@ def test_batched_per_sample_loss_equals_the_loop(golden):
     gb = torch.autograd.grad(per_sample_loss(crit, preds4, labels4).sum(), preds4)
     for x, y in zip(ga, gb):
         assert torch.allclose(x, y, rtol=1e-4, atol=1e-7)
+    # the target assignment depends on labels and map shapes only: computed once (rl.train_iteration) and reused for a
+    # second batch of predictions, it gives the same losses as assigning inside each call
+    from adaptiveisp_amd.yolo.loss import assign_labels
+    shared = assign_labels(crit, preds4, labels4)
+    other = [torch.randn(p.shape, generator=gen) for p in preds4]
+    for pr in (preds4, other):
+        assert torch.equal(batched_per_sample_loss(crit, pr, labels4, shared), batched_per_sample_loss(crit, pr, labels4))
