@@ -18,7 +18,7 @@ __global__ __launch_bounds__(64 * WAVES) void k(const unsigned char* src, float*
     __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, nbytes, 0x00020000);
     unsigned off = ((blockIdx.x * WAVES + wave) * 64 + lane) * 16;
     unsigned long long t0 = __builtin_readcyclecounter();
-    for (int it = 0; it < 512; ++it) {
+    for (int it = 0; it < 4096; ++it) {
         unsigned char* dst = lds + wave * 16384 + (it & 15) * 1024;
         for (int i = 0; i < 4; ++i) {
             acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[i], 0, 0, 0);
@@ -59,7 +59,7 @@ void run(const char* name, const unsigned char* src, unsigned nbytes) {
     for (int b = 0; b < 256; ++b) for (int w = 0; w < WAVES; ++w) { sum += (double)c[b * 8 + w]; ++n; }
     const double ticks = sum / n;
     printf("%-44s %d waves/CU: %7.1f ticks per trip; kernel %.1f us wall -> %.2f GHz tick rate if the loop is the kernel; %.0f TFLOP/s\n", name, WAVES,
-           ticks / 512.0, ms * 100.0, ticks / (ms * 100.0) / 1e3, 256.0 * WAVES * 512 * 4 * 32768.0 / (ms / 10 * 1e-3) / 1e12);
+           ticks / 4096.0, ms * 100.0, ticks / (ms * 100.0) / 1e3, 256.0 * WAVES * 4096 * 4 * 32768.0 / (ms / 10 * 1e-3) / 1e12);
     hipFree(out); hipFree(cyc);
 }
 int main() {
