@@ -92,6 +92,15 @@ int adayolo_stem_fwd_act(const float* img, const float* weight, const float* bia
                        static_cast<hipStream_t>(stream)) == hipSuccess ? ADAYOLO_OK : ADAYOLO_ELAUNCH;
 }
 
+int adayolo_letterbox_pack(const float* img, void* out, int out_cstride, int B, int H, int W, int Hp, int pad_top,
+                           float pad_value, void* stream) {
+    if (!img || !out) return ADAYOLO_EINVAL;
+    if (B <= 0 || H <= 0 || W <= 0 || Hp < H || pad_top < 0 || pad_top + H > Hp) return ADAYOLO_EINVAL;
+    if (out_cstride % 8 || out_cstride < 8 || B > 65535 || Hp > 65535) return ADAYOLO_ESHAPE;
+    return launch_letterbox_pack(img, out, out_cstride, B, H, W, Hp, pad_top, pad_value,
+                                 static_cast<hipStream_t>(stream)) == hipSuccess ? ADAYOLO_OK : ADAYOLO_ELAUNCH;
+}
+
 int adayolo_stem_down_fwd(const float* img, const float* w_stem, const float* b_stem, const void* w_down,
                           const float* b_down, void* out, int out_cstride, int B, int H, int W, int Hp, int pad_top,
                           float pad_value, const void* w_next, const float* b_next, void* out_next, int out_next_cstride,

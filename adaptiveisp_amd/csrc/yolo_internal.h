@@ -49,6 +49,8 @@ hipError_t launch_conv_pp(ConvArgs a, hipStream_t s, int variant);
 hipError_t launch_conv_pp128(ConvArgs a, hipStream_t s, int variant); // 256x128 ping-pong, 3-deep ring (yolo_conv_pp128.hip)    // 256x256 ping-pong wave groups (yolo_conv_pp.hip) // 3x3, Cin 32/64, whole K resident (yolo_conv_small.hip)
 hipError_t launch_stem(const float* img, const float* w, const float* bias, void* out, int out_cs, int B, int H,
                        int W, int Hp, int pad_top, float pad_value, int act, hipStream_t s);
+hipError_t launch_letterbox_pack(const float* img, void* out, int out_cs, int B, int H, int W, int Hp, int pad_top,
+                                 float pad_value, hipStream_t s);
 hipError_t launch_stem_down(const float* img, const float* w0, const float* b0, const void* w1, const float* b1, void* out,
                             int out_cs, int B, int H, int W, int Hp, int pad_top, float pad_value, const void* w2,
                             const float* b2, void* out2, int out2_cs, hipStream_t s);

@@ -115,6 +115,33 @@ hipError_t launch_stem(const float* img, const float* w, const float* bias, void
 }
 
 // ---------------------------------------------------------------------------------------------------
+// Letterbox + layout change only: planar fp32 [B,3,H,W] -> NHWC bf16 [B,Hp,W,8] (channels 3..7 zero), for detectors
+// whose first conv is not the 3->32 stem above (width-scaled checkpoints): the generic conv then runs with Cin = 8
+// on zero-padded weights. One lane = one pixel = one 16-byte store.
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_letterbox_pack(const float* __restrict__ img, unsigned short* __restrict__ out,
+                                                        int out_cs, int H, int W, int Hp, int pad_top, float pad_value) {
+    const int b = blockIdx.z, gy = blockIdx.y, gx = blockIdx.x * 256 + threadIdx.x;
+    if (gx >= W) return;
+    const long plane = (long)H * W;
+    const int sy = gy - pad_top;
+    float r = pad_value, g = pad_value, bl = pad_value;
+    if (sy >= 0 && sy < H) {
+        const float* src = img + (long)b * 3 * plane + (long)sy * W + gx;
+        r = src[0]; g = src[plane]; bl = src[2 * plane];
+    }
+    const u32x4 o = {pack2(r, g), pack2(bl, 0.0f), 0u, 0u};
+    *reinterpret_cast<u32x4*>(out + (((long)b * Hp + gy) * W + gx) * out_cs) = o;
+}
+
+hipError_t launch_letterbox_pack(const float* img, void* out, int out_cs, int B, int H, int W, int Hp, int pad_top,
+                                 float pad_value, hipStream_t s) {
+    hipLaunchKernelGGL(k_letterbox_pack, dim3((W + 255) / 256, Hp, B), dim3(256), 0, s, img,
+                       static_cast<unsigned short*>(out), out_cs, H, W, Hp, pad_top, pad_value);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------
 // Nearest 2x up-sampling into a channel slice of the concat buffer (nn.Upsample + Concat).
 // One lane moves one 16-byte channel chunk of an input pixel to its 4 output pixels.
 // ---------------------------------------------------------------------------------------------------

@@ -8,7 +8,7 @@ _HERE = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB_PATH = os.path.join(_HERE, "csrc", "libadayolo.so")
 ABI_VERSION = 1
 ACT_NONE, ACT_SILU = 0, 1
-EXPORTS = ("adayolo_conv_fwd", "adayolo_conv_fwd_variant", "adayolo_stem_fwd", "adayolo_upsample2x", "adayolo_detect_decode", "adayolo_nms", "adayolo_nms_workspace_bytes", "adayolo_stem_fwd_act", "adayolo_stem_down_fwd", "adayolo_silu_fwd", "adayolo_silu_bwd",
+EXPORTS = ("adayolo_conv_fwd", "adayolo_conv_fwd_variant", "adayolo_stem_fwd", "adayolo_upsample2x", "adayolo_detect_decode", "adayolo_nms", "adayolo_nms_workspace_bytes", "adayolo_stem_fwd_act", "adayolo_stem_down_fwd", "adayolo_letterbox_pack", "adayolo_silu_fwd", "adayolo_silu_bwd",
            "adayolo_zero_insert2x", "adayolo_upsample2x_bwd", "adayolo_image_grad", "adayolo_strerror",
            "adayolo_abi_version")
 _lib = None
@@ -37,12 +37,14 @@ def load():
     L.adayolo_stem_fwd_act.argtypes = [vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, cf, ci, ci, vp]
     L.adayolo_stem_down_fwd.argtypes = [vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, cf, vp, vp, vp, ci, vp]
     L.adayolo_stem_down_fwd.restype = ci
+    L.adayolo_letterbox_pack.argtypes = [vp, vp, ci, ci, ci, ci, ci, ci, cf, vp]
+    L.adayolo_letterbox_pack.restype = ci
     L.adayolo_silu_fwd.argtypes = [vp, ci, vp, ci, vp, ci, cl, ci, vp]
     L.adayolo_silu_bwd.argtypes = [vp, ci, vp, ci, vp, ci, vp, ci, ci, cl, ci, vp]
     L.adayolo_zero_insert2x.argtypes = [vp, ci, vp, ci, ci, ci, ci, ci, ci, ci, vp]
     L.adayolo_upsample2x_bwd.argtypes = [vp, ci, vp, ci, ci, ci, ci, ci, ci, vp]
     L.adayolo_image_grad.argtypes = [vp, ci, vp, ci, ci, ci, ci, ci, vp]
-    for n in ("adayolo_stem_fwd_act", "adayolo_stem_down_fwd", "adayolo_silu_fwd", "adayolo_silu_bwd", "adayolo_zero_insert2x",
+    for n in ("adayolo_stem_fwd_act", "adayolo_stem_down_fwd", "adayolo_letterbox_pack", "adayolo_silu_fwd", "adayolo_silu_bwd", "adayolo_zero_insert2x",
               "adayolo_upsample2x_bwd", "adayolo_image_grad"):
         getattr(L, n).restype = ci
     L.adayolo_nms.argtypes = [vp, ci, cf, ci, vp, vp, vp, vp]

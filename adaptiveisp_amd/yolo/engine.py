@@ -110,6 +110,11 @@ class YoloEngine:
         flops = 2.0 * self.B * dst.H * dst.W * cout * k * k * src.C
         self.flops += flops
 
+    @staticmethod
+    def _fused_stem_ok(m):
+        c = m.conv
+        return (c.in_channels, c.out_channels, c.kernel_size[0], c.stride[0]) == (3, 32, 3, 1)
+
     def _build(self, model):
         self.flops = 0.0
         self.ops = []            # the same launches as `plan`, with their views (used by the training engine)
@@ -150,7 +155,21 @@ class YoloEngine:
         # pass 3: launch plan
         for i, m in enumerate(layers):
             src = view[_src(i, m.f)] if (i > 0 and isinstance(m.f, int)) else None
-            if i == 0:
+            if i == 0 and not self._fused_stem_ok(m):
+                # width-scaled detector (first conv is not 3->32 k3 s1): letterbox + NHWC pack, then the generic conv
+                # on weights zero-padded to 8 input channels
+                packed = _View(self._new(self.Hp, self.W, 8), 0, 8)
+                args = (None, ctypes.c_void_p(packed.ptr), packed.cs, self.B, self.H, self.W, self.Hp, self.pad_top,
+                        LETTERBOX_VALUE)
+                self._stem = None
+                self._pack_dst = packed
+                self.plan.append(("pack", self.L.adayolo_letterbox_pack, args))
+                self.ops.append(dict(kind="pack", dst=packed))
+                w, b = m.folded()
+                w = torch.nn.functional.pad(w.detach().float(), (0, 0, 0, 0, 0, 8 - w.shape[1]))
+                w, b = _pack_conv(w, b)
+                self._conv_op(packed, w, b, view[0], m.conv.kernel_size[0], m.conv.stride[0], _lib.ACT_SILU)
+            elif i == 0:
                 w, b = m.folded()
                 w = w.detach().float().permute(0, 2, 3, 1).contiguous().to(self.dev)      # [32][3][3][3] fp32
                 b = b.detach().float().contiguous().to(self.dev)
@@ -205,10 +224,11 @@ class YoloEngine:
     def _plans(self):
         return [self.plan]
 
-    def autotune(self, reps=5, cache=None, retune=False):
+    def autotune(self, reps=5, cache=None, retune=False, write=True):
         """Pick the fastest conv kernel variant per layer by timing it on this engine's own buffers (all variants
         compute the same result; see include/adayolo.h). Like a vendor library's 'find' step. With `cache` (a JSON
-        path) the choices are loaded when every layer shape is present, otherwise measured and written back."""
+        path) the choices are loaded when every layer shape is present, otherwise measured and written back (atomically;
+        `write=False` for ranks other than 0 of a multi-process job)."""
         import json
         import os
         st = _lib.stream_ptr()
@@ -257,12 +277,18 @@ class YoloEngine:
                     chosen[key] = best[0]
                 args[16] = chosen[key]
         self.tuned = chosen
-        if cache:
+        if cache and write:
             try:
-                old = json.load(open(cache)) if os.path.exists(cache) else {}
+                try:
+                    old = json.load(open(cache)) if os.path.exists(cache) else {}
+                except ValueError:
+                    old = {}
                 old.update({",".join(str(int(x)) for x in k): int(v) for k, v in chosen.items()})
                 os.makedirs(os.path.dirname(cache), exist_ok=True)
-                json.dump(old, open(cache, "w"), indent=0, sort_keys=True)
+                tmp = f"{cache}.{os.getpid()}.tmp"                # whole-file replace: a concurrent reader never sees a
+                with open(tmp, "w") as f:                         # partial table (one process per GPU under torchrun)
+                    json.dump(old, f, indent=0, sort_keys=True)
+                os.replace(tmp, cache)
             except OSError:
                 pass                                            # read-only checkout: keep the in-memory choice
         return chosen
@@ -276,6 +302,12 @@ class YoloEngine:
         img = img.contiguous()
         with torch.cuda.device(self.dev):
             st = _lib.stream_ptr()
+            if self._stem is None:                               # generic first conv: pack launch takes the image pointer
+                for kind, fn, args in self.plan:
+                    rc = fn(ctypes.c_void_p(img.data_ptr()), *args[1:], st) if kind == "pack" else fn(*args, st)
+                    if rc != 0:
+                        _lib.check(rc, f"adayolo {kind}")
+                return self.pred
             w, b, out = self._stem
             if self.fuse_head:
                 d, n = self._head_down, self._head_next

@@ -67,6 +67,9 @@ class YoloTrainEngine(YoloEngine):
 
         bwd = []                                    # built in forward order, reversed at the end
         for op in self.ops:
+            if op["kind"] == "pack":
+                raise _lib.AdayoloError("YoloTrainEngine serves the yolov3.yaml stem (Conv 3->32 k3 s1); width-scaled "
+                                        "detectors run forward-only (YoloEngine)")
             if op["kind"] == "stem":
                 dst = op["dst"]
                 P = self._dense(dst.H, dst.W, 32)

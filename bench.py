@@ -69,7 +69,17 @@ def build_workload(a, dev):
     torch.manual_seed(1)
     det = yolov3().eval()
     engine = YoloEngine(det, a.batch, a.height, a.width, device=dev)
-    engine.autotune(cache=TUNE_CACHE, retune=a.retune)
+    # one writer: rank 0 measures (if it has to) and rewrites the table, the other ranks read it after the barrier
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        import torch.distributed as dist
+        if rank == 0:
+            engine.autotune(cache=TUNE_CACHE, retune=a.retune)
+        dist.barrier()
+        if rank != 0:
+            engine.autotune(cache=TUNE_CACHE, write=False)
+    else:
+        engine.autotune(cache=TUNE_CACHE, retune=a.retune)
     g = torch.Generator(device="cpu").manual_seed(1234 + 1)
     x0 = (torch.rand(a.batch, 3, a.height, a.width, generator=g) ** 2.2 * 0.5).to(dev)
     z = torch.rand(a.batch, cfg.z_dim, generator=g).to(dev)

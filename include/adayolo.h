@@ -74,6 +74,14 @@ int adayolo_stem_fwd(const float* img, const float* weight, const float* bias, v
                      int B, int H, int W, int Hp, int pad_top, float pad_value, int Cout, void* stream);
 
 /*
+ * The hand-over alone, for detectors whose first conv is not 3->32 (width-scaled checkpoints,
+ * yolov3/models/yolo.py:301-336 `width_multiple`): letterbox as above and write NHWC bf16 [B,Hp,W,8] with
+ * channels 3..7 zero; the first conv then runs through adayolo_conv_fwd with Cin = 8 on zero-padded weights.
+ */
+int adayolo_letterbox_pack(const float* img, void* out, int out_cstride, int B, int H, int W, int Hp, int pad_top,
+                           float pad_value, void* stream);
+
+/*
  * adayolo_stem_fwd fused with the first down-sampling block of yolov3.yaml (layer 1: Conv(32->64, k3 s2) + SiLU):
  * planar fp32 image in, NHWC bf16 [B, Hp/2, W/2, 64] out; the 32-channel stem output stays in LDS.
  * w_stem fp32 [32][3][3][3], w_down bf16 [64][3][3][32] (BN folded), biases fp32. Hp and W even.

@@ -87,3 +87,32 @@ def test_width_multiple_matches_reference_channel_rounding():
     m = DetectionModel(nc=7, width=0.0625)
     assert m.model[0].conv.out_channels == 8 and m.model[9].conv.out_channels == 64
     assert m.model[28].m[0].out_channels == 3 * 12
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fused", [False, True])
+def test_imported_pickle_through_the_hip_engine(golden, fused):
+    """f2 end to end on the device: a detector pickled by the REFERENCE's classes (yolov3/models/experimental.py:73-89
+    is the loader this replaces) -> restricted unpickler -> DetectionModel -> YoloEngine (bf16 MFMA kernels) -> the
+    output the reference module itself produced (`ckpt_import.npz`). The fixture is a width-0.0625, nc=7 network, so
+    this also drives the generic first conv (letterbox pack + Cin=8 conv) and the narrow-channel tiles."""
+    from adaptiveisp_amd.yolo import YoloEngine
+    from adaptiveisp_amd.yolo.checkpoint import load_detector_checkpoint
+    g = golden("ckpt_import")
+    name = "yolov3_w0625_refpickle_fused.pt" if fused else "yolov3_w0625_refpickle.pt"
+    m = load_detector_checkpoint(os.path.join(GOLD, name)).eval()
+    x = torch.from_numpy(g["x"])
+    B, _, H, W = x.shape
+    eng = YoloEngine(m, B, H, W, device="cuda:0")
+    assert eng._stem is None and eng.plan[0][0] == "pack"
+    pred = eng(x.to("cuda:0")).cpu().numpy()
+    ref = g["pred_fused_fp32"] if fused else g["pred"]
+    rel = np.abs(pred - ref) / (np.abs(ref) + 1.0)
+    assert rel.max() < 2e-2, rel.max()
+    raw0 = eng.raw_maps()[0].cpu().numpy()
+    if not fused:
+        assert np.abs(raw0 - g["raw0"]).max() <= 3e-2 * np.abs(g["raw0"]).max()
+    # the detections that survive a confidence threshold are the same boxes
+    conf = ref[..., 4] * ref[..., 5:].max(-1)
+    top = np.argsort(-conf[0])[:20]
+    np.testing.assert_allclose(pred[0, top, :4], ref[0, top, :4], rtol=3e-2, atol=0.5)

@@ -173,3 +173,44 @@ def test_training_iteration_end_to_end():
     after = torch.cat([p.detach().reshape(-1) for p in agent.parameters()])
     assert (after != before).any()                            # the heads moved
     assert out["retouch"].shape == imgs.shape and float(out["retouch"].min()) >= 0 and float(out["retouch"].max()) <= 1
+
+
+def test_device_side_sampling_train_mode(golden):
+    """k_finish with train_mode=1: the inverse-CDF sampler of agent.py:12-16 on the device. The selection must equal
+    `pdf_sample` (pinned to the reference bit-exactly by tests/golden/select.npz on the CPU) applied to the pdf the
+    same launch returned; u = 0 gives id -1 -> all-zero one-hot -> op ZERO -> an all-zero image and an unchanged usage
+    vector; u just below 1 gives the last filter with non-zero probability."""
+    from adaptiveisp_amd import _lib
+    from adaptiveisp_amd.agent import one_hot, pdf_sample
+    from adaptiveisp_amd.policy_fast import FastPolicy
+    from _synth import test_image
+    g = golden("select")
+    ag, cfg, dev = _agent()
+    B = g["u"].shape[0]
+    x = T(test_image(B, 40, 56, seed=21, special=False)).to(dev)
+    z = torch.rand(B, cfg.z_dim, generator=torch.Generator().manual_seed(3)).to(dev)
+    z[:, 0] = T(g["u"][:, 0]).to(dev)                     # includes u = 0, u = 1 - ulp
+    states = torch.zeros(B, cfg.num_state_dim, device=dev)
+    states[:, 3:] = (torch.rand(B, 10, generator=torch.Generator().manual_seed(4)) < 0.3).float().to(dev)
+    fp = FastPolicy(ag)
+    o = fp.run(_lib.pool64(x), z, states, 0.25, None, train_mode=True)
+    torch.cuda.synchronize()
+    pdf = o["pdf"].cpu()
+    want = pdf_sample(pdf, z[:, 0:1].cpu()).to(torch.int64)
+    sel = o["selected"].cpu()
+    assert torch.equal(sel, want), (sel, want)
+    assert sel[0].item() == -1 and sel[1].item() == 9
+    assert len(set(sel.tolist())) > 2, "sampling should not collapse onto the arg-max"
+    ops = torch.tensor([-1] + [int(f.op_code) for f in ag.filters], dtype=torch.int32)
+    assert torch.equal(o["op_ids"].cpu(), ops[sel + 1])
+    hot = one_hot(10, sel).float()
+    ns = o["new_states"].cpu()
+    assert torch.equal(ns[:, 3:], torch.maximum(states[:, 3:].cpu(), hot))
+    assert torch.equal(ns[:, 2], states[:, 2].cpu() + 1)
+    sur = torch.sum(hot * torch.log(pdf + 1e-10), dim=1, keepdim=True)
+    torch.testing.assert_close(o["surrogate"].cpu(), sur, rtol=1e-5, atol=1e-6)
+    y = _lib.forward(x, o["op_ids"], o["packed"], clip=True)
+    assert not y[0].any() and y[1].any()
+    # the same launch in eval mode is the arg-max
+    e = fp.run(_lib.pool64(x), z, states, 0.25, None, train_mode=False)
+    assert torch.equal(e["selected"].cpu(), torch.argmax(e["pdf"].cpu(), dim=1))

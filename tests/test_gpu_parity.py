@@ -41,13 +41,23 @@ def rand_params(op, B, rng):
     raise KeyError(op)
 
 
+# Stages whose arithmetic is +,-,*,/,min,max,floor,compare only: the kernels are built -ffp-contract=off in the
+# reference's operation order, so the HIP result must be BIT-IDENTICAL to the reference's (and to the oracle's).
+# The rest go through a transcendental (exp/log/pow/cos/sqrt: device unit vs ATen/libm) or — NLM, USM — a long sum
+# whose association differs from ATen's: 1e-5 relative (north_star).
+BIT_EXACT = ("CCM", "Shr", "ShrV2", "T", "Sp", "BW", "W")
+
+
 @pytest.mark.parametrize("name", sorted(OPS))
 @pytest.mark.parametrize("mode", ["process", "forward"])
 def test_golden_vectors(golden, name, mode):
     """Same inputs as the reference run in the build container -> same outputs."""
     g = golden("filters")
     out = gpu_process(OPS[name], g["img"], g[f"{name}.param"], clip=(mode == "forward"))
-    np.testing.assert_allclose(out, g[f"{name}.{mode}"], rtol=RTOL, atol=ATOL)
+    if name in BIT_EXACT:
+        np.testing.assert_array_equal(out, g[f"{name}.{mode}"])
+    else:
+        np.testing.assert_allclose(out, g[f"{name}.{mode}"], rtol=RTOL, atol=ATOL)
 
 
 @pytest.mark.parametrize("tag", ["a", "tiny", "odd"])
@@ -95,7 +105,8 @@ def test_golden_pool64(golden, tag):
     from adaptiveisp_amd import _lib
     g = golden("pool64")
     out = _lib.pool64(torch.from_numpy(g[f"{tag}.img"]).to(dev())).cpu().numpy()
-    np.testing.assert_allclose(out, g[f"{tag}.out"], rtol=RTOL, atol=1e-7)
+    # window sums in a fixed (but not ATen's) order, then one division: a few ulp, never more
+    np.testing.assert_allclose(out, g[f"{tag}.out"], rtol=2e-6, atol=0)
 
 
 SHAPES = [(2, 64, 128), (1, 37, 53), (3, 5, 7), (1, 3, 3), (1, 33, 260), (2, 96, 64)]
@@ -116,7 +127,10 @@ def test_vs_oracle_shapes(oracle_mod, name, shape):
     for clip in (False, True):
         out = gpu_process(OPS[name], img, p, clip)
         ref = oracle_mod.forward(img, OPS[name], p, clip=clip)
-        np.testing.assert_allclose(out, ref, rtol=RTOL, atol=ATOL, err_msg=f"{name} {shape} clip={clip}")
+        if name in BIT_EXACT:
+            np.testing.assert_array_equal(out, ref, err_msg=f"{name} {shape} clip={clip}")
+        else:
+            np.testing.assert_allclose(out, ref, rtol=RTOL, atol=ATOL, err_msg=f"{name} {shape} clip={clip}")
 
 
 def test_mixed_ids_one_call(oracle_mod):
@@ -280,3 +294,67 @@ def test_fullsize_4k_properties(oracle_mod):
     assert float(y.min()) >= 0.0 and float(y.max()) <= 1.0
     p = _lib.pool64(x)
     torch.testing.assert_close(p, torch.nn.functional.adaptive_avg_pool2d(x, 64), rtol=1e-5, atol=1e-6)
+
+
+# ---- BASELINE.json sizes against the oracle itself ---------------------------------------------------------
+
+SCHEDULES = {"S_mixed": ["E", "CCM", "NLM", "Shr", "T"], "S_point": ["E", "W", "CCM", "T", "G"]}
+
+
+@pytest.mark.parametrize("sched", sorted(SCHEDULES))
+def test_fullsize_episode_vs_oracle(oracle_mod, sched):
+    """Config 2 (8 x 3 x 720 x 1280), five RL steps through adaisp_forward with MIXED op ids in every call (image b runs
+    the schedule rotated by b, so each launch carries all five kernels' work) and fixed regressed-range parameters.
+    Every step is compared with the oracle on all 8 images, the oracle being fed the same step input (rtol 1e-5;
+    bit-exact for the BIT_EXACT stages); the fused 64x64 pooling of every step likewise; and the oracle's own chained
+    episode (its outputs fed back to it) must agree with the device's final image."""
+    from adaptiveisp_amd import _lib
+    names = SCHEDULES[sched]
+    B, H, W = 8, 720, 1280
+    rng = np.random.default_rng(2024)
+    x = _full(B, H, W, seed=1235)
+    chain = x.cpu().numpy()
+    for k in range(5):
+        step_names = [names[(k + b) % 5] for b in range(B)]
+        ids = np.array([OPS[n] for n in step_names], np.int32)
+        params = np.zeros((B, 24), np.float32)
+        for b, n in enumerate(step_names):
+            p = rand_params(OPS[n], 1, rng)
+            if n == "E":
+                p = np.clip(p, -1.0, 1.5)                 # keep the episode inside [0,1] so later steps see content
+            if n == "NLM":
+                p = rng.uniform(0.02, 0.3, (1, 1))
+            params[b, :p.shape[1]] = p[0]
+        pooled = torch.empty(B, 3, 64, 64, device=dev())
+        y = _lib.forward(x, torch.from_numpy(ids).to(dev()), torch.from_numpy(params).to(dev()), clip=True, pooled=pooled)
+        torch.cuda.synchronize()
+        ref = oracle_mod.forward(x.cpu().numpy(), ids, params, clip=True)
+        out = y.cpu().numpy()
+        for b, n in enumerate(step_names):
+            if n in BIT_EXACT:
+                np.testing.assert_array_equal(out[b], ref[b], err_msg=f"step {k} image {b} {n}")
+            else:
+                np.testing.assert_allclose(out[b], ref[b], rtol=RTOL, atol=ATOL, err_msg=f"step {k} image {b} {n}")
+        np.testing.assert_allclose(pooled.cpu().numpy(), oracle_mod.pool64(out), rtol=2e-6, atol=0)
+        chain = oracle_mod.forward(chain, ids, params, clip=True)
+        x = y
+    # end to end: five chained steps on each side. Differences of 1e-5 relative per step pass through sharpen's
+    # (1 + 2f) gain and the tone curve's slopes, hence the wider absolute bound; most pixels stay within 1e-5.
+    d = np.abs(x.cpu().numpy() - chain)
+    assert d.max() < 2e-4, d.max()
+    assert np.mean(d > 1e-5 * np.abs(chain) + 2e-6) < 1e-3
+
+
+def test_4k_denoise_sharpen_vs_oracle(oracle_mod):
+    """Config 5 (2160 x 3840, S_heavy = [NLM, Shr]) on one real-content frame, the whole frame against the oracle."""
+    from adaptiveisp_amd import _lib
+    x = _full(1, 2160, 3840, seed=77)
+    h = torch.tensor([[0.12]], device=dev())
+    f = torch.tensor([[3.5]], device=dev())
+    y = _lib.process(OPS["NLM"], x, h, clip=True)
+    z = _lib.process(OPS["Shr"], y, f, clip=True)
+    torch.cuda.synchronize()
+    ref_y = oracle_mod.forward(x.cpu().numpy(), OPS["NLM"], h.cpu().numpy(), clip=True)
+    np.testing.assert_allclose(y.cpu().numpy(), ref_y, rtol=RTOL, atol=ATOL)
+    ref_z = oracle_mod.forward(y.cpu().numpy(), OPS["Shr"], f.cpu().numpy(), clip=True)
+    np.testing.assert_array_equal(z.cpu().numpy(), ref_z)

@@ -1,0 +1,191 @@
+"""Every conv kernel the autotuner may pick (yolo/tuning/mi355x.json) against fp32 `F.conv2d` on the same bf16-rounded
+operands, at the layer shapes it is benchmarked on, plus the whole TUNED engine at the BASELINE sizes against the fp32
+module tree (yolo/model.py, itself bit-identical to the reference's DetectionModel on tests/golden/yolo.npz).
+
+What each case demands (reference semantics: Conv.forward_fuse = act(conv(x) + folded-BN bias),
+Bottleneck.forward = x + cv2(cv1(x)); yolov3/models/common.py:45-59,110-120):
+  * the output buffer is pre-filled with NaN, so a tile that is never written fails;
+  * 4 launches give bit-identical results (race screen);
+  * max |err| <= 2e-2 * max(1, max|ref|) and mean |err| <= 2e-3 * max(1, max|ref|) (two bf16 roundings)."""
+import ctypes
+import json
+import os
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+TUNE = os.path.join(ROOT, "adaptiveisp_amd", "yolo", "tuning", "mi355x.json")
+
+
+def _table():
+    return {tuple(int(x) for x in k.split(",")): int(v) for k, v in json.load(open(TUNE)).items()}
+
+
+def _serves(v, cin, cout, k, s):
+    """Shapes a variant is specialised for (adayolo.h: other shapes fall through to the default kernel)."""
+    if 40 <= v < 50:
+        return k == 3 and cin in (32, 64)
+    if 50 <= v < 60:
+        return cin % 64 == 0 and cout % 256 == 0
+    if v >= 60:
+        return cin % 64 == 0 and cout % 128 == 0
+    return True
+
+
+def _run_variant(x, w, b, res, k, s, act, v, reps=4):
+    from adaptiveisp_amd.yolo import _lib
+    L = _lib.load()
+    B, H, W, cin = x.shape
+    cout = w.shape[0]
+    Ho, Wo = (H - 1) // s + 1, (W - 1) // s + 1
+    first = None
+    for _ in range(reps):
+        out = torch.full((B, Ho, Wo, cout), float("nan"), dtype=torch.bfloat16, device=DEV)
+        rc = L.adayolo_conv_fwd_variant(ctypes.c_void_p(x.data_ptr()), cin, ctypes.c_void_p(w.data_ptr()),
+                                        ctypes.c_void_p(b.data_ptr()), ctypes.c_void_p(res.data_ptr()) if res is not None else None,
+                                        cout if res is not None else 0, ctypes.c_void_p(out.data_ptr()), cout, B, H, W, cin,
+                                        cout, k, s, act, v, _lib.stream_ptr())
+        _lib.check(rc, "conv")
+        torch.cuda.synchronize()
+        if first is None:
+            first = out
+        else:
+            assert torch.equal(first.view(torch.int16), out.view(torch.int16)), "run-to-run difference"
+    return first
+
+
+def _reference(x, w, b, res, k, s, act):
+    ref = F.conv2d(x.float().permute(0, 3, 1, 2), w.float().permute(0, 3, 1, 2), b, stride=s, padding=k // 2)
+    if act:
+        ref = F.silu(ref)
+    ref = ref.permute(0, 2, 3, 1)
+    if res is not None:
+        ref = ref.to(torch.bfloat16).float() + res.float()
+    return ref
+
+
+def _check(shape, v, use_res, acts=(1,)):
+    B, H, W, cin, cout, k, s = shape
+    g = torch.Generator(device="cpu").manual_seed((H * 131 + cin * 7 + cout + v) % 2 ** 31)
+    x = torch.randn(B, H, W, cin, generator=g).to(torch.bfloat16).to(DEV)
+    w = (torch.randn(cout, k, k, cin, generator=g) / (k * k * cin) ** 0.5).to(torch.bfloat16).to(DEV)
+    b = torch.randn(cout, generator=g).to(DEV)
+    Ho, Wo = (H - 1) // s + 1, (W - 1) // s + 1
+    res = torch.randn(B, Ho, Wo, cout, generator=g).to(torch.bfloat16).to(DEV) if use_res else None
+    for act in acts:
+        out = _run_variant(x, w, b, res, k, s, act, v)
+        ref = _reference(x, w, b, res, k, s, act)
+        assert torch.isfinite(out.float()).all(), "unwritten (NaN) outputs"
+        scale = max(1.0, ref.abs().max().item())
+        d = (out.float() - ref).abs()
+        assert d.max().item() <= 2e-2 * scale, f"{shape} v{v} act{act}: max err {d.max().item()} (scale {scale})"
+        assert d.mean().item() <= 2e-3 * scale, f"{shape} v{v} act{act}: mean err {d.mean().item()}"
+        del out, ref, d
+
+
+# the layer shapes of the BASELINE network (8 x 736 x 1280) with the kernel the tuning table picks for each
+def _c2_cases():
+    t = _table()
+    return sorted((k[:7], v) for k, v in t.items() if k[1] in (736, 368, 184, 92, 46, 23) and k[7] == 1)
+
+
+@pytest.mark.parametrize("shape,v", _c2_cases(), ids=lambda p: "x".join(map(str, p)) if isinstance(p, tuple) else f"v{p}")
+def test_tuned_kernel_at_its_baseline_layer(shape, v):
+    """Each (layer shape, chosen variant) pair of the benchmarked network, full size, residual as in a Bottleneck."""
+    k, s = shape[5], shape[6]
+    _check(shape, v, use_res=(k == 3 and s == 1))
+
+
+def _used_variants():
+    return sorted(set(_table().values()))
+
+
+RAGGED = [  # B, H, W, Cin, Cout, k, s, residual — partial tiles in M and N, tiny maps, stride 2 on odd sizes
+    (2, 19, 33, 128, 256, 3, 1, True), (1, 5, 6, 512, 1024, 3, 1, True), (3, 9, 11, 64, 256, 1, 1, False),
+    (1, 7, 9, 64, 256, 3, 2, False), (2, 37, 53, 64, 128, 3, 2, False), (1, 9, 7, 192, 384, 3, 1, True),
+    (2, 16, 24, 32, 64, 3, 2, False), (1, 23, 40, 64, 32, 1, 1, False), (2, 12, 20, 32, 64, 3, 1, True),
+    (3, 9, 11, 768, 256, 1, 1, False), (2, 7, 5, 8, 32, 3, 1, False), (1, 30, 30, 64, 128, 3, 2, False),
+    (1, 1, 1, 64, 256, 3, 1, False), (1, 2, 3, 128, 128, 1, 1, True), (5, 13, 17, 256, 768, 1, 1, False),
+    (2, 31, 29, 32, 64, 3, 1, False), (1, 3, 200, 64, 64, 3, 1, True),
+]
+
+
+@pytest.mark.parametrize("v", _used_variants())
+def test_every_tuned_variant_on_ragged_shapes(v):
+    """Every variant the table can select, on small / odd / partial-tile shapes it serves, act on and off."""
+    n = 0
+    for (B, H, W, cin, cout, k, s, use_res) in RAGGED:
+        if _serves(v, cin, cout, k, s):
+            _check((B, H, W, cin, cout, k, s), v, use_res, acts=(0, 1))
+            n += 1
+    assert n >= 3, f"variant {v}: too few shapes exercised"
+
+
+@pytest.mark.parametrize("v", _used_variants())
+def test_variant_channel_slices(v):
+    """Concat is free because convs read / write channel slices of wider tensors: strides larger than C, every variant."""
+    from adaptiveisp_amd.yolo import _lib
+    L = _lib.load()
+    cin, cout, k, s = (64, 256, 3, 1)
+    g = torch.Generator(device="cpu").manual_seed(50 + v)
+    wide_in = torch.randn(2, 21, 35, cin + 64, generator=g).to(torch.bfloat16).to(DEV)
+    wide_out = torch.full((2, 21, 35, cout + 128), 7.0, dtype=torch.bfloat16, device=DEV)
+    wide_res = torch.randn(2, 21, 35, cout + 8, generator=g).to(torch.bfloat16).to(DEV)
+    w = (torch.randn(cout, k, k, cin, generator=g) / 24).to(torch.bfloat16).to(DEV)
+    b = torch.randn(cout, generator=g).to(DEV)
+    xin, xout, xres = wide_in[..., 32:32 + cin], wide_out[..., 64:64 + cout], wide_res[..., 8:]
+    rc = L.adayolo_conv_fwd_variant(ctypes.c_void_p(xin.data_ptr()), wide_in.shape[3], ctypes.c_void_p(w.data_ptr()),
+                                    ctypes.c_void_p(b.data_ptr()), ctypes.c_void_p(xres.data_ptr()), wide_res.shape[3],
+                                    ctypes.c_void_p(xout.data_ptr()), wide_out.shape[3], 2, 21, 35, cin, cout, k, s, 1, v,
+                                    _lib.stream_ptr())
+    _lib.check(rc, "conv")
+    torch.cuda.synchronize()
+    ref = _reference(xin.contiguous(), w, b, xres.contiguous(), k, s, 1)
+    assert (xout.float() - ref).abs().max().item() <= 2e-2 * max(1.0, ref.abs().max().item())
+    assert (wide_out[..., :64] == 7).all() and (wide_out[..., 64 + cout:] == 7).all()       # neighbours untouched
+
+
+def _tuned_engine_vs_module_tree(B, H, W, images):
+    from _synth import synth_yolo_state_dict, test_image
+    from adaptiveisp_amd.yolo import YoloEngine, yolov3
+    m = yolov3().eval()
+    m.load_state_dict(synth_yolo_state_dict(m))
+    x = torch.from_numpy(test_image(B, H, W, seed=91, special=False)).to(DEV)
+    eng = YoloEngine(m, B, H, W, device=DEV)
+    tuned = eng.autotune(cache=TUNE)
+    assert set(tuned.values()) - {2}, "the tuning table must route layers to the specialised kernels"
+    if (B, H, W) == (8, 720, 1280):
+        assert set(tuned.values()) >= {50, 60}, "BASELINE shape: table lost the ping-pong kernels"
+    pred = eng(x).clone()
+    raws = [r.clone() for r in eng.raw_maps()]
+    torch.cuda.synchronize()
+    ref_model = m.to(DEV)
+    for i in images:
+        boxed = torch.full((1, 3, eng.Hp, W), 114 / 255, device=DEV)
+        boxed[:, :, eng.pad_top:eng.pad_top + H] = x[i:i + 1]
+        with torch.no_grad():
+            ref_pred, ref_raw = ref_model(boxed)
+        for r, rr in zip(raws, ref_raw):
+            scale = rr.abs().max().item()
+            err = (r[i:i + 1] - rr).abs().max().item()
+            assert err <= 3e-2 * scale, f"image {i}: raw head map err {err} vs scale {scale}"
+        rel = ((pred[i:i + 1] - ref_pred).abs() / (ref_pred.abs() + 1.0)).max().item()
+        assert rel < 2e-2, f"image {i}: decoded prediction rel err {rel}"
+        del ref_pred, ref_raw
+    m.to("cpu")
+    return tuned
+
+
+def test_tuned_engine_baseline_size_vs_fp32_module_tree():
+    """YoloEngine(8 x 720 x 1280) WITH the tuning table the bench uses (variants 50/60/27/5/22/40) vs the fp32 module
+    tree on images 0 and 7: three raw maps <= 3e-2 of scale, decoded prediction <= 2e-2 relative."""
+    _tuned_engine_vs_module_tree(8, 720, 1280, images=(0, 7))
+
+
+def test_tuned_engine_4k_vs_fp32_module_tree():
+    """Config 5 detector (4 x 2160 x 3840 -> letterboxed 2176): one image against the fp32 module tree."""
+    _tuned_engine_vs_module_tree(4, 2160, 3840, images=(3,))
