@@ -19,7 +19,7 @@ NLM_EXACT = 2      # NLM patch sums in the reference's running-sum order (slower
 NLM_SEP_V1 = 4     # the compiler-scheduled form of the separable kernel (cross-check / measurement)
 ABI_VERSION = 3
 
-EXPORTS = ("adaisp_forward", "adaisp_process", "adaisp_backward_params", "adaisp_pool64", "adaisp_demosaic", "adaisp_num_params",
+EXPORTS = ("adaisp_forward", "adaisp_process", "adaisp_backward_params", "adaisp_pool64", "adaisp_pool64_backward", "adaisp_demosaic", "adaisp_num_params",
            "adaisp_policy_conv", "adaisp_policy_fc1", "adaisp_policy_finish",
            "adaisp_strerror", "adaisp_abi_version")
 
@@ -44,6 +44,8 @@ def load():
     L.adaisp_process.argtypes = [ci, vp, vp, vp, ci, ci, ci, ci, cu, vp]
     L.adaisp_backward_params.argtypes = [vp, vp, vp, vp, ci, vp, ci, ci, ci, cu, vp]
     L.adaisp_pool64.argtypes = [vp, vp, ci, ci, ci, vp]
+    L.adaisp_pool64_backward.argtypes = [vp, vp, ci, ci, ci, vp]
+    L.adaisp_pool64_backward.restype = ci
     L.adaisp_demosaic.argtypes = [vp, vp, ci, ci, ci, ci, ctypes.c_float, ctypes.c_float, vp]
     L.adaisp_demosaic.restype = ci
     L.adaisp_num_params.argtypes = [ci]
@@ -142,6 +144,20 @@ def pool64(img):
     with torch.cuda.device(img.device):
         rc = L.adaisp_pool64(img.data_ptr(), out.data_ptr(), B, H, W, _stream())
     _check(rc, "adaisp_pool64")
+    return out
+
+
+def pool64_backward(grad_pooled, H, W):
+    """grad_pooled [B,3,64,64] -> gradient w.r.t. the [B,3,H,W] image that adaisp_pool64 pooled."""
+    L = load()
+    g = _dev_f32(grad_pooled, "grad_pooled")
+    B = g.shape[0]
+    if tuple(g.shape[1:]) != (3, 64, 64):
+        raise AdaispError(f"grad_pooled must be [B,3,64,64], got {tuple(g.shape)}")
+    out = torch.empty((B, 3, H, W), dtype=torch.float32, device=g.device)
+    with torch.cuda.device(g.device):
+        rc = L.adaisp_pool64_backward(g.data_ptr(), out.data_ptr(), B, H, W, _stream())
+    _check(rc, "adaisp_pool64_backward")
     return out
 
 

@@ -57,6 +57,13 @@ int adaisp_pool64(const float* img, float* pooled, int B, int H, int W, void* st
                                                                                                 : ADAISP_ELAUNCH;
 }
 
+int adaisp_pool64_backward(const float* grad_pooled, float* grad_img, int B, int H, int W, void* stream) {
+    if (!grad_pooled || !grad_img || B <= 0 || H <= 0 || W <= 0) return ADAISP_EINVAL;
+    if ((long)B * 3 > 65535 || H > 65535) return ADAISP_ESHAPE;
+    return launch_pool64_bwd(grad_pooled, grad_img, B, H, W, static_cast<hipStream_t>(stream)) == hipSuccess
+               ? ADAISP_OK : ADAISP_ELAUNCH;
+}
+
 int adaisp_demosaic(const uint16_t* raw, float* out, int B, int H, int W, int pattern, float black_level,
                     float white_level, void* stream) {
     if (!raw || !out || B <= 0 || H <= 0 || W <= 0) return ADAISP_EINVAL;
@@ -101,8 +108,9 @@ int adaisp_forward(const float* img, float* out, float* pooled64_next, const int
     Batch a{img, out, filter_id, 0, params, param_stride, B, H, W, flags};
     // The ids live on the device, so each kernel family is enqueued for the whole batch and its
     // workgroups return at once for images whose op belongs to another family.
+    if (H < 3 || W < 3) return ADAISP_ESHAPE;     // as adaisp_process: an image whose op is a stencil could not be served
     if (launch_pointwise(a, s) != hipSuccess) return ADAISP_ELAUNCH;
-    if (H >= 3 && W >= 3 && launch_conv(a, s) != hipSuccess) return ADAISP_ELAUNCH;
+    if (launch_conv(a, s) != hipSuccess) return ADAISP_ELAUNCH;
     if (launch_nlm(a, s) != hipSuccess) return ADAISP_ELAUNCH;
     if (pooled64_next && launch_pool64(out, pooled64_next, B, H, W, s) != hipSuccess) return ADAISP_ELAUNCH;
     return ADAISP_OK;

@@ -34,6 +34,7 @@ hipError_t launch_pointwise(const Batch& a, hipStream_t s);
 hipError_t launch_conv(const Batch& a, hipStream_t s);     // 3x3 sharpen, 3x3 sharpness, 5x5 USM
 hipError_t launch_nlm(const Batch& a, hipStream_t s);
 hipError_t launch_pool64(const float* img, float* pooled, int B, int H, int W, hipStream_t s);
+hipError_t launch_pool64_bwd(const float* grad_pooled, float* grad_img, int B, int H, int W, hipStream_t s);
 hipError_t launch_demosaic(const uint16_t* raw, float* out, int B, int H, int W, int pattern, float black, float white,
                            hipStream_t s);
 hipError_t launch_backward_params(const float* img, const float* grad_out, const int32_t* ids,

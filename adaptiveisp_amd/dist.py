@@ -54,7 +54,13 @@ class GradBucket:
         self.numel = sum(p.numel() for p in self.params)
         self.flat = None
 
+    @staticmethod
+    def _active():
+        return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
     def all_reduce_mean(self, async_op=False):
+        if not self._active():
+            return None                       # single process: the gradients stay where autograd put them
         dev = self.params[0].device
         if self.flat is None or self.flat.device != dev:
             self.flat = torch.zeros(self.numel, dtype=torch.float32, device=dev)
@@ -74,16 +80,18 @@ class GradBucket:
         return work
 
     def finish(self, work=None):
-        """Complete an async all-reduce (if any) and scatter the averaged bucket back into .grad."""
+        """Complete an async all-reduce (if any) and scatter the averaged bucket back into .grad. Parameters that
+        never enter the loss (the filters' fc_mask heads: masking is hard-wired off, isp/filters.py:161-162) keep
+        .grad = None as in the reference, so Adam creates no state for them and saved optimizer state matches."""
+        if not self._active():
+            return
         if work is not None:
             work.wait()
             self.flat.div_(dist.get_world_size())
         off = 0
         for p in self.params:
             n = p.numel()
-            if p.grad is None:
-                p.grad = self.flat[off:off + n].view_as(p).clone()
-            else:
+            if p.grad is not None:
                 p.grad.copy_(self.flat[off:off + n].view_as(p))
             off += n
 

@@ -38,9 +38,21 @@ class FeatureExtractor(nn.Module):
         return self.droupout(x) if hasattr(self, "droupout") else x
 
 
+class _Pool64Fn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        ctx.hw = (int(x.shape[2]), int(x.shape[3]))
+        return _lib.pool64(x)
+
+    @staticmethod
+    def backward(ctx, grad):
+        return _lib.pool64_backward(grad.contiguous(), *ctx.hw)
+
+
 class Pool64(nn.Module):
-    """nn.AdaptiveAvgPool2d((64,64)) as one HIP launch (adaisp_pool64). Images are constants of the RL
-    graph, so no gradient is propagated through the pooling."""
+    """nn.AdaptiveAvgPool2d((64,64)) as one HIP launch (adaisp_pool64), differentiable like the reference's module:
+    the critic's V(retouch, new_states) reaches the filter parameters through this pooling when cfg.use_TD
+    (train.py:281-305). Inputs that do not require grad (the dataset images) take the plain launch."""
 
     def __init__(self, size=(64, 64)):
         super().__init__()
@@ -48,5 +60,6 @@ class Pool64(nn.Module):
             raise NotImplementedError("the pooling kernel is built for the reference's 64x64 policy input")
 
     def forward(self, x):
-        with torch.no_grad():
-            return _lib.pool64(x.detach())
+        if torch.is_grad_enabled() and x.requires_grad:
+            return _Pool64Fn.apply(x)
+        return _lib.pool64(x.detach())

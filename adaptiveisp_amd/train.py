@@ -35,7 +35,7 @@ class Trainer:
         self.use_truncated, self.max_bri, self.rank, self.world = use_truncated, max_bri, rank, world
         self.max_iter_step = max(1, int(epochs * 1000 // (self.batch_size * world)))
         self.agent_optimizer = torch.optim.Adam(agent.parameters(), lr=lr)
-        self.value_optimizer = torch.optim.Adam(value.parameters(), lr=lr)
+        self.value_optimizer = torch.optim.Adam(value.parameters(), lr=lr * float(cfg.value_lr_mul))   # train.py:208-209
         lf = lr_lambda(self.max_iter_step)
         self.agent_scheduler = torch.optim.lr_scheduler.LambdaLR(self.agent_optimizer, lr_lambda=lf)
         self.value_scheduler = torch.optim.lr_scheduler.LambdaLR(self.value_optimizer, lr_lambda=lf)
@@ -82,3 +82,105 @@ class Trainer:
         path = os.path.join(self.save_dir, "ckpt-%d.pth" % it)           # train.py:473 naming
         save_isp_checkpoint(path, it, self.agent, self.value, self.agent_optimizer, self.value_optimizer)
         return path
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Launchable entry (BASELINE config 4): `python -m adaptiveisp_amd.train ...` on one GPU, or one process per GPU under
+#   python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 -m adaptiveisp_amd.train
+# The counterpart of train.py:620-660 (`DynamicISP(...).train()`), minus the dataset plumbing: the data source is
+# any object with `get_next_batch(n)` (dataset.py:921-931); without a dataset in the container the synthetic source
+# stands in.
+# ---------------------------------------------------------------------------------------------------------------
+def build_trainer(cfg, rank, world, device, batch_size, image_size, lr=3e-5, epochs=800, save_dir=None, sync_bn=False,
+                  detector_ckpt=None, isp_ckpt=None, source=None, seed=0, tune_cache=None):
+    """Everything one rank owns: its own replay pool in HBM (seeded by rank, so ranks draw different records), the
+    frozen detector on the HIP training engine, agent / value / optimizers. Rank 0's weights are broadcast."""
+    import random
+
+    from .agent import Agent
+    from .replay import DeviceReplayMemory, SyntheticSource
+    from .value import Value
+    from .yolo import YoloTrainEngine, yolov3
+    from .yolo.checkpoint import load_detector_checkpoint, load_isp_checkpoint
+    from .yolo.loss import DetectionLoss, default_hyp
+    H = W = int(image_size)
+    torch.manual_seed(seed)
+    agent = Agent(cfg, shape=(6 + len(cfg.filters), 64, 64), device=device).to(device)
+    value = Value(cfg, shape=(9 + len(cfg.filters), 64, 64)).to(device)
+    if isp_ckpt:
+        load_isp_checkpoint(isp_ckpt, agent, value, map_location=device)
+    det = load_detector_checkpoint(detector_ckpt) if detector_ckpt else yolov3()
+    det = det.to(device).train()
+    for m in det.modules():                                   # frozen reward model (train.py:236-243)
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.eval()
+    for p in det.parameters():
+        p.requires_grad_(False)
+    nc = det.model[-1].nc
+    loss_fn = DetectionLoss(det.model[-1].anchors, nc=nc, hyp=default_hyp(nc, H), device=device)
+    detector = YoloTrainEngine(det, batch_size, H, W, device=device)
+    if tune_cache:
+        detector.autotune(cache=tune_cache, write=(rank == 0))
+    if source is None:
+        source = SyntheticSource((3, H, W), nc=nc, seed=1000 * seed + rank, device=device)
+    replay = DeviceReplayMemory(cfg, source, batch_size, device, (3, H, W), rng=random.Random(1000 * seed + rank))
+    return Trainer(cfg, agent, value, detector, loss_fn, replay, batch_size=batch_size, lr=lr, epochs=epochs,
+                   save_dir=save_dir, rank=rank, world=world, sync_bn=sync_bn)
+
+
+def main(argv=None):
+    import argparse
+    import json
+    import time
+
+    from .config import cfg
+    ap = argparse.ArgumentParser(description="RL training of the ISP policy, data-parallel over the GPUs torchrun gives it")
+    ap.add_argument("--iters", type=int, default=None, help="iterations to run (default: the full schedule)")
+    ap.add_argument("--warmup", type=int, default=2, help="untimed iterations before the throughput clock starts")
+    ap.add_argument("--batch", type=int, default=8, help="per-rank batch (config 4: 8 x 8 GPUs = 64)")
+    ap.add_argument("--size", type=int, default=512, help="training image size (train.py --imgsz 512)")
+    ap.add_argument("--lr", type=float, default=3e-5)
+    ap.add_argument("--epochs", type=int, default=800)
+    ap.add_argument("--save-dir", default=None)
+    ap.add_argument("--sync-bn", action="store_true")
+    ap.add_argument("--detector-ckpt", default=None, help="yolov3.pt (pickled reference module)")
+    ap.add_argument("--isp-ckpt", default=None, help="ckpt-*.pth to resume from")
+    ap.add_argument("--seed", type=int, default=0)
+    a = ap.parse_args(argv)
+    rank, world, device = adist.init_from_env()
+    if device.type != "cuda":
+        raise SystemExit("adaptiveisp_amd.train needs a HIP device (the ISP and detector kernels have no CPU path)")
+    cache = os.path.join(os.path.dirname(os.path.abspath(__file__)), "yolo", "tuning", "mi355x.json")
+    tr = build_trainer(cfg, rank, world, device, a.batch, a.size, lr=a.lr, epochs=a.epochs, save_dir=a.save_dir,
+                       sync_bn=a.sync_bn, detector_ckpt=a.detector_ckpt, isp_ckpt=a.isp_ckpt, seed=a.seed, tune_cache=cache)
+    n = tr.max_iter_step + 1 if a.iters is None else a.iters
+    tr.train(min(a.warmup, n))
+
+    def fence():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    fence()
+    t0 = time.perf_counter()
+    tr.train(max(0, n - a.warmup))
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+    timed = max(0, n - a.warmup)
+    if rank == 0:
+        last = tr.history[-1] if tr.history else {}
+        print(json.dumps({"metric": "RL training images/sec", "value": round(world * a.batch * timed / dt, 2) if timed else None,
+                          "n_gpus": world, "iters": timed, "ms_per_iter": round(dt / max(timed, 1) * 1e3, 2),
+                          "per_gpu_batch": a.batch, "global_batch": a.batch * world, "image": f"{a.size}x{a.size}",
+                          "last": last}), flush=True)
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -185,11 +185,15 @@ class YoloEngine:
                 blocks = [m] if isinstance(m, Bottleneck) else list(m)
                 cur = src
                 for bi, blk in enumerate(blocks):
-                    hidden = _View(self._new(cur.H, cur.W, blk.cv1.conv.out_channels), 0, blk.cv1.conv.out_channels)
+                    # the hidden width is c2/2: 4 in the narrowest width-scaled checkpoints. Pad it to the kernels' 8-channel
+                    # granule with zero filters (SiLU(0) = 0 feeds zero weights: the result is unchanged)
+                    ch = (blk.cv1.conv.out_channels + 7) // 8 * 8
+                    hidden = _View(self._new(cur.H, cur.W, ch), 0, ch)
                     out = view[i] if bi == len(blocks) - 1 else \
                         _View(self._new(cur.H, cur.W, blk.cv2.conv.out_channels), 0, blk.cv2.conv.out_channels)
-                    w1, b1 = _pack_conv(*blk.cv1.folded())
-                    w2, b2 = _pack_conv(*blk.cv2.folded())
+                    w1, b1 = _pack_conv(*blk.cv1.folded(), pad_cout_to=ch)
+                    wf2, bf2 = blk.cv2.folded()
+                    w2, b2 = _pack_conv(torch.nn.functional.pad(wf2.detach().float(), (0, 0, 0, 0, 0, ch - wf2.shape[1])), bf2)
                     self._conv_op(cur, w1, b1, hidden, 1, 1, _lib.ACT_SILU)
                     self._conv_op(hidden, w2, b2, out, 3, 1, _lib.ACT_SILU, res=cur if blk.add else None)
                     cur = out

@@ -12,7 +12,8 @@ N GPUs = N independent replicas (one process per GPU, no data-path collective): 
 
 Prints ONE JSON line (rank 0). Extra objects: `roofline` (dominant kernel: the 128x128 implicit-GEMM conv,
 timed per launch with HIP events on the launch stream), `isp` (per-step ISP kernel times vs the HBM roof)
-and `cpu_baseline` (the CPU oracle + plain torch-CPU detector on a bounded sample, host cores of this box).
+and `cpu_baseline` (the reference's op chain restated on torch-CPU + plain torch-CPU detector on a bounded sample,
+host cores of this box; 1 warm-up + 3 repeats, min/median).
 """
 import argparse
 import json
@@ -231,38 +232,85 @@ def pmc_traffic(kernel_name):
     return best
 
 
+def _timed(fn, repeats=3):
+    """1 warm-up + `repeats` timed runs -> (min, median) seconds (SURVEY 8(d) protocol)."""
+    fn()
+    ts = []
+    for _ in range(repeats):
+        t0 = time.perf_counter()
+        fn()
+        ts.append(time.perf_counter() - t0)
+    ts.sort()
+    return ts[0], ts[len(ts) // 2]
+
+
 def cpu_baseline(a, sched):
-    """The CPU oracle (oracle/isp_oracle.c, OpenMP on all host cores) for the 5 ISP steps + plain torch-CPU fp32
-    for the detector, on ONE image of the batch (bounded sample); images/sec."""
+    """The hot path on the host cores of this box, on a BOUNDED sample: ONE image of the batch. Three ISP figures, each
+    1 warm-up + 3 repeats (min / median):
+      reference_faithful  oracle/torch_ref.py, the reference's own formulation: every RL step runs ALL 10 filters on the
+                          image (roll-based NLM, 8-pass tone, masked HSV), stacks them and keeps one by one-hot
+                          multiply-sum (agent.py:103-116,154); one step is timed, the episode is 5 of them (its cost
+                          does not depend on which filter is selected);
+      selected_only       the same torch ops, only the scheduled filter per step (5 steps timed);
+      c_oracle            oracle/isp_oracle.c (per-pixel gather form, OpenMP), the parity checker, 5 steps timed.
+    The detector is the plain fp32 module tree on torch-CPU with a warm-up. `value` = images/sec of
+    reference_faithful ISP + detector (medians)."""
     import numpy as np
     import oracle
+    from oracle import torch_ref
     from adaptiveisp_amd.yolo import yolov3
     oracle.build()
-    cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
+    ncpu = os.cpu_count() or 1
+    threads = max(1, min(ncpu, 64))          # one socket's worth: more threads only add oneDNN/OpenMP hand-over cost
+    torch.set_num_threads(threads)
     rng = np.random.default_rng(1235)
-    x = (rng.random((1, 3, a.height, a.width)) ** 2.2 * 0.5).astype(np.float32)
-    npar = {0: 1, 1: 1, 2: 9, 3: 1, 4: 1, 5: 8, 6: 1, 7: 1, 8: 1, 9: 3}
-    t0 = time.perf_counter()
-    cur = x
-    for op in sched:
-        oracle.pool64(cur)
-        p = (rng.random((1, npar[op])) * 0.8 + 0.6).astype(np.float32)
-        cur = oracle.forward(cur, op, p, clip=True)
-    t_isp = time.perf_counter() - t0
+    x_np = (rng.random((1, 3, a.height, a.width)) ** 2.2 * 0.5).astype(np.float32)
+    x = torch.from_numpy(x_np)
+    ops = list(range(10))
+    params = [torch.from_numpy((rng.random((1, torch_ref.NUM_PARAMS[op])) * 0.8 + 0.6).astype(np.float32)) for op in ops]
+    params[4] = torch.full((1, 1), 0.2)      # NLM h
+    with torch.no_grad():
+        sel = torch.tensor([sched[2 % len(sched)]])
+        step_min, step_med = _timed(lambda: torch_ref.policy_step(x, params, sel))
+
+        def selected_chain():
+            cur = x
+            for op in sched:
+                F.adaptive_avg_pool2d(cur, 64)
+                cur = torch_ref.forward(op, cur, params[op])
+            return cur
+        import torch.nn.functional as F
+        so_min, so_med = _timed(selected_chain)
+
+    def c_chain():
+        cur = x_np
+        for op in sched:
+            oracle.pool64(cur)
+            cur = oracle.forward(cur, op, params[op].numpy(), clip=True)
+        return cur
+    c_min, c_med = _timed(c_chain)
+    cur = c_chain()
     torch.manual_seed(1)
     det = yolov3().eval()
     Hp = (a.height + 31) // 32 * 32
     boxed = torch.full((1, 3, Hp, a.width), 114 / 255)
     boxed[:, :, (Hp - a.height) // 2:(Hp - a.height) // 2 + a.height] = torch.from_numpy(cur)
     with torch.no_grad():
-        t0 = time.perf_counter()
-        det(boxed)
-        t_det = time.perf_counter() - t0
-    return {"value": round(1.0 / (t_isp + t_det), 4), "unit": "images/sec", "cores": cores, "kind": "port",
-            "sample": f"1 image of the batch @{a.width}x{a.height}: 5 ISP steps {[NAMES[k] for k in sched]} with the C "
-                      f"oracle ({t_isp:.2f} s) + YOLOv3 fp32 torch-CPU forward ({t_det:.2f} s)",
-            "isp_s": round(t_isp, 3), "detector_s": round(t_det, 3)}
+        d_min, d_med = _timed(lambda: det(boxed))
+    nsteps = len(sched)
+    isp_ref = nsteps * step_med
+    r3 = lambda v: round(v, 3)  # noqa: E731
+    return {"value": round(1.0 / (isp_ref + d_med), 4), "unit": "images/sec", "cores": threads, "kind": "port",
+            "sample": f"1 image of the batch @{a.width}x{a.height}; ISP = {nsteps} x one reference-faithful RL step (all 10 "
+                      f"filters + one-hot select, torch-CPU op-for-op restatement oracle/torch_ref.py, median {step_med:.2f} s "
+                      f"per step) + YOLOv3 fp32 torch-CPU forward (median {d_med:.2f} s); 1 warm-up + 3 repeats each",
+            "protocol": "1 warm-up + 3 repeats, min/median", "torch": torch.__version__, "host_cpus": ncpu,
+            "isp_reference_faithful_s": {"per_step_min": r3(step_min), "per_step_median": r3(step_med),
+                                         "episode_median": r3(isp_ref)},
+            "isp_selected_only_s": {"schedule": [NAMES[k] for k in sched], "min": r3(so_min), "median": r3(so_med)},
+            "isp_c_oracle_s": {"schedule": [NAMES[k] for k in sched], "min": r3(c_min), "median": r3(c_med),
+                               "threads": ncpu},
+            "detector_s": {"min": r3(d_min), "median": r3(d_med)}}
 
 
 def main():

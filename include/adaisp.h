@@ -111,6 +111,14 @@ int adaisp_demosaic(const uint16_t* raw, float* out, int B, int H, int W, int pa
 /* AdaptiveAvgPool2d((64,64)) of a [B,3,H,W] image: agent.py:85,97, value.py:61,63. */
 int adaisp_pool64(const float* img, float* pooled, int B, int H, int W, void* stream);
 
+/*
+ * Backward of adaisp_pool64: grad_pooled [B,3,64,64] -> grad_img [B,3,H,W] (every pixel written). The critic sees the
+ * retouched image through this pooling (value.py:61-63) and, with cfg.use_TD, the agent loss back-propagates through
+ * V(retouch, new_states) into the filter parameters (train.py:281-305): this gradient enters adaisp_backward_params
+ * as part of grad_out.
+ */
+int adaisp_pool64_backward(const float* grad_pooled, float* grad_img, int B, int H, int W, void* stream);
+
 /* ---------------------------------------------------------------------------------------------------------
  * Fused eval path of one policy step (Agent.forward in eval mode, agent.py:88-285; FeatureExtractor
  * agent.py:26-60; Filter.extract_parameters / filter_param_regressor isp/filters.py:65-73 and per class).

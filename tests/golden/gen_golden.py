@@ -271,9 +271,43 @@ def main():
     gen_ckpt()
     gen_replay()
     gen_mosaic()
+    gen_value_path()
     tot = sum(os.path.getsize(os.path.join(HERE, f)) for f in os.listdir(HERE) if f.endswith(".npz"))
     print("fixtures written, total bytes:", tot)
 
+
+def gen_value_path():
+    """The critic-to-actor gradient (train.py:281-305 with cfg.use_TD): L = -mean(V(retouch, new_states)) where retouch
+    comes out of Agent.forward — the reference back-propagates through AdaptiveAvgPool2d and the selected filter into
+    that filter's heads. Eval-mode modules (no dropout, BN running statistics) with autograd on; teacher-forced so every
+    filter is covered. Records the gradient w.r.t. the selected filter's fc_filter weight/bias and agent.fc? none."""
+    filters, cfg, agent_mod, value_mod = import_reference()
+    T = torch.from_numpy
+    ag = agent_mod.Agent(cfg, shape=(6 + len(cfg.filters), 64, 64), device="cpu")
+    ag.load_state_dict(synth_state_dict(ag, seed=0))
+    ag.eval()
+    va = value_mod.Value(cfg, shape=(9 + len(cfg.filters), 64, 64))
+    va.load_state_dict(synth_state_dict(va, seed=1))
+    va.eval()
+    x = test_image(2, 72, 88, seed=41, special=False)
+    z = np.random.default_rng(42).random((2, cfg.z_dim)).astype(np.float32)
+    s0 = np.zeros((2, cfg.num_state_dim), np.float32)
+    out = {"x": x, "z": z, "s0": s0}
+    for k, flt in enumerate(ag.filters):
+        ag.zero_grad(set_to_none=True)
+        (xo, ns, sur, pen), dbg, _ = ag((T(x), T(z), T(s0)), 1.0, selected_filter_id=k)
+        v = va(xo, ns)
+        (-v.mean()).backward()
+        out[f"f{k}.value"] = v.detach().numpy()
+        out[f"f{k}.gw"] = flt.fc_filter.weight.grad.numpy().copy()
+        out[f"f{k}.gb"] = flt.fc_filter.bias.grad.numpy().copy()
+    np.savez_compressed(os.path.join(HERE, "value_path.npz"), **out)
+    print("value_path.npz:", {k: (v.shape, float(np.abs(v).max())) for k, v in out.items() if k.endswith(".gb")})
+
+
+if __name__ == "__main__" and "--value-path-only" in sys.argv:
+    gen_value_path()
+    sys.exit(0)
 
 if __name__ == "__main__" and "--eval-only" not in sys.argv and "--ckpt-only" not in sys.argv and "--replay-only" not in sys.argv and "--mosaic-only" not in sys.argv:
     main()

@@ -214,3 +214,51 @@ def test_device_side_sampling_train_mode(golden):
     # the same launch in eval mode is the arg-max
     e = fp.run(_lib.pool64(x), z, states, 0.25, None, train_mode=False)
     assert torch.equal(e["selected"].cpu(), torch.argmax(e["pdf"].cpu(), dim=1))
+
+
+@pytest.mark.parametrize("shape", [(2, 72, 100), (1, 30, 50), (2, 128, 64), (1, 720, 1280)])
+def test_pool64_backward_matches_aten(shape):
+    """adaisp_pool64_backward against autograd of nn.AdaptiveAvgPool2d((64,64)) (the reference's down_sample,
+    agent.py:85 / value.py:61): same window rule, same g/kh/kw, same accumulation order -> a few ulp at most."""
+    from adaptiveisp_amd import _lib
+    from adaptiveisp_amd.nets import Pool64
+    dev = torch.device("cuda:0")
+    B, H, W = shape
+    g = torch.Generator().manual_seed(H + W)
+    x = torch.rand(B, 3, H, W, generator=g).to(dev).requires_grad_(True)
+    go = torch.randn(B, 3, 64, 64, generator=g).to(dev)
+    y = Pool64()(x)
+    y.backward(go)
+    xr = x.detach().cpu().requires_grad_(True)
+    torch.nn.AdaptiveAvgPool2d((64, 64))(xr).backward(go.cpu())
+    torch.testing.assert_close(x.grad.cpu(), xr.grad, rtol=2e-6, atol=1e-9)
+    assert torch.equal(y.detach(), _lib.pool64(x.detach()))
+
+
+@pytest.mark.parametrize("k", range(10))
+def test_critic_to_actor_gradient_matches_reference(golden, k):
+    """train.py:281-305 with cfg.use_TD: agent_loss contains -V(retouch, new_states), so the critic back-propagates
+    through the 64x64 pooling and the selected filter into that filter's heads. Golden: the reference's autograd of
+    L = -mean(V(retouch, new_states)) (tests/golden/gen_golden.py::gen_value_path), teacher-forced filter k."""
+    from _synth import synth_state_dict
+    from adaptiveisp_amd.config import cfg
+    from adaptiveisp_amd.value import Value
+    g = golden("value_path")
+    ag, _, dev = _agent()
+    va = Value(cfg, shape=(9 + len(cfg.filters), 64, 64))
+    va.load_state_dict(synth_state_dict(va, seed=1))
+    va = va.to(dev).eval()
+    ag.zero_grad(set_to_none=True)
+    (xo, ns, sur, pen), dbg, _ = ag((T(g["x"]).to(dev), T(g["z"]).to(dev), T(g["s0"]).to(dev)), 1.0, selected_filter_id=k)
+    assert xo.requires_grad
+    v = va(xo, ns)
+    np.testing.assert_allclose(v.detach().cpu().numpy(), g[f"f{k}.value"], rtol=1e-3, atol=1e-4)
+    (-v.mean()).backward()
+    flt = ag.filters[k]
+    for got, key in ((flt.fc_filter.weight.grad, "gw"), (flt.fc_filter.bias.grad, "gb")):
+        ref = g[f"f{k}.{key}"]
+        assert got is not None and np.abs(ref).max() > 0
+        np.testing.assert_allclose(got.cpu().numpy(), ref, rtol=2e-3, atol=2e-3 * np.abs(ref).max())
+    for j, other in enumerate(ag.filters):                 # only the selected filter's heads see this gradient
+        if j != k and other.fc_filter.bias.grad is not None:
+            assert not other.fc_filter.bias.grad.any()

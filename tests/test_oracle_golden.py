@@ -52,3 +52,55 @@ def test_state_update_matches_agent_fixture(golden, oracle_mod):
                                                g["z"][:, 0], g[tag], train=False)
         assert np.array_equal(sel, g[f"{tag}.selected"])
         assert np.array_equal(ns, g[f"{tag}.new_states"])
+
+
+# ---- the torch-CPU op-for-op restatement (oracle/torch_ref.py: what bench.py's cpu_baseline times) -------------
+
+@pytest.mark.parametrize("name", sorted(OPS))
+@pytest.mark.parametrize("mode", ["process", "forward"])
+def test_torch_restatement_matches_reference(golden, name, mode):
+    """Same formulation as the reference (whole-tensor ops, masked HSV, 8-pass curves): same ATen kernels, so the
+    result is bit-identical except where a reduction's order is ATen's choice (conv) — there 1e-6."""
+    import torch
+    from oracle import torch_ref
+    g = golden("filters")
+    img, p = torch.from_numpy(g["img"]), torch.from_numpy(g[f"{name}.param"])
+    out = (torch_ref.process if mode == "process" else torch_ref.forward)(OPS[name], img, p).numpy()
+    ref = g[f"{name}.{mode}"]
+    if name in ("NLM", "USM", "Shr", "ShrV2"):
+        np.testing.assert_allclose(out, ref, rtol=0, atol=1e-6)
+    else:
+        assert np.array_equal(out, ref), f"{name}: {np.abs(out - ref).max()}"
+
+
+@pytest.mark.parametrize("tag", ["a", "tiny", "odd"])
+def test_torch_restatement_nlm_wraparound(golden, tag):
+    import torch
+    from oracle import torch_ref
+    g = golden("nlm")
+    out = torch_ref.forward(torch_ref.NLM, torch.from_numpy(g[f"{tag}.img"]), torch.from_numpy(g[f"{tag}.h"])).numpy()
+    np.testing.assert_allclose(out, g[f"{tag}.out"], rtol=0, atol=1e-6)
+
+
+def test_torch_policy_step_all_filters_vs_selected_only(golden, oracle_mod):
+    """The reference's stack + one-hot select (agent.py:103-116,154) equals running only the selected filter per image,
+    equals the C oracle's mixed-id call; id -1 (u = 0) gives the zero image in all three."""
+    import torch
+    from oracle import torch_ref
+    g = golden("filters")
+    img = torch.from_numpy(np.concatenate([g["img"], g["img"][::-1]], 0).copy())      # 4 images
+    names = ["E", "G", "CCM", "Shr", "NLM", "T", "Ct", "Sp", "BW", "W"]
+    params = [torch.from_numpy(np.concatenate([g[f"{n}.param"], g[f"{n}.param"][::-1]], 0).copy()) for n in names]
+    sel = torch.tensor([5, -1, 2, 7])
+    full = torch_ref.policy_step(img, params, sel)
+    only = torch_ref.policy_step(img, params, sel, selected_only=True)
+    np.testing.assert_allclose(full.numpy(), only.numpy(), rtol=0, atol=1e-7)
+    assert not full[1].any()
+    packed = np.zeros((4, 24), np.float32)
+    for b, j in enumerate(sel.tolist()):
+        if j >= 0:
+            q = params[j][b].reshape(-1).numpy()
+            packed[b, :q.size] = q
+    ids = np.array([j if j >= 0 else -1 for j in sel.tolist()], np.int32)
+    ref = oracle_mod.forward(img.numpy(), ids, packed, clip=True)
+    np.testing.assert_allclose(full.numpy(), ref, rtol=0, atol=5e-7)
