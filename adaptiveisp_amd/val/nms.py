@@ -2,7 +2,8 @@
 (csrc/yolo_nms.hip through the C-ABI `adayolo_nms`, replacing `torchvision.ops.nms` :949).
 
 Differences from the reference, deliberate: no wall-clock time limit (general.py:891,962-964 aborts after
-0.5 s + 0.05 s/image, which makes results machine-dependent) and no merge-NMS branch (dead code there, `merge = False`).
+0.5 s + 0.05 s/image, which makes results machine-dependent), no merge-NMS branch (dead code there, `merge = False`),
+and the candidate selection runs once for the batch instead of once per image.
 """
 import ctypes
 
@@ -37,51 +38,77 @@ def hip_nms(boxes, scores, iou_thres, max_det=300):
     return order[keep[:k].long()]
 
 
+def _with_label_rows(pred, labels, nc, nm):
+    """Autolabelling priors (general.py:911-918): per image, rows (xywh of the label, obj 1, its class 1) are added to
+    the candidates unconditionally. Returns the padded prediction and a mask of the rows that are such priors."""
+    B, N, C = pred.shape
+    extra = max((len(lb) for lb in labels), default=0)
+    forced = torch.zeros((B, N + extra), dtype=torch.bool, device=pred.device)
+    if extra == 0:
+        return pred, forced
+    pred = torch.cat((pred, pred.new_zeros((B, extra, C))), 1)
+    for b, lb in enumerate(labels):
+        k = len(lb)
+        if k:
+            rows = pred[b, N:N + k]
+            rows[:, :4] = lb[:, 1:5]
+            rows[:, 4] = 1.0
+            rows[torch.arange(k), lb[:, 0].long() + 5] = 1.0
+            forced[b, N:N + k] = True
+    return pred, forced
+
+
 def non_max_suppression(prediction, conf_thres=0.25, iou_thres=0.45, classes=None, agnostic=False, multi_label=False,
                         labels=(), max_det=300, nm=0, nms_fn=None):
-    """prediction [B, N, 5+nc(+nm)] (xywh, obj, cls...) -> list of [n,6(+nm)] (xyxy, conf, cls) per image.
-    `nms_fn(boxes, scores, iou_thres)` defaults to the HIP kernel; tests inject the CPU oracle."""
-    assert 0 <= conf_thres <= 1, f"Invalid Confidence threshold {conf_thres}, valid values are between 0.0 and 1.0"
-    assert 0 <= iou_thres <= 1, f"Invalid IoU {iou_thres}, valid values are between 0.0 and 1.0"
+    """prediction [B, N, 5+nc(+nm)] (xywh, obj, cls...) -> list of [n,6(+nm)] (xyxy, conf, cls) per image — the
+    results of yolov3/utils/general.py:856-966 (pinned by tests/golden/evalharness.npz).
+
+    The candidates of the WHOLE batch are extracted once (one threshold, one gather, one score product, one box
+    conversion); images are then contiguous segments of that list, each sorted by score and handed to the greedy NMS
+    with the per-class coordinate offset. `nms_fn(boxes, scores, iou_thres)` defaults to the HIP kernel; tests inject
+    the CPU oracle."""
+    if not 0 <= conf_thres <= 1:
+        raise ValueError(f"confidence threshold {conf_thres} outside [0, 1]")
+    if not 0 <= iou_thres <= 1:
+        raise ValueError(f"IoU threshold {iou_thres} outside [0, 1]")
     if isinstance(prediction, (list, tuple)):
         prediction = prediction[0]
     if nms_fn is None:
         nms_fn = lambda b, s, t: hip_nms(b, s, t, max_det)       # noqa: E731
-    bs = prediction.shape[0]
+    B = prediction.shape[0]
     nc = prediction.shape[2] - nm - 5
-    xc = prediction[..., 4] > conf_thres
-    multi_label &= nc > 1
-    mi = 5 + nc
-    output = [torch.zeros((0, 6 + nm), device=prediction.device)] * bs
-    for xi, x in enumerate(prediction):
-        x = x[xc[xi]]
-        if labels and len(labels[xi]):
-            lb = labels[xi]
-            v = torch.zeros((len(lb), nc + nm + 5), device=x.device)
-            v[:, :4] = lb[:, 1:5]
-            v[:, 4] = 1.0
-            v[range(len(lb)), lb[:, 0].long() + 5] = 1.0
-            x = torch.cat((x, v), 0)
-        if not x.shape[0]:
+    first_mask = 5 + nc
+    candidate = prediction[..., 4] > conf_thres
+    if labels and any(len(lb) for lb in labels):
+        prediction, forced = _with_label_rows(prediction, labels, nc, nm)
+        candidate = torch.cat((candidate, candidate.new_zeros((B, forced.shape[1] - candidate.shape[1]))), 1) | forced
+    image, row = candidate.nonzero(as_tuple=True)                  # image-major: every image is one contiguous run
+    cand = prediction[image, row]
+    scaled = cand[:, 5:] * cand[:, 4:5]                            # class scores (and mask coefficients) x objectness
+    scores, coeff = scaled[:, :nc], scaled[:, nc:]
+    box = xywh2xyxy(cand[:, :4])
+    if multi_label and nc > 1:                                     # one detection per (box, class) above the threshold
+        r, c = (scores > conf_thres).nonzero(as_tuple=True)
+        det = torch.cat((box[r], scores[r, c, None], c[:, None].float(), coeff[r]), 1)
+        image = image[r]
+    else:                                                          # best class only
+        conf, c = scores.max(1, keepdim=True)
+        keep = conf.view(-1) > conf_thres
+        det = torch.cat((box, conf, c.float(), coeff), 1)[keep]
+        image = image[keep]
+    if classes is not None:
+        wanted = (det[:, 5:6] == torch.tensor(classes, device=det.device)).any(1)
+        det, image = det[wanted], image[wanted]
+    counts = torch.bincount(image, minlength=B).tolist()
+    output, start = [], 0
+    for n in counts:
+        seg = det[start:start + n]
+        start += n
+        if n == 0:
+            output.append(torch.zeros((0, 6 + nm), device=prediction.device))
             continue
-        x[:, 5:] *= x[:, 4:5]                                      # conf = obj_conf * cls_conf
-        box = xywh2xyxy(x[:, :4])
-        mask = x[:, mi:]
-        if multi_label:
-            i, j = (x[:, 5:mi] > conf_thres).nonzero(as_tuple=False).T
-            x = torch.cat((box[i], x[i, 5 + j, None], j[:, None].float(), mask[i]), 1)
-        else:
-            conf, j = x[:, 5:mi].max(1, keepdim=True)
-            x = torch.cat((box, conf, j.float(), mask), 1)[conf.view(-1) > conf_thres]
-        if classes is not None:
-            x = x[(x[:, 5:6] == torch.tensor(classes, device=x.device)).any(1)]
-        n = x.shape[0]
-        if not n:
-            continue
-        x = x[x[:, 4].argsort(descending=True)[:MAX_NMS]]
-        c = x[:, 5:6] * (0 if agnostic else MAX_WH)
-        boxes, scores = x[:, :4] + c, x[:, 4]
-        i = nms_fn(boxes, scores, iou_thres)
-        i = i[:max_det]
-        output[xi] = x[i]
+        seg = seg[seg[:, 4].argsort(descending=True)[:MAX_NMS]]
+        offset = seg[:, 5:6] * (0 if agnostic else MAX_WH)         # classes never suppress each other
+        kept = nms_fn(seg[:, :4] + offset, seg[:, 4], iou_thres)[:max_det]
+        output.append(seg[kept])
     return output

@@ -125,3 +125,33 @@ def test_run_eval_on_cpu_with_oracle(oracle_mod, tmp_path):
     lines = rec.read_text().strip().split("\n")
     assert lines[0].split(",") == res["filter_names"] and len(lines) == 3 and lines[1].startswith("a.png,")
     assert all(len(l.split(",")) == 4 for l in lines[1:])
+
+
+def test_nms_label_priors_and_empty_images(oracle_mod):
+    """Autolabelling priors (general.py:911-918) enter as confidence-1 detections of their class even when no
+    prediction passes the threshold; images without candidates give empty [0,6] results."""
+    from adaptiveisp_amd.val import non_max_suppression
+    pred = torch.zeros(3, 6, 5 + 4)
+    pred[..., :4] = torch.tensor([50.0, 50.0, 10.0, 10.0])
+    pred[1, 2, 4], pred[1, 2, 5 + 1] = 0.9, 0.8                      # one real detection in image 1
+    labels = [torch.tensor([[2.0, 10.0, 10.0, 4.0, 4.0]]), torch.zeros((0, 5)), torch.zeros((0, 5))]
+    out = non_max_suppression(pred, conf_thres=0.25, iou_thres=0.5, labels=labels, nms_fn=_oracle_nms_fn(oracle_mod, 300))
+    assert [o.shape for o in out] == [(1, 6), (1, 6), (0, 6)]
+    np.testing.assert_allclose(out[0][0].numpy(), [8, 8, 12, 12, 1.0, 2.0])
+    np.testing.assert_allclose(out[1][0].numpy(), [45, 45, 55, 55, 0.9 * 0.8, 1.0], rtol=1e-6)
+    with pytest.raises(ValueError):
+        non_max_suppression(pred, conf_thres=1.5)
+
+
+def test_matching_rule_edge_cases():
+    from adaptiveisp_amd.val import process_batch
+    iouv = torch.linspace(0.5, 0.95, 10)
+    lab = torch.tensor([[0.0, 0, 0, 10, 10], [1.0, 20, 20, 30, 30]])
+    det = torch.tensor([[0, 0, 10, 10, 0.9, 0.0],        # perfect on label 0
+                        [0, 0, 10, 9, 0.8, 0.0],         # IoU 0.9 with label 0, already taken by detection 0
+                        [20, 20, 30, 30, 0.7, 0.0],      # right box, wrong class
+                        [21, 20, 30, 30, 0.6, 1.0]])     # IoU 0.9 with label 1
+    c = process_batch(det, lab, iouv)
+    assert c[0].all() and not c[1].any() and not c[2].any()
+    assert c[3].tolist() == [True] * 9 + [False]
+    assert process_batch(det[:0], lab, iouv).shape == (0, 10) and not process_batch(det, lab[:0], iouv).any()

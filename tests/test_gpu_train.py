@@ -115,7 +115,8 @@ def test_train_iteration_with_hip_detector_matches_torch_detector():
         class Bucket(adist.GradBucket):                      # capture the pre-clip gradient
             def finish(self, work=None):
                 super().finish(work)
-                captured[id(self)] = self.flat.clone()
+                captured[id(self)] = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1)
+                                                for p in self.params]).clone()
 
         bk = [Bucket(agent), Bucket(value)]
         torch.manual_seed(7)                                 # same dropout masks / sampling in both runs
@@ -124,7 +125,12 @@ def test_train_iteration_with_hip_detector_matches_torch_detector():
         outs.append(out)
         grads.append(captured[id(bk[0])])
     a, b = outs
-    assert torch.allclose(a["reward"], b["reward"], rtol=0.1, atol=2.0), (a["reward"], b["reward"])
-    assert abs(float(a["value_loss"]) - float(b["value_loss"])) <= 0.1 * abs(float(a["value_loss"])) + 1.0
+    # measured on MI355X: reward differs by <= 2.2e-3 (it is 100 x a DIFFERENCE of two detection losses, each carrying
+    # the bf16 detector's ~1e-3 relative noise), value loss by 0.2 %, pre-clip head gradient: cosine 0.9999992,
+    # relative error 0.33 %
+    assert torch.allclose(a["reward"], b["reward"], rtol=0.02, atol=6e-3), (a["reward"], b["reward"])
+    assert abs(float(a["value_loss"].detach()) - float(b["value_loss"].detach())) <= 0.01 * abs(float(a["value_loss"].detach()))
     cos = torch.nn.functional.cosine_similarity(grads[0].reshape(1, -1), grads[1].reshape(1, -1)).item()
-    assert cos > 0.95, cos
+    assert cos > 0.9995, cos
+    rel = ((grads[0] - grads[1]).norm() / grads[0].norm()).item()
+    assert rel < 0.02, rel
