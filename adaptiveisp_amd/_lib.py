@@ -17,6 +17,7 @@ MAX_PARAMS = 24
 CLIP01 = 1
 NLM_EXACT = 2      # NLM patch sums in the reference's running-sum order (slower); default is the separable kernel
 NLM_SEP_V1 = 4     # the compiler-scheduled form of the separable kernel (cross-check / measurement)
+NO_USM = 8         # adaisp_forward: no image selects the unsharp mask (its empty launch is skipped)
 ABI_VERSION = 3
 
 EXPORTS = ("adaisp_forward", "adaisp_process", "adaisp_backward_params", "adaisp_pool64", "adaisp_pool64_backward", "adaisp_demosaic", "adaisp_num_params",
@@ -101,7 +102,7 @@ def process(op, img, params, clip=False, out=None, nlm_exact=False, nlm_v1=False
     return out
 
 
-def forward(img, op_ids, params, clip=True, pooled=None, out=None, nlm_exact=False):
+def forward(img, op_ids, params, clip=True, pooled=None, out=None, nlm_exact=False, no_usm=False):
     """adaisp_forward: image b is filtered by op_ids[b] (int32, device). params [B,stride]."""
     L = load()
     img = _dev_f32(img, "img")
@@ -115,7 +116,8 @@ def forward(img, op_ids, params, clip=True, pooled=None, out=None, nlm_exact=Fal
     with torch.cuda.device(img.device):
         rc = L.adaisp_forward(img.data_ptr(), out.data_ptr(), pooled.data_ptr() if pooled is not None else None,
                               op_ids.data_ptr(), params.data_ptr(), params.shape[1], B, H, W,
-                              (CLIP01 if clip else 0) | (NLM_EXACT if nlm_exact else 0), _stream())
+                              (CLIP01 if clip else 0) | (NLM_EXACT if nlm_exact else 0) | (NO_USM if no_usm else 0),
+                              _stream())
     _check(rc, "adaisp_forward")
     return out
 

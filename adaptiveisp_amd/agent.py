@@ -92,8 +92,9 @@ class Agent(nn.Module):
             from .policy_fast import FastPolicy
             self._fast = FastPolicy(self)
         o = self._fast.run(self.down_sample(x), z, states, progress, selected_filter_id)
-        x_out = _lib.forward(x, o["op_ids"], o["packed"], clip=True)
-        hr_out = _lib.forward(high_res, o["op_ids"], o["packed"], clip=True) if high_res is not None else None
+        no_usm = _lib.OP_USM not in self._op_table_host
+        x_out = _lib.forward(x, o["op_ids"], o["packed"], clip=True, no_usm=no_usm)
+        hr_out = _lib.forward(high_res, o["op_ids"], o["packed"], clip=True, no_usm=no_usm) if high_res is not None else None
         mask = torch.ones((1, 1, 1, 1), dtype=torch.float32, device=x.device)
         fdi = []
         for j, flt in enumerate(self.filters):

@@ -7,6 +7,7 @@
 //
 // Reference: isp/sharpen.py:105-142 (adjust_sharpness), :145-182 (sharpness), :63-102 (unsharp_mask).
 #include "isp_internal.h"
+#include <cstdlib>
 
 namespace adaisp {
 namespace {
@@ -146,13 +147,16 @@ __device__ void conv_tile(float* __restrict__ lds, const float* __restrict__ in,
 
 // ---------------------------------------------------------------------------------------------------------
 // Row-sliding variant (used whenever rows are 16-byte aligned): no LDS at all. A wave owns a 256-px wide strip of
-// ONE plane and walks down RS output rows; each lane holds 4 consecutive pixels of the current 3 (5) input rows
+// ONE plane and walks down `rs` output rows; each lane holds 4 consecutive pixels of the current 3 (5) input rows
 // in registers and gets its horizontal neighbours from the adjacent lanes with DPP wave shifts
 // (v_mov_b32_dpp wave_shl/shr). Every input row is loaded once per strip with one coalesced 16-B load per lane
-// ((RS+2R)/RS re-read factor along y only), every output row is one 16-B store per lane.
+// ((rs+2R)/rs re-read factor along y only), every output row is one 16-B store per lane.
+//
+// The walk is software-pipelined in groups of G = 2R+1 rows: the 16-B loads of the NEXT group (and the two strip-edge
+// lanes' outside neighbours) are all issued before the current group is computed, so a wave keeps G rows in flight
+// instead of one (one load per trip = one full memory round trip per row: 4.4 TB/s at 4K; the kernel is HBM-bound).
+// With G rows per group the 2R+1-row window is a register ring with compile-time slots: no row shifting moves.
 // ---------------------------------------------------------------------------------------------------------
-constexpr int RS = 16;                          // output rows per wave
-
 __device__ __forceinline__ float dpp_from_prev(float v) {   // lane i <- lane i-1
     return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0x138, 0xF, 0xF, false));
 }
@@ -160,52 +164,68 @@ __device__ __forceinline__ float dpp_from_next(float v) {   // lane i <- lane i+
     return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0x130, 0xF, 0xF, false));
 }
 
-// one input row of this lane: its 4 pixels plus R neighbours on each side -> v[0 .. 4+2R)
+struct RawRow {          // what a lane fetches for one input row: its 4 pixels + (strip-edge lanes only) 2 outside pixels
+    float4 c;
+    float e0, e1;        // left edge lane: (x-2, x-1); right edge lane: (x+4, x+5); R = 1 uses e1 (left) / e0 (right)
+};
+
+// issue the loads of input row y; nothing is consumed here, so consecutive calls put all their loads in flight
 template <int R, int MODE>
-__device__ __forceinline__ void load_row(const float* __restrict__ src, int y, int H, int W, int gx, int lane,
-                                         bool active, float* v) {
+__device__ __forceinline__ void issue_row(const float* __restrict__ src, int y, int H, int W, int gx, bool active,
+                                          bool edge_l, bool edge_r, RawRow& r) {
     int yy = y;
     if (MODE == kUSM) yy = reflect(y, H);
     const bool row_ok = yy >= 0 && yy < H;
-    float4 c = make_float4(0.f, 0.f, 0.f, 0.f);
     const float* rowp = src + (long)(row_ok ? yy : 0) * W;
-    if (active && row_ok) c = *reinterpret_cast<const float4*>(rowp + gx);
+    r.c = make_float4(0.f, 0.f, 0.f, 0.f);
+    r.e0 = 0.f; r.e1 = 0.f;
+    if (active && row_ok) {
+        r.c = *reinterpret_cast<const float4*>(rowp + gx);
+        if (edge_l) {
+            if (MODE == kUSM) { r.e0 = rowp[reflect(gx - 2, W)]; r.e1 = rowp[reflect(gx - 1, W)]; }
+            else if (gx > 0) r.e1 = rowp[gx - 1];
+        } else if (edge_r) {                               // lane 63 of a strip that is not the image's last: gx + 5 < W
+            r.e0 = rowp[gx + 4];
+            if (MODE == kUSM) r.e1 = rowp[gx + 5];
+        }
+    }
+}
+
+// the lane's 4 pixels plus R neighbours on each side -> v[0 .. 4+2R)
+template <int R, int MODE>
+__device__ __forceinline__ void finish_row(const RawRow& r, bool active, bool edge_l, bool edge_r, bool last_col,
+                                           float* v) {
+    const float4 c = r.c;
     v[R + 0] = c.x; v[R + 1] = c.y; v[R + 2] = c.z; v[R + 3] = c.w;
-    // neighbours inside the wave
     float l1 = dpp_from_prev(c.w), r1 = dpp_from_next(c.x);
     float l2 = 0.f, r2 = 0.f;
     if (R == 2) { l2 = dpp_from_prev(c.z); r2 = dpp_from_next(c.y); }
-    // strip edges: the first lane and the last active lane fetch their outside neighbours themselves
-    if (lane == 0 || !active) {
-        l1 = 0.f; l2 = 0.f;
-        if (active && row_ok) {
-            if (MODE == kUSM) { l1 = rowp[reflect(gx - 1, W)]; l2 = rowp[reflect(gx - 2, W)]; }
-            else if (gx > 0) l1 = rowp[gx - 1];
-        }
-    }
-    if (lane == 63 || gx + 4 >= W) {
-        r1 = 0.f; r2 = 0.f;
-        if (active && row_ok) {
-            if (MODE == kUSM) { r1 = rowp[reflect(gx + 4, W)]; r2 = rowp[reflect(gx + 5, W)]; }
-            else if (gx + 4 < W) r1 = rowp[gx + 4];
-        }
+    if (edge_l || !active) { l2 = r.e0; l1 = r.e1; }        // inactive lanes hold zeros
+    if (edge_r) { r1 = r.e0; r2 = r.e1; }
+    if (last_col) {                                          // the image's right border (W % 4 == 0: gx + 4 == W)
+        // reflect(W) = W - 2, reflect(W + 1) = W - 3: the lane's own pixels; the 3x3 filters see zero (and keep the frame)
+        r1 = (MODE == kUSM) ? c.z : 0.f;
+        r2 = (MODE == kUSM) ? c.y : 0.f;
     }
     if (R == 1) { v[0] = l1; v[5] = r1; }
     else { v[0] = l2; v[1] = l1; v[6] = r1; v[7] = r2; }
 }
 
-template <int R, int MODE>
+template <int R, int MODE, int NG>
 __device__ void conv_rows(const float* __restrict__ in, float* __restrict__ out, const float* __restrict__ p, int H,
-                          int W, int c, int strip, int band) {
+                          int W, int c, int strip, int band, int rs) {
+    constexpr int G = 2 * R + 1, GS = G * NG;        // ring period, rows per pipeline group
     const int lane = threadIdx.x & 63;
     const long plane = (long)H * W;
     const float* src = in + c * plane;
     float* dst = out + c * plane;
     const int gx = strip * 256 + 4 * lane;
     const bool active = gx < W;                      // W % 4 == 0 on this path
-    const int y_begin = band * RS, y_end = min(H, y_begin + RS);
+    const bool last_col = active && gx + 4 >= W;
+    const bool edge_l = lane == 0, edge_r = lane == 63 && active && !last_col;
+    const int y_begin = band * rs, y_end = min(H, y_begin + rs);
 
-    float w[2 * R + 1][2 * R + 1];
+    float w[G][G];
     float amount;
     if (MODE == kUSM) {
         const float sigma = p[0];
@@ -220,65 +240,86 @@ __device__ void conv_rows(const float* __restrict__ in, float* __restrict__ out,
 #pragma unroll
         for (int i = 0; i < 5; ++i) g1[i] = g1[i] / sum;
 #pragma unroll
-        for (int i = 0; i < 2 * R + 1; ++i)
+        for (int i = 0; i < G; ++i)
 #pragma unroll
-            for (int j = 0; j < 2 * R + 1; ++j) w[i][j] = g1[i] * g1[j];
+            for (int j = 0; j < G; ++j) w[i][j] = g1[i] * g1[j];
     } else {
         amount = p[0];
         const float a = 1.0f / 13.0f, c5 = 5.0f / 13.0f;
 #pragma unroll
-        for (int i = 0; i < 2 * R + 1; ++i)
+        for (int i = 0; i < G; ++i)
 #pragma unroll
-            for (int j = 0; j < 2 * R + 1; ++j) w[i][j] = (i == R && j == R) ? c5 : a;
+            for (int j = 0; j < G; ++j) w[i][j] = (i == R && j == R) ? c5 : a;
     }
 
-    float rows[2 * R + 1][4 + 2 * R];                // sliding window of input rows y-R .. y+R
+    // ring of input rows: row (y_begin - R + n) lives in slot n % G
+    float win[G][4 + 2 * R];
+    RawRow cur[GS], nxt[GS];
+    {
+        RawRow head[2 * R];
 #pragma unroll
-    for (int i = 0; i < 2 * R; ++i) load_row<R, MODE>(src, y_begin - R + i, H, W, gx, lane, active, rows[i + 1]);
-    for (int y = y_begin; y < y_end; ++y) {
+        for (int i = 0; i < 2 * R; ++i) issue_row<R, MODE>(src, y_begin - R + i, H, W, gx, active, edge_l, edge_r, head[i]);
 #pragma unroll
-        for (int i = 0; i < 2 * R; ++i)
+        for (int u = 0; u < GS; ++u)
+            issue_row<R, MODE>(src, y_begin + R + u, H, W, gx, active, edge_l, edge_r, cur[u]);
 #pragma unroll
-            for (int j = 0; j < 4 + 2 * R; ++j) rows[i][j] = rows[i + 1][j];
-        load_row<R, MODE>(src, y + R, H, W, gx, lane, active, rows[2 * R]);
-        float o[4];
+        for (int i = 0; i < 2 * R; ++i) finish_row<R, MODE>(head[i], active, edge_l, edge_r, last_col, win[i]);
+    }
+    for (int y0 = y_begin; y0 < y_end; y0 += GS) {
+        // loads of the next group first (rows past the band's last input row are never consumed: skip them)
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            float blur = 0.0f;
-#pragma unroll
-            for (int i = 0; i < 2 * R + 1; ++i)
-#pragma unroll
-                for (int j = 0; j < 2 * R + 1; ++j) blur = fmaf(w[i][j], rows[i][k + j], blur);
-            const float ctr = rows[R][k + R];
-            if (MODE != kUSM) {
-                const int xx = gx + k;
-                if (y == 0 || y == H - 1 || xx == 0 || xx >= W - 1) blur = ctr;
-            }
-            const float r = (MODE == kAdjust) ? ctr * amount + blur * (1.0f - amount) : ctr + (ctr - blur) * amount;
-            o[k] = clamp01(r);
+        for (int u = 0; u < GS; ++u) {
+            const int yn = y0 + GS + u;                  // output row that would need input row yn + R
+            if (yn < y_end) issue_row<R, MODE>(src, yn + R, H, W, gx, active, edge_l, edge_r, nxt[u]);
+            else { nxt[u].c = make_float4(0.f, 0.f, 0.f, 0.f); nxt[u].e0 = 0.f; nxt[u].e1 = 0.f; }
         }
-        if (active) *reinterpret_cast<float4*>(dst + (long)y * W + gx) = make_float4(o[0], o[1], o[2], o[3]);
+#pragma unroll
+        for (int u = 0; u < GS; ++u) {
+            const int y = y0 + u;
+            finish_row<R, MODE>(cur[u], active, edge_l, edge_r, last_col, win[(u + 2 * R) % G]);   // input row y + R
+            float o[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float blur = 0.0f;
+#pragma unroll
+                for (int i = 0; i < G; ++i)
+#pragma unroll
+                    for (int j = 0; j < G; ++j) blur = fmaf(w[i][j], win[(u + i) % G][k + j], blur);
+                const float ctr = win[(u + R) % G][k + R];
+                if (MODE != kUSM) {
+                    const int xx = gx + k;
+                    if (y == 0 || y == H - 1 || xx == 0 || xx >= W - 1) blur = ctr;
+                }
+                const float r = (MODE == kAdjust) ? ctr * amount + blur * (1.0f - amount) : ctr + (ctr - blur) * amount;
+                o[k] = clamp01(r);
+            }
+            if (active && y < y_end) *reinterpret_cast<float4*>(dst + (long)y * W + gx) = make_float4(o[0], o[1], o[2], o[3]);
+        }
+#pragma unroll
+        for (int u = 0; u < GS; ++u) cur[u] = nxt[u];
     }
 }
 
+// R = 1: the two 3x3 sharpeners; R = 2: the 5x5 unsharp mask (its own kernel: the 5-row pipeline needs 134 VGPRs, which
+// would cost the 3x3 filters two of their five waves per SIMD).
+template <int R, int NG>
 __global__ __launch_bounds__(kThreads) void k_conv_rows(const float* __restrict__ img, float* __restrict__ out,
                                                         const int32_t* __restrict__ ids, int uniform_op,
                                                         const float* __restrict__ params, int pstride, int H, int W,
-                                                        int strips) {
+                                                        int strips, int rs) {
     const int b = blockIdx.z;
     const int op = ids ? ids[b] : uniform_op;
-    if (op != ADAISP_OP_SHARPEN && op != ADAISP_OP_SHARPEN_V2 && op != ADAISP_OP_USM) return;
+    if (R == 1 && op != ADAISP_OP_SHARPEN && op != ADAISP_OP_SHARPEN_V2) return;
+    if (R == 2 && op != ADAISP_OP_USM) return;
     const int wave = threadIdx.x >> 6;
     const int band = blockIdx.y * 4 + wave;          // 4 waves = 4 consecutive row bands
-    if (band * RS >= H) return;
+    if (band * rs >= H) return;
     const int c = blockIdx.x / strips, strip = blockIdx.x - c * strips;
     const long off = (long)b * 3 * H * W;
     const float* p = params + (long)b * pstride;
-    switch (op) {
-        case ADAISP_OP_SHARPEN:    conv_rows<1, kAdjust>(img + off, out + off, p, H, W, c, strip, band); break;
-        case ADAISP_OP_SHARPEN_V2: conv_rows<1, kSharpness>(img + off, out + off, p, H, W, c, strip, band); break;
-        default:                   conv_rows<2, kUSM>(img + off, out + off, p, H, W, c, strip, band); break;
-    }
+    if (R == 2) conv_rows<2, kUSM, NG>(img + off, out + off, p, H, W, c, strip, band, rs);
+    else if (op == ADAISP_OP_SHARPEN) conv_rows<1, kAdjust, NG>(img + off, out + off, p, H, W, c, strip, band, rs);
+    else conv_rows<1, kSharpness, NG>(img + off, out + off, p, H, W, c, strip, band, rs);
 }
 
 template <bool VEC>
@@ -301,13 +342,36 @@ __global__ __launch_bounds__(kThreads) void k_conv(const float* __restrict__ img
 }  // namespace
 
 hipError_t launch_conv(const Batch& a, hipStream_t s) {
-    const bool vec = (a.W % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.img) & 15) == 0) &&
+    const bool vec = (a.W % 4 == 0) && (a.W >= 8) && ((reinterpret_cast<uintptr_t>(a.img) & 15) == 0) &&
                      ((reinterpret_cast<uintptr_t>(a.out) & 15) == 0);
     dim3 grid((a.W + TW - 1) / TW, (a.H + TH - 1) / TH, a.B);
     if (vec) {
-        const int strips = (a.W + 255) / 256, bands = (a.H + RS - 1) / RS;
-        hipLaunchKernelGGL(k_conv_rows, dim3(3 * strips, (bands + 3) / 4, a.B), dim3(kThreads), 0, s, a.img, a.out,
-                           a.ids, a.uniform_op, a.params, a.pstride, a.H, a.W, strips);
+        // rows per wave: taller bands re-read fewer halo rows ((rs + 2R) / rs), but the chip wants >= ~8 waves per SIMD
+        // (256 CUs x 4 SIMDs): 30 rows when the launch still has that many waves (4K), else 15 (both multiples of 3 and 5,
+        // the group sizes of the row pipeline)
+        const int strips = (a.W + 255) / 256;
+        const long waves30 = 3L * strips * ((a.H + 29) / 30) * a.B;
+        int rs = waves30 >= 8 * 1024 ? 30 : 15;
+        static const int env_rs = getenv("ADAISP_CONV_RS") ? atoi(getenv("ADAISP_CONV_RS")) : 0;     // measurement overrides
+        static const int env_ng = getenv("ADAISP_CONV_NG") ? atoi(getenv("ADAISP_CONV_NG")) : 0;
+        if (env_rs > 0) rs = env_rs;
+        const int bands = (a.H + rs - 1) / rs;
+        const dim3 g(3 * strips, (bands + 3) / 4, a.B);
+        // per-image ids live on the device: both families are enqueued (workgroups of the other family's images return at
+        // once) unless the caller rules the unsharp mask out (ADAISP_NO_USM: it is not in the policy's filter list)
+        const bool want3 = a.ids ? true : (a.uniform_op != ADAISP_OP_USM);
+        const bool want5 = a.ids ? !(a.flags & ADAISP_NO_USM) : (a.uniform_op == ADAISP_OP_USM);
+        if (want3) {
+            if (env_ng == 1)
+                hipLaunchKernelGGL((k_conv_rows<1, 1>), g, dim3(kThreads), 0, s, a.img, a.out, a.ids, a.uniform_op, a.params,
+                                   a.pstride, a.H, a.W, strips, rs);
+            else
+                hipLaunchKernelGGL((k_conv_rows<1, 2>), g, dim3(kThreads), 0, s, a.img, a.out, a.ids, a.uniform_op, a.params,
+                                   a.pstride, a.H, a.W, strips, rs);
+        }
+        if (want5)
+            hipLaunchKernelGGL((k_conv_rows<2, 1>), g, dim3(kThreads), 0, s, a.img, a.out, a.ids, a.uniform_op, a.params,
+                               a.pstride, a.H, a.W, strips, rs);
     } else
         hipLaunchKernelGGL(k_conv<false>, grid, dim3(kThreads), 0, s, a.img, a.out, a.ids, a.uniform_op, a.params,
                            a.pstride, a.H, a.W);

@@ -20,7 +20,7 @@ int adayolo_abi_version(void) { return ADAYOLO_ABI_VERSION; }
 const char* adayolo_strerror(int code) {
     switch (code) {
         case ADAYOLO_OK: return "ok";
-        case ADAYOLO_EINVAL: return "invalid argument (null pointer or non-positive size)";
+        case ADAYOLO_EINVAL: return "invalid argument (null pointer, non-positive size or unknown kernel variant)";
         case ADAYOLO_ESHAPE: return "shape not supported (channels/strides must be multiples of 8, ksize 1 or 3, stride 1 or 2)";
         case ADAYOLO_ELAUNCH: return "kernel launch failed";
         default: return "unknown error";
@@ -56,13 +56,25 @@ int adayolo_conv_fwd_variant(const void* in, int in_cstride, const void* weight,
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (variant == 0) variant = ADAYOLO_DEFAULT_VARIANT;
     hipError_t e = hipErrorInvalidValue;
-    if (variant >= 60) e = launch_conv_pp128(a, s, variant);               // Cin % 64 == 0 and Cout % 128 == 0 only
-    else if (variant >= 50) e = launch_conv_pp(a, s, variant);                  // Cin % 64 == 0 and Cout % 256 == 0 only; falls through otherwise
-    else if (variant >= 35 && variant <= 39) e = launch_conv_dma2(a, s, variant);   // ablation builds
-    else if (variant >= 40) e = launch_conv_small(a, s, variant);            // 3x3, Cin 32/64 only; falls through otherwise
-    else if (variant >= 30) e = launch_conv_patch(a, s, variant);       // 3x3 stride-1 only; falls through otherwise
-    if (e == hipErrorInvalidValue && variant >= 30) variant = ADAYOLO_DEFAULT_VARIANT;
-    if (variant < 30) e = (variant == 1) ? launch_conv(a, s) : (variant >= 5) ? launch_conv_dma2(a, s, variant) : launch_conv_dma(a, s, variant);
+    bool known = false;
+    switch (variant) {
+        case 2: known = true; e = launch_conv_dma(a, s, variant); break;
+        case 5: case 22: case 26: case 27: known = true; e = launch_conv_dma2(a, s, variant); break;
+        case 40: known = true; e = launch_conv_small(a, s, variant); break;       // 3x3, Cin 32 / 64 only
+        case 50: known = true; e = launch_conv_pp(a, s, variant); break;          // Cin % 64 == 0, Cout % 256 == 0 only
+        case 60: known = true; e = launch_conv_pp128(a, s, variant); break;       // Cin % 64 == 0, Cout % 128 == 0 only
+        default: break;
+    }
+#ifdef ADAYOLO_MEASURE
+    if (!known) {
+        known = true;
+        if (variant >= 60) e = launch_conv_pp128(a, s, variant);
+        else if (variant >= 50) e = launch_conv_pp(a, s, variant);
+        else e = launch_conv_dma2(a, s, variant);
+    }
+#endif
+    if (!known) return ADAYOLO_EINVAL;                                            // not a kernel of this library
+    if (e == hipErrorInvalidValue && variant >= 40) e = launch_conv_dma(a, s, ADAYOLO_DEFAULT_VARIANT);   // shape not served
     return e == hipSuccess ? ADAYOLO_OK : ADAYOLO_ELAUNCH;
 }
 

@@ -246,24 +246,15 @@ static hipError_t launch(ConvArgs a, hipStream_t s) {
 
 }  // namespace dma
 
-// variant: 2 = 2-stage ring (64 KB, 2 workgroups/CU), 3 = 3-stage ring (96 KB, 1 workgroup/CU), 4 = 4-stage
+// The library default (variant 2): 2-stage ring, 64 KB, 2 workgroups/CU; tile shape by Cout / grid size.
 hipError_t launch_conv_dma(ConvArgs a, hipStream_t s, int variant) {
     using namespace dma;
+    (void)variant;
     const long blocks128 = (long)((a.M + 127) / 128) * ((a.Cout + 127) / 128);
-    if (a.Cout <= 32) {
-        return variant == 2 ? launch<128, 32, 4, 1, 2>(a, s) : variant == 4 ? launch<128, 32, 4, 1, 4>(a, s)
-                                                                            : launch<128, 32, 4, 1, 3>(a, s);
-    }
-    if (a.Cout <= 64) {
-        return variant == 2 ? launch<128, 64, 4, 1, 2>(a, s) : variant == 4 ? launch<128, 64, 4, 1, 4>(a, s)
-                                                                            : launch<128, 64, 4, 1, 3>(a, s);
-    }
-    if (blocks128 < 512) {
-        return variant == 2 ? launch<64, 128, 2, 2, 2>(a, s) : variant == 4 ? launch<64, 128, 2, 2, 4>(a, s)
-                                                                            : launch<64, 128, 2, 2, 3>(a, s);
-    }
-    return variant == 2 ? launch<128, 128, 2, 2, 2>(a, s) : variant == 4 ? launch<128, 128, 2, 2, 4>(a, s)
-                                                                         : launch<128, 128, 2, 2, 3>(a, s);
+    if (a.Cout <= 32) return launch<128, 32, 4, 1, 2>(a, s);
+    if (a.Cout <= 64) return launch<128, 64, 4, 1, 2>(a, s);
+    if (blocks128 < 512) return launch<64, 128, 2, 2, 2>(a, s);
+    return launch<128, 128, 2, 2, 2>(a, s);
 }
 
 }  // namespace adayolo

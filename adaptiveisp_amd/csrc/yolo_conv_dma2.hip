@@ -303,39 +303,33 @@ static hipError_t launch(ConvArgs a, hipStream_t s) {
 
 }  // namespace dma2
 
-// variant 5: 2-stage ring, 6: 3-stage ring
+// Variants the autotuner chooses from (each one wins layers in yolo/tuning/mi355x.json and is covered by
+// tests/test_gpu_yolo_variants.py):
+//    5  128x128 / 64x128 / 128x64 / 128x32 tiles by shape, BK 64, 2-stage ring
+//   22  128 px x 64 ch, 4 waves, BK 32, 4-stage ring (small Cin / Cout)
+//   26  128 px x 256 ch, 8 waves, BK 32, 3 stages, <= 128 VGPRs: 2 workgroups/CU
+//   27  256 px x 128 ch, 8 waves, BK 32, 3 stages, 72 KB: 2 workgroups/CU
+// With -DADAYOLO_MEASURE the ablation builds the DESIGN.md timeline was measured with are compiled in as well.
 hipError_t launch_conv_dma2(ConvArgs a, hipStream_t s, int variant) {
     using namespace dma2;
-    if (variant == 7) return launch<128, 128, 2, 2, 2, 1>(a, s);     // ablation: compute only
-    if (variant == 8) return launch<128, 128, 2, 2, 2, 2>(a, s);     // ablation: DMA only
-    if (variant == 9) return launch<256, 128, 4, 2, 3>(a, s);        // 8 waves, 256 px x 128 ch, 3-stage ring (144 KB)
-    if (variant == 10) return launch<256, 128, 4, 2, 3, 1>(a, s);
-    if (variant == 11) return launch<256, 128, 4, 2, 3, 2>(a, s);
-    if (variant == 12) return launch<256, 128, 4, 2, 2>(a, s);       // 2-stage (96 KB)
-    if (variant == 13) return launch<256, 256, 4, 2, 2>(a, s);       // 8 waves, 256 px x 256 ch, wave tile 64 px x 128 ch
-    if (variant == 14) return launch<256, 256, 4, 2, 2, 1>(a, s);
-    if (variant == 15) return launch<256, 256, 4, 2, 2, 2>(a, s);
-    if (variant == 22) return launch<128, 64, 4, 1, 4, 0, 32>(a, s);    // small Cin/Cout: BK=32 (no half-empty k-steps at Cin=32)
-    if (variant == 24) return launch<256, 128, 4, 2, 4, 0, 32>(a, s);   // 8 waves, 256 px x 128 ch, BK=32
-    if (variant == 26) return launch<128, 256, 2, 4, 3, 0, 32, 4>(a, s);   // v19 squeezed to 128 VGPRs: 2 workgroups/CU
-    if (variant == 27) return launch<256, 128, 4, 2, 3, 0, 32, 4>(a, s);   // 256 px x 128 ch, 72 KB, 2 workgroups/CU
-    if (variant == 28) return launch<128, 128, 2, 2, 3, 0, 64, 3>(a, s);   // 4 waves, 96 KB... 1/CU by LDS; 3 waves/SIMD regs
-    if (variant == 29) return launch<256, 64, 4, 1, 4, 0, 32>(a, s);       // small Cout: 256 px x 64 ch, 80 KB
-    if (variant == 20) return launch<256, 256, 4, 2, 2, 3>(a, s);     // ablation: MFMA only
-    if (variant == 21) return launch<256, 256, 4, 2, 2, 4>(a, s);     // ablation: LDS reads only
-    if (variant == 35) return launch<256, 256, 4, 2, 2, 5>(a, s);     // ablation: no epilogue
-    if (variant == 36) return launch<256, 256, 4, 2, 2, 6>(a, s);     // ablation: no k-loop (prologue + epilogue only)
-    if (variant == 37) return launch<256, 256, 4, 2, 2, 7>(a, s);     // ablation: no global stores
-    if (variant == 38) return launch<256, 128, 2, 2, 3, 0, 32, 2>(a, s);   // 4 waves, wave tile 128 px x 64 ch, 72 KB: 2 WG/CU
-    if (variant == 39) return launch<128, 256, 2, 2, 3, 0, 32, 2>(a, s);   // 4 waves, wave tile 64 px x 128 ch, 72 KB: 2 WG/CU
-    if (variant == 16) return launch<256, 256, 4, 2, 4, 0, 32>(a, s);   // BK=32, 4-stage ring (128 KB), 3 steps of look-ahead
-    if (variant == 18) return launch<128, 128, 2, 2, 4, 0, 32>(a, s);   // 64 KB, 2 workgroups/CU
-    if (variant == 19) return launch<128, 256, 2, 4, 3, 0, 32>(a, s);   // 8 waves 128 px x 256 ch, 72 KB, 2 workgroups/CU
+    if (variant == 22) return launch<128, 64, 4, 1, 4, 0, 32>(a, s);
+    if (variant == 26) return launch<128, 256, 2, 4, 3, 0, 32, 4>(a, s);
+    if (variant == 27) return launch<256, 128, 4, 2, 3, 0, 32, 4>(a, s);
+#ifdef ADAYOLO_MEASURE
+    if (variant == 7) return launch<128, 128, 2, 2, 2, 1>(a, s);     // compute only
+    if (variant == 8) return launch<128, 128, 2, 2, 2, 2>(a, s);     // DMA only
+    if (variant == 13) return launch<256, 256, 4, 2, 2>(a, s);       // lock-step 256 x 256 (the ping-pong kernel's ancestor)
+    if (variant == 20) return launch<256, 256, 4, 2, 2, 3>(a, s);    // MFMA only
+    if (variant == 21) return launch<256, 256, 4, 2, 2, 4>(a, s);    // LDS reads only
+    if (variant == 35) return launch<256, 256, 4, 2, 2, 5>(a, s);    // no epilogue
+    if (variant == 36) return launch<256, 256, 4, 2, 2, 6>(a, s);    // no k-loop
+    if (variant == 37) return launch<256, 256, 4, 2, 2, 7>(a, s);    // no global stores
+#endif
     const long blocks128 = (long)((a.M + 127) / 128) * ((a.Cout + 127) / 128);
-    if (a.Cout <= 32) return variant == 6 ? launch<128, 32, 4, 1, 3>(a, s) : launch<128, 32, 4, 1, 2>(a, s);
-    if (a.Cout <= 64) return variant == 6 ? launch<128, 64, 4, 1, 3>(a, s) : launch<128, 64, 4, 1, 2>(a, s);
-    if (blocks128 < 512) return variant == 6 ? launch<64, 128, 2, 2, 3>(a, s) : launch<64, 128, 2, 2, 2>(a, s);
-    return variant == 6 ? launch<128, 128, 2, 2, 3>(a, s) : launch<128, 128, 2, 2, 2>(a, s);
+    if (a.Cout <= 32) return launch<128, 32, 4, 1, 2>(a, s);
+    if (a.Cout <= 64) return launch<128, 64, 4, 1, 2>(a, s);
+    if (blocks128 < 512) return launch<64, 128, 2, 2, 2>(a, s);
+    return launch<128, 128, 2, 2, 2>(a, s);
 }
 
 }  // namespace adayolo

@@ -38,7 +38,11 @@ typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
 
 __device__ __attribute__((aligned(16))) unsigned int g_zero16[4] = {0u, 0u, 0u, 0u};
+#ifdef ADAYOLO_MEASURE
 __device__ unsigned long long g_stamp[4096 * 8];     // ABL 7: per-workgroup s_memtime stamps (measurement build)
+#else
+__device__ unsigned long long g_stamp[8];
+#endif
 #define PP_STAMP(k) do { if (ABL == 7 && threadIdx.x == 0 && blockIdx.x < 4096) g_stamp[blockIdx.x * 8 + (k)] = __builtin_readcyclecounter(); } while (0)
 
 __device__ __forceinline__ float bf16_to_f32(unsigned short h) { return __uint_as_float(((unsigned)h) << 16); }
@@ -412,9 +416,11 @@ static hipError_t launch(ConvArgs a, hipStream_t s) {
 
 }  // namespace pp
 
-// variant 50 = the kernel, 51..55 = measurement builds. hipErrorInvalidValue -> caller falls back.
+// variant 50 = the kernel; with -DADAYOLO_MEASURE 51..57 = the measurement builds (ABL above). hipErrorInvalidValue ->
+// the shape is not served (the caller falls back to the default kernel).
 hipError_t launch_conv_pp(ConvArgs a, hipStream_t s, int variant) {
     if (a.Cin % 64 || a.Cout % 256) return hipErrorInvalidValue;
+#ifdef ADAYOLO_MEASURE
     if (variant == 51) return pp::launch<1>(a, s);
     if (variant == 52) return pp::launch<2>(a, s);
     if (variant == 53) return pp::launch<3>(a, s);
@@ -422,12 +428,16 @@ hipError_t launch_conv_pp(ConvArgs a, hipStream_t s, int variant) {
     if (variant == 55) return pp::launch<5>(a, s);
     if (variant == 56) return pp::launch<6>(a, s);
     if (variant == 57) return pp::launch<7>(a, s);
+#endif
+    (void)variant;
     return pp::launch<0>(a, s);
 }
 
+#ifdef ADAYOLO_MEASURE
 // measurement helper (not part of the ABI): copies the stamps of the last variant-57 launch
 extern "C" int adayolo_debug_stamps(unsigned long long* dst, int n) {
     return hipMemcpyFromSymbol(dst, HIP_SYMBOL(pp::g_stamp), sizeof(unsigned long long) * n) == hipSuccess ? 0 : -1;
 }
+#endif
 
 }  // namespace adayolo

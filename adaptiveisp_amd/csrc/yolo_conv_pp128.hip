@@ -369,11 +369,14 @@ static hipError_t launch(ConvArgs a, hipStream_t s) {
 
 }  // namespace pp128
 
-// variant 60 = the kernel, 65 / 66 = measurement builds. hipErrorInvalidValue -> caller falls back.
+// variant 60 = the kernel; with -DADAYOLO_MEASURE 65 / 66 = measurement builds. hipErrorInvalidValue -> not served.
 hipError_t launch_conv_pp128(ConvArgs a, hipStream_t s, int variant) {
     if (a.Cin % 64 || a.Cout % 128) return hipErrorInvalidValue;
+#ifdef ADAYOLO_MEASURE
     if (variant == 65) return pp128::launch<5>(a, s);
     if (variant == 66) return pp128::launch<6>(a, s);
+#endif
+    (void)variant;
     return pp128::launch<0>(a, s);
 }
 

@@ -220,28 +220,17 @@ static hipError_t launch(ConvArgs a, hipStream_t s) {
 
 }  // namespace smallk
 
-// variants 40..: whole-K-resident kernels for Cin in {32, 64}, 3x3, stride 1 or 2.
+// variant 40: whole-K-resident kernel for Cin in {32, 64}, 3x3, stride 1 or 2 (hipErrorInvalidValue otherwise).
 hipError_t launch_conv_small(ConvArgs a, hipStream_t s, int variant) {
     using namespace smallk;
+    (void)variant;
     if (a.ks != 3 || (a.Cin != 32 && a.Cin != 64)) return hipErrorInvalidValue;
     if (a.Cin == 32) {
-        if (a.stride == 1) {
-            if (variant == 40) return launch<32, 64, 1, 8, 32, 4, 2>(a, s);   // 256 px x 64 ch, 8 waves, 58 KB
-            if (variant == 41) return launch<32, 64, 1, 4, 32, 4, 1>(a, s);   // 128 px x 64 ch, 4 waves, 50 KB
-        } else {
-            if (variant == 40) return launch<32, 64, 2, 4, 32, 4, 1>(a, s);   // 128 px, 4 waves, 75 KB
-            if (variant == 41) return launch<32, 64, 2, 2, 32, 2, 1>(a, s);   // 64 px, 2 waves, 49 KB
-        }
-    } else {
-        if (a.stride == 1) {
-            if (variant == 40) return launch<64, 64, 1, 8, 32, 4, 2>(a, s);   // 256 px x 64 ch: 44 + 74 KB
-            if (variant == 41) return launch<64, 64, 1, 4, 32, 4, 1>(a, s);   // 128 px x 64 ch: 27 + 74 KB
-        } else {
-            if (variant == 40) return launch<64, 64, 2, 4, 32, 4, 1>(a, s);   // 75 + 74 KB
-            if (variant == 41) return launch<64, 64, 2, 2, 32, 2, 1>(a, s);   // 25 + 74 KB
-        }
+        if (a.stride == 1) return launch<32, 64, 1, 8, 32, 4, 2>(a, s);   // 256 px x 64 ch, 8 waves, 58 KB
+        return launch<32, 64, 2, 4, 32, 4, 1>(a, s);                      // 128 px, 4 waves, 75 KB
     }
-    return hipErrorInvalidValue;
+    if (a.stride == 1) return launch<64, 64, 1, 8, 32, 4, 2>(a, s);       // 256 px x 64 ch: 44 + 74 KB
+    return launch<64, 64, 2, 4, 32, 4, 1>(a, s);                          // 75 + 74 KB
 }
 
 }  // namespace adayolo

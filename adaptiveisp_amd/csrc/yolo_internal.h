@@ -40,13 +40,11 @@ __device__ __forceinline__ void bias_act_pack4(float a0, float a1, float a2, flo
     hi = __builtin_bit_cast(unsigned, __builtin_convertvector(x1, bf16x2_pk));
 }
 
-hipError_t launch_conv(ConvArgs a, hipStream_t s);                    // register-staged (yolo_conv.hip)
 hipError_t launch_conv_dma(ConvArgs a, hipStream_t s, int variant);   // LDS-DMA ring (yolo_conv_dma.hip)
 hipError_t launch_conv_dma2(ConvArgs a, hipStream_t s, int variant);  // lean-address 32x32 MFMA ring (yolo_conv_dma2.hip)
-hipError_t launch_conv_patch(ConvArgs a, hipStream_t s, int variant); // 3x3 s1, input patch resident in LDS (yolo_conv_patch.hip)
-hipError_t launch_conv_small(ConvArgs a, hipStream_t s, int variant);
-hipError_t launch_conv_pp(ConvArgs a, hipStream_t s, int variant);
-hipError_t launch_conv_pp128(ConvArgs a, hipStream_t s, int variant); // 256x128 ping-pong, 3-deep ring (yolo_conv_pp128.hip)    // 256x256 ping-pong wave groups (yolo_conv_pp.hip) // 3x3, Cin 32/64, whole K resident (yolo_conv_small.hip)
+hipError_t launch_conv_small(ConvArgs a, hipStream_t s, int variant); // 3x3, Cin 32/64, whole K resident (yolo_conv_small.hip)
+hipError_t launch_conv_pp(ConvArgs a, hipStream_t s, int variant);    // 256x256 ping-pong wave groups (yolo_conv_pp.hip)
+hipError_t launch_conv_pp128(ConvArgs a, hipStream_t s, int variant); // 256x128 ping-pong, 3-deep ring (yolo_conv_pp128.hip)
 hipError_t launch_stem(const float* img, const float* w, const float* bias, void* out, int out_cs, int B, int H,
                        int W, int Hp, int pad_top, float pad_value, int act, hipStream_t s);
 hipError_t launch_letterbox_pack(const float* img, void* out, int out_cs, int B, int H, int W, int Hp, int pad_top,

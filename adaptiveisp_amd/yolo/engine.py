@@ -223,7 +223,7 @@ class YoloEngine:
         self.views = view
 
     # ------------------------------------------------------------------------------------------
-    TUNE_CANDIDATES = (2, 5, 12, 13, 18, 19, 22, 24, 26, 27, 30, 31, 32, 33, 40, 41, 50, 60)
+    TUNE_CANDIDATES = (2, 5, 22, 26, 27, 40, 50, 60)
 
     def _plans(self):
         return [self.plan]
@@ -258,8 +258,6 @@ class YoloEngine:
                 if key not in chosen:
                     best = (None, float("inf"))
                     for v in self.TUNE_CANDIDATES:
-                        if 30 <= v < 40 and not (args[13] == 3 and args[14] == 1):
-                            continue                             # patch-resident kernels serve 3x3 stride-1 only
                         if 40 <= v < 50 and not (args[13] == 3 and args[11] in (32, 64)):
                             continue                             # whole-K-resident kernels: 3x3 with Cin 32 / 64
                         if 50 <= v < 60 and (args[11] % 64 or args[12] % 256):

@@ -52,6 +52,7 @@ enum adaisp_op {
 #define ADAISP_NLM_EXACT 2u /* NLM: add the 25 patch terms in the reference's single running-sum order
                                (isp/denoise.py:60-63) instead of the default 5x5 separable association; ~3.5x slower */
 #define ADAISP_NLM_SEP_V1 4u /* NLM: the compiler-scheduled form of the separable kernel (measurement / cross-check) */
+#define ADAISP_NO_USM 8u /* adaisp_forward: no image of the batch selects ADAISP_OP_USM (saves its empty launch) */
 
 /* error codes */
 #define ADAISP_OK          0

@@ -50,11 +50,12 @@ int adayolo_conv_fwd(const void* in, int in_cstride,
                      int ksize, int stride, int act, void* stream);
 
 /*
- * Same as adayolo_conv_fwd with an explicit kernel variant (tuning / A-B measurements; results are identical):
- * 0 = library default, 1 = register-staged tile loads, 2/3/4 = LDS-DMA ring with 2/3/4 stages (16x16x32 MFMA),
- * 5/6 = lean-address LDS-DMA ring with 2/3 stages (32x32x16 MFMA); 9..24 = fixed tile shapes of that kernel
- * (256x128 / 256x256 / 128x256 px x ch, BK 32 or 64; see yolo_conv_dma2.hip); 30..33 = 3x3 stride-1 kernels with
- * the input patch resident in LDS (yolo_conv_patch.hip; other shapes fall back to the default).
+ * Same as adayolo_conv_fwd with an explicit kernel (what YoloEngine.autotune picks per layer; results agree to the
+ * bf16 rounding of the output, tests/test_gpu_yolo_variants.py): 0 = library default (= 2); 2 = LDS-DMA ring, 16x16x32
+ * MFMA; 5 / 22 / 26 / 27 = lean-address LDS-DMA ring on 32x32x16 MFMA with tiles 128x128 (by shape) / 128x64 /
+ * 128x256 / 256x128 px x ch; 40 = whole-K-resident 3x3 for Cin 32 / 64; 50 = 256x256 ping-pong wave groups
+ * (Cin % 64 == 0, Cout % 256 == 0); 60 = 256x128 ping-pong (Cin % 64 == 0, Cout % 128 == 0). A specialised kernel
+ * asked for a shape it does not serve runs the default instead; any other number is ADAYOLO_EINVAL.
  */
 int adayolo_conv_fwd_variant(const void* in, int in_cstride,
                              const void* weight, const float* bias,

@@ -40,3 +40,31 @@ def test_argument_checks_without_gpu():
     assert L.adaisp_process(99, p, p, p, 1, 1, 2, 2, 0, None) == -2          # unknown op
     assert L.adaisp_process(2, p, p, p, 1, 1, 2, 2, 0, None) == -1           # CCM needs 9 params, stride 1
     assert L.adaisp_process(3, p, p, p, 1, 1, 2, 2, 0, None) == -3           # stencil in place
+
+
+def test_libadayolo_exports_header_symbols():
+    from adaptiveisp_amd.yolo import _lib
+    L = _lib.load()
+    names = _declared("adayolo.h")
+    assert set(_lib.EXPORTS) <= set(names)
+    for n in names:
+        assert hasattr(L, n), f"libadayolo.so does not export {n}"
+    assert L.adayolo_abi_version() == _lib.ABI_VERSION
+    assert not hasattr(L, "adayolo_debug_stamps")            # measurement builds are not in the shipped library
+
+
+def test_adayolo_argument_checks_without_gpu():
+    """Rejected before anything touches a device: null pointers, bad channel counts, kernel numbers that are not in the
+    library (only the variants the tuning table may name exist: include/adayolo.h)."""
+    from adaptiveisp_amd.yolo import _lib
+    L = _lib.load()
+    buf = (ctypes.c_float * 64)()
+    p = ctypes.cast(buf, ctypes.c_void_p)
+    conv = L.adayolo_conv_fwd_variant
+    assert conv(None, 8, p, p, None, 0, p, 8, 1, 4, 4, 8, 8, 3, 1, 1, 0, None) == -1
+    assert conv(p, 8, p, p, None, 0, p, 8, 1, 4, 4, 7, 8, 3, 1, 1, 0, None) == -2            # Cin % 8
+    assert conv(p, 8, p, p, None, 0, p, 8, 1, 4, 4, 8, 8, 5, 1, 1, 0, None) == -2            # ksize 5
+    for bogus in (1, 3, 13, 33, 41, 57, 66, 99):
+        assert conv(p, 8, p, p, None, 0, p, 8, 1, 4, 4, 8, 8, 3, 1, 1, bogus, None) == -1, bogus
+    assert L.adayolo_letterbox_pack(None, p, 8, 1, 4, 4, 4, 0, 0.5, None) == -1
+    assert L.adayolo_letterbox_pack(p, p, 6, 1, 4, 4, 4, 0, 0.5, None) == -2

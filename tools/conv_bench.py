@@ -38,7 +38,7 @@ def run(L, x, w, b, out, B, H, W, cin, cout, k, s, variant, iters):
 
 
 def main():
-    variants = [int(v) for v in (sys.argv[1] if len(sys.argv) > 1 else "1,2,3,4").split(",")]
+    variants = [int(v) for v in (sys.argv[1] if len(sys.argv) > 1 else "2,5,27,50,60").split(",")]
     B = 8
     L = _lib.load()
     tot = {v: 0.0 for v in variants}

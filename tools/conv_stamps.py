@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Per-workgroup timeline of the ping-pong conv kernel (variant 57 = stamped build): medians of the stage durations."""
+"""Per-workgroup timeline of the ping-pong conv kernel (variant 57 = stamped build; needs a library built with ADAYOLO_EXTRA_FLAGS=-DADAYOLO_MEASURE python -m adaptiveisp_amd.build --force): medians of the stage durations."""
 import ctypes, os, sys
 import numpy as np
 import torch
