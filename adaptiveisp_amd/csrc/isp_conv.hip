@@ -7,7 +7,6 @@
 //
 // Reference: isp/sharpen.py:105-142 (adjust_sharpness), :145-182 (sharpness), :63-102 (unsharp_mask).
 #include "isp_internal.h"
-#include <cstdlib>
 
 namespace adaisp {
 namespace {
@@ -346,32 +345,21 @@ hipError_t launch_conv(const Batch& a, hipStream_t s) {
                      ((reinterpret_cast<uintptr_t>(a.out) & 15) == 0);
     dim3 grid((a.W + TW - 1) / TW, (a.H + TH - 1) / TH, a.B);
     if (vec) {
-        // rows per wave: taller bands re-read fewer halo rows ((rs + 2R) / rs), but the chip wants >= ~8 waves per SIMD
-        // (256 CUs x 4 SIMDs): 30 rows when the launch still has that many waves (4K), else 15 (both multiples of 3 and 5,
-        // the group sizes of the row pipeline)
+        // rows per wave, measured (profiles/round2_stencil_sweep.txt, 8x720x1280 and 4x2160x3840): taller bands re-read fewer
+        // halo rows ((rs + 2R) / rs) but leave fewer waves; 15 is best for the 3x3 filters at both sizes (30: -7 % at 4K,
+        // 60: -35 %), 30 for the 5x5 (its halo is twice as tall). Multiples of 3 and 5, the pipeline's group sizes.
         const int strips = (a.W + 255) / 256;
-        const long waves30 = 3L * strips * ((a.H + 29) / 30) * a.B;
-        int rs = waves30 >= 8 * 1024 ? 30 : 15;
-        static const int env_rs = getenv("ADAISP_CONV_RS") ? atoi(getenv("ADAISP_CONV_RS")) : 0;     // measurement overrides
-        static const int env_ng = getenv("ADAISP_CONV_NG") ? atoi(getenv("ADAISP_CONV_NG")) : 0;
-        if (env_rs > 0) rs = env_rs;
-        const int bands = (a.H + rs - 1) / rs;
-        const dim3 g(3 * strips, (bands + 3) / 4, a.B);
+        const int rs3 = 15, rs5 = 30;
         // per-image ids live on the device: both families are enqueued (workgroups of the other family's images return at
         // once) unless the caller rules the unsharp mask out (ADAISP_NO_USM: it is not in the policy's filter list)
         const bool want3 = a.ids ? true : (a.uniform_op != ADAISP_OP_USM);
         const bool want5 = a.ids ? !(a.flags & ADAISP_NO_USM) : (a.uniform_op == ADAISP_OP_USM);
-        if (want3) {
-            if (env_ng == 1)
-                hipLaunchKernelGGL((k_conv_rows<1, 1>), g, dim3(kThreads), 0, s, a.img, a.out, a.ids, a.uniform_op, a.params,
-                                   a.pstride, a.H, a.W, strips, rs);
-            else
-                hipLaunchKernelGGL((k_conv_rows<1, 2>), g, dim3(kThreads), 0, s, a.img, a.out, a.ids, a.uniform_op, a.params,
-                                   a.pstride, a.H, a.W, strips, rs);
-        }
+        if (want3)
+            hipLaunchKernelGGL((k_conv_rows<1, 1>), dim3(3 * strips, ((a.H + rs3 - 1) / rs3 + 3) / 4, a.B), dim3(kThreads), 0, s,
+                               a.img, a.out, a.ids, a.uniform_op, a.params, a.pstride, a.H, a.W, strips, rs3);
         if (want5)
-            hipLaunchKernelGGL((k_conv_rows<2, 1>), g, dim3(kThreads), 0, s, a.img, a.out, a.ids, a.uniform_op, a.params,
-                               a.pstride, a.H, a.W, strips, rs);
+            hipLaunchKernelGGL((k_conv_rows<2, 1>), dim3(3 * strips, ((a.H + rs5 - 1) / rs5 + 3) / 4, a.B), dim3(kThreads), 0, s,
+                               a.img, a.out, a.ids, a.uniform_op, a.params, a.pstride, a.H, a.W, strips, rs5);
     } else
         hipLaunchKernelGGL(k_conv<false>, grid, dim3(kThreads), 0, s, a.img, a.out, a.ids, a.uniform_op, a.params,
                            a.pstride, a.H, a.W);

@@ -221,20 +221,24 @@ def time_dominant_conv(engine, x, reps=3):
 
 
 def pmc_traffic(kernel_name):
-    """HBM bytes per launch of `kernel_name` from the committed PMC passes (profiles/*_pmc_traffic.json, produced by
-    tools/refresh_profiles.sh: separate --pmc runs, FETCH_SIZE x2 per the gfx950 note). None if not collected."""
+    """HBM bytes per launch of `kernel_name` from the newest committed PMC passes (profiles/*_pmc_traffic.json, produced
+    by tools/refresh_profiles.sh: separate --pmc runs, FETCH_SIZE x2 per the gfx950 note), averaged over the launches
+    of that kernel in the benchmarked network (records are per launch geometry). None if not collected."""
     import glob
-    best = None
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json"))):
+    key = kernel_name.split("::")[-1].replace(" ", "")
+    if not key:
+        return None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")), reverse=True):
         try:
             table = json.load(open(path))
         except Exception:
             continue
-        key = kernel_name.split("::")[-1].replace(" ", "")
-        for name, rec in table.items():
-            if key and key in name.replace(" ", ""):
-                best = rec["hbm_bytes_per_launch"]
-    return best
+        recs = table if isinstance(table, list) else [dict(kernel=k, **v) for k, v in table.items()]
+        hit = [r for r in recs if key in r["kernel"].replace(" ", "")]
+        n = sum(r["launches"] for r in hit)
+        if n:
+            return sum(r["hbm_bytes_per_launch"] * r["launches"] for r in hit) / n
+    return None
 
 
 def _timed(fn, repeats=3):

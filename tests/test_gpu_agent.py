@@ -262,3 +262,24 @@ def test_critic_to_actor_gradient_matches_reference(golden, k):
     for j, other in enumerate(ag.filters):                 # only the selected filter's heads see this gradient
         if j != k and other.fc_filter.bias.grad is not None:
             assert not other.fc_filter.bias.grad.any()
+
+
+def test_config1_single_640_three_steps_on_the_hip_path(oracle_mod):
+    """BASELINE config 1 (one 640x640 frame, steps=3, no detector) on the device: every step of the fused eval path
+    equals the oracle's filter applied with the parameters the heads regressed on the device."""
+    from adaptiveisp_amd import _lib
+    ag, cfg, dev = _agent()
+    rng = np.random.default_rng(1234)
+    x = torch.from_numpy((rng.random((1, 3, 640, 640)) ** 2.2 * 0.5).astype(np.float32)).to(dev)
+    z = torch.from_numpy(rng.random((1, cfg.z_dim)).astype(np.float32)).to(dev)
+    st = torch.zeros(1, cfg.num_state_dim, device=dev)
+    ops = {0: _lib.OP_EXPOSURE, 9: _lib.OP_WB, 5: _lib.OP_TONE, 4: _lib.OP_NLM}
+    with torch.no_grad():
+        for step, k in enumerate((0, 4, 5)):
+            (y, st2, _, pen), dbg, _ = ag((x, z, st), 1.0, selected_filter_id=k)
+            assert ag._fast is not None
+            p = dbg["filter_debug_info"][k]["filter_parameters"].reshape(1, -1).cpu().numpy()
+            ref = oracle_mod.forward(x.cpu().numpy(), ops[k], p, clip=True)
+            np.testing.assert_allclose(y.cpu().numpy(), ref, rtol=1e-5, atol=2e-6)
+            assert float(st2[0, 2]) == step + 1 and float(st2[0, 3 + k]) == 1.0 and int(dbg["selected_filter"][0]) == k
+            x, st = y, st2

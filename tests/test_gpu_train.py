@@ -134,3 +134,28 @@ def test_train_iteration_with_hip_detector_matches_torch_detector():
     assert cos > 0.9995, cos
     rel = ((grads[0] - grads[1]).norm() / grads[0].norm()).item()
     assert rel < 0.02, rel
+
+
+def test_train_iteration_at_the_config4_per_rank_shape():
+    """BASELINE config 4, what ONE rank does per iteration: batch 8 x 512 x 512 through `build_trainer` (the entry
+    `python -m adaptiveisp_amd.train` uses: full-width detector on the HIP training engine with the tuning table,
+    replay pool in HBM) — two iterations, finite losses, heads move, records re-enter the pool."""
+    from adaptiveisp_amd.config import cfg
+    from adaptiveisp_amd.train import build_trainer
+    from adaptiveisp_amd.util import Dict
+    c = Dict(cfg)
+    c.replay_memory_size = 16
+    np.random.seed(0)
+    cache = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "adaptiveisp_amd", "yolo", "tuning",
+                         "mi355x.json")
+    tr = build_trainer(c, 0, 1, torch.device(DEV), batch_size=8, image_size=512, tune_cache=cache)
+    assert tr.max_iter_step == 800 * 1000 // 8
+    before = torch.cat([p.detach().reshape(-1) for p in tr.agent.parameters()]).clone()
+    hist = tr.train(iters=2)
+    torch.cuda.synchronize()
+    assert all(np.isfinite([h["agent_loss"], h["value_loss"], h["reward"]]).all() for h in hist)
+    after = torch.cat([p.detach().reshape(-1) for p in tr.agent.parameters()])
+    assert (after != before).any()
+    assert tr.replay.images.shape[1:] == (3, 512, 512) and tr.replay.images.device.type == "cuda"
+    dead = [n for n, p in tr.agent.named_parameters() if p.grad is None]
+    assert dead and all("fc_mask" in n for n in dead)          # as in the reference: heads that never enter the loss
