@@ -65,6 +65,7 @@ class Agent(nn.Module):
         self._op_table = None
         self._param_width = max(f.get_num_filter_parameters() for f in self.filters)
         self._fast = None            # fused eval path (policy_fast.FastPolicy), built on first use
+        self._ones_mask = None
         self.use_fast_eval = True
 
     # ------------------------------------------------------------------------------------------
@@ -86,16 +87,18 @@ class Agent(nn.Module):
         return isp_apply_selected(img, packed, op_ids, clip=True)
 
     # ------------------------------------------------------------------------------------------
-    def _forward_fast(self, x, z, states, progress, high_res, selected_filter_id):
+    def _forward_fast(self, x, z, states, progress, high_res, selected_filter_id, out=None):
         """Eval-mode step on the fused kernels: 7 launches instead of ~250 (see policy_fast.py)."""
         if self._fast is None:
             from .policy_fast import FastPolicy
             self._fast = FastPolicy(self)
         o = self._fast.run(self.down_sample(x), z, states, progress, selected_filter_id)
         no_usm = _lib.OP_USM not in self._op_table_host
-        x_out = _lib.forward(x, o["op_ids"], o["packed"], clip=True, no_usm=no_usm)
+        x_out = _lib.forward(x, o["op_ids"], o["packed"], clip=True, no_usm=no_usm, out=out)
         hr_out = _lib.forward(high_res, o["op_ids"], o["packed"], clip=True, no_usm=no_usm) if high_res is not None else None
-        mask = torch.ones((1, 1, 1, 1), dtype=torch.float32, device=x.device)
+        mask = self._ones_mask                      # Filter.get_mask with masking off (isp/filters.py:161-173): ones(1,1,1,1)
+        if mask is None or mask.device != x.device:
+            mask = self._ones_mask = torch.ones((1, 1, 1, 1), dtype=torch.float32, device=x.device)
         fdi = []
         for j, flt in enumerate(self.filters):
             n = flt.get_num_filter_parameters()
@@ -118,12 +121,16 @@ class Agent(nn.Module):
             return (x_out, o["new_states"], o["surrogate"], o["penalty"]), debug_info, debugger
         return (x_out, o["new_states"], hr_out), debug_info, debugger
 
-    def forward(self, inp, progress, high_res=None, selected_filter_id=None):
+    def forward(self, inp, progress, high_res=None, selected_filter_id=None, out=None):
+        """Reference signature (agent.py:88) plus `out`: an optional preallocated [B,3,H,W] tensor the retouched image is
+        written into (eval path; a caller that double-buffers the hand-over to the detector saves a full-frame copy)."""
         train = 1 if self.training else 0
         x, z, states = inp
         if (self.use_fast_eval and not self.training and not torch.is_grad_enabled() and x.is_cuda
                 and len(self.filters) <= 16 and all(f._regressor is not None for f in self.filters)):
-            return self._forward_fast(x, z, states, progress, high_res, selected_filter_id)
+            return self._forward_fast(x, z, states, progress, high_res, selected_filter_id, out=out)
+        if out is not None:
+            raise ValueError("`out` is only supported on the fused eval path (eval mode, autograd off)")
         num_filters = len(self.filters)
         selection_noise = z[:, 0:1]
 

@@ -223,7 +223,7 @@ class YoloEngine:
         self.views = view
 
     # ------------------------------------------------------------------------------------------
-    TUNE_CANDIDATES = (2, 5, 22, 26, 27, 40, 50, 60)
+    TUNE_CANDIDATES = (2, 5, 22, 26, 27, 40, 50, 60, 80)
 
     def _plans(self):
         return [self.plan]
@@ -262,8 +262,10 @@ class YoloEngine:
                             continue                             # whole-K-resident kernels: 3x3 with Cin 32 / 64
                         if 50 <= v < 60 and (args[11] % 64 or args[12] % 256):
                             continue                             # ping-pong kernel: Cin % 64 == 0, Cout % 256 == 0
-                        if v >= 60 and (args[11] % 64 or args[12] % 128):
+                        if 60 <= v < 80 and (args[11] % 64 or args[12] % 128):
                             continue                             # 256x128 ping-pong kernel: Cin % 64 == 0, Cout % 128 == 0
+                        if v >= 80 and (args[11] % 32 or args[12] % 128):
+                            continue                             # 256x128, two workgroups per CU: Cin % 32 == 0, Cout % 128 == 0
                         args[16] = v
                         fn(*args, st)
                         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -34,7 +34,7 @@ TUNE_CACHE = os.path.join(ROOT, "adaptiveisp_amd", "yolo", "tuning", "mi355x.jso
 CONV_KERNEL_NAMES = {2: "dma::k_conv_igemm_dma<128,128,2,2,2>", 5: "dma2::k_conv_igemm_dma32<128,128,2,2,2,0,64,1>",
                      22: "dma2::k_conv_igemm_dma32<128,64,4,1,4,0,32,1>", 26: "dma2::k_conv_igemm_dma32<128,256,2,4,3,0,32,4>",
                      27: "dma2::k_conv_igemm_dma32<256,128,4,2,3,0,32,4>", 40: "smallk::k_conv3x3_small<...>",
-                     50: "pp::k_conv_pp<0>", 60: "pp128::k_conv_pp128<0>"}
+                     50: "pp::k_conv_pp<0>", 60: "pp128::k_conv_pp128<0>", 80: "pq::k_conv_pq<0>"}
 
 
 def parse():
@@ -82,11 +82,12 @@ def build_workload(a, dev):
     s0 = torch.zeros(a.batch, cfg.num_state_dim, device=dev)
     sched = SCHEDULES[a.schedule]
 
-    def isp_chain():
+    def isp_chain(out=None):
+        """The 5-step episode; `out`: where the last step writes the retouched batch (the pipeline's hand-over buffer)."""
         x, st = x0, s0
         with torch.no_grad():
-            for k in sched:
-                (x, st, _, _), _, _ = agent((x, z, st), 1.0, selected_filter_id=k)
+            for i, k in enumerate(sched):
+                (x, st, _, _), _, _ = agent((x, z, st), 1.0, selected_filter_id=k, out=out if i == len(sched) - 1 else None)
         return x
 
     def step():
@@ -117,13 +118,13 @@ def build_pipeline(step, engine, x0):
             side.wait_stream(cur)
             with torch.cuda.stream(side), torch.no_grad():
                 engine(xbuf[1 - p])                      # detector of the batch the previous replay retouched
-            xbuf[p].copy_(step.isp_chain())              # ISP episode of the next batch
+            step.isp_chain(out=xbuf[p])                  # ISP episode of the next batch, written into the hand-over buffer
             cur.wait_stream(side)
         graphs.append(g)
     state = {"i": 0}
 
     def prime():
-        xbuf[1].copy_(step.isp_chain())
+        step.isp_chain(out=xbuf[1])
         state["i"] = 0
 
     def run():

@@ -31,8 +31,10 @@ def _serves(v, cin, cout, k, s):
         return k == 3 and cin in (32, 64)
     if 50 <= v < 60:
         return cin % 64 == 0 and cout % 256 == 0
-    if v >= 60:
+    if 60 <= v < 80:
         return cin % 64 == 0 and cout % 128 == 0
+    if v >= 80:
+        return cin % 32 == 0 and cout % 128 == 0 and k * k * cin >= 96
     return True
 
 

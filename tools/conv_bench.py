@@ -38,9 +38,12 @@ def run(L, x, w, b, out, B, H, W, cin, cout, k, s, variant, iters):
 
 
 def main():
+    global SHAPES
     variants = [int(v) for v in (sys.argv[1] if len(sys.argv) > 1 else "2,5,27,50,60").split(",")]
     B = 8
     L = _lib.load()
+    if len(sys.argv) > 2 and sys.argv[2] == "big":          # the MFMA-bound 3x3 layers only
+        SHAPES[:] = [sh for sh in SHAPES if sh[4] == 3 and sh[2] >= 128]
     tot = {v: 0.0 for v in variants}
     totfl = 0.0
     print(f"{'shape':38s} " + " ".join(f"v{v:>2d} TF/s   ms " for v in variants))
