@@ -18,6 +18,7 @@ CLIP01 = 1
 NLM_EXACT = 2      # NLM patch sums in the reference's running-sum order (slower); default is the separable kernel
 NLM_SEP_V1 = 4     # the compiler-scheduled form of the separable kernel (cross-check / measurement)
 NO_USM = 8         # adaisp_forward: no image selects the unsharp mask (its empty launch is skipped)
+NLM_TILE32 = 16    # the 32-row tile of the default NLM kernel (cross-check / measurement)
 ABI_VERSION = 3
 
 EXPORTS = ("adaisp_forward", "adaisp_process", "adaisp_backward_params", "adaisp_pool64", "adaisp_pool64_backward", "adaisp_demosaic", "adaisp_num_params",
@@ -86,7 +87,7 @@ def _img_shape(img):
     return int(img.shape[0]), int(img.shape[2]), int(img.shape[3])
 
 
-def process(op, img, params, clip=False, out=None, nlm_exact=False, nlm_v1=False):
+def process(op, img, params, clip=False, out=None, nlm_exact=False, nlm_v1=False, nlm_tile32=False):
     """adaisp_process: one host-known op for the whole batch. params [B,n] (regressed)."""
     L = load()
     img = _dev_f32(img, "img")
@@ -96,7 +97,8 @@ def process(op, img, params, clip=False, out=None, nlm_exact=False, nlm_v1=False
         out = torch.empty_like(img)
     with torch.cuda.device(img.device):
         rc = L.adaisp_process(int(op), img.data_ptr(), out.data_ptr(), params.data_ptr(), params.shape[1], B, H, W,
-                              (CLIP01 if clip else 0) | (NLM_EXACT if nlm_exact else 0) | (NLM_SEP_V1 if nlm_v1 else 0),
+                              (CLIP01 if clip else 0) | (NLM_EXACT if nlm_exact else 0) | (NLM_SEP_V1 if nlm_v1 else 0) |
+                              (NLM_TILE32 if nlm_tile32 else 0),
                               _stream())
     _check(rc, "adaisp_process")
     return out

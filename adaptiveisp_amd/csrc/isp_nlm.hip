@@ -421,16 +421,21 @@ __global__ __launch_bounds__(kThreads) void k_nlm_sep(const float* __restrict__ 
 //   * red and green are interleaved in LDS: one ds_read_b64 per pixel, accumulated as (R,G) x (w,w); every LDS read
 //     uses an immediate offset from one base register.
 // ~100 VALU + 20 LDS instructions per shift for 8 pixels. Same association of the 25-term sum up to the order of the
-// five column sums (~1 ulp of the patch distance; parity rtol 1e-5 against the oracle). LDS 58 KB: 2 workgroups / CU.
+// five column sums (~1 ulp of the patch distance; parity rtol 1e-5 against the oracle).
 // ---------------------------------------------------------------------------------------------------------
-constexpr int HALF = TH / 2;                    // 16: distance between the two rows of a lane's pair
-constexpr int RQ = 4;                           // row pairs per lane
-constexpr int Y2ROWS = YROWS - HALF;            // 30 luminance pairs (a, a+16)
-constexpr int B2ROWS = CROWS - HALF;            // 26 blue pairs
-
+// RQ = row pairs per lane: 4 -> 32-row tile, 58 KB of LDS, 2 workgroups per CU; 3 -> 24-row tile, 48.5 KB, THREE
+// workgroups per CU (the kernel issues ~65 % of the time with two waves per SIMD; the third wave is worth more than the
+// 5-row column sums it re-computes: 7 squared differences per 3 outputs instead of 8 per 4). 720 = 30 x 24 and
+// 2160 = 90 x 24: no ragged tile row at the BASELINE sizes. Measured in one process (tools/nlm_ab.py), bit-identical
+// outputs: 8x720x1280 0.488 vs 0.538 ms, 4x2160x3840 1.904 vs 2.154 ms; a 16-row tile (4 per CU) 0.478 / 2.005 ms: no better.
+template <int RQ>
 __global__ __launch_bounds__(kThreads) void k_nlm_fwd(const float* __restrict__ img, float* __restrict__ out,
                                                       const int32_t* __restrict__ ids, int uniform_op,
                                                       const float* __restrict__ params, int pstride, int H, int W) {
+    constexpr int TH = 8 * RQ, HALF = TH / 2;       // HALF: distance between the two rows of a lane's pair
+    constexpr int YROWS = TH + 2 * HY, CROWS = TH + 2 * SR;
+    constexpr int Y2ROWS = YROWS - HALF;            // luminance pairs (a, a + HALF)
+    constexpr int B2ROWS = CROWS - HALF;            // blue pairs
     __shared__ v2f y2[Y2ROWS * SP];
     __shared__ v2f crg[CROWS * SP];
     __shared__ v2f cb2[B2ROWS * SP];
@@ -503,45 +508,79 @@ __global__ __launch_bounds__(kThreads) void k_nlm_fwd(const float* __restrict__ 
                 c[2 * i] = cc.x;
                 c[2 * i + 1] = cc.y;
             }
-            float D[8], t1[8], t2[8], P[8];
-            asm("s_nop 1\n\t"
-                "v_add_f32_dpp %8, %32, %32 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
-                "v_add_f32_dpp %9, %33, %33 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
-                "v_add_f32_dpp %10, %34, %34 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
-                "v_add_f32_dpp %11, %35, %35 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
-                "v_add_f32_dpp %12, %36, %36 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
-                "v_add_f32_dpp %13, %37, %37 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
-                "v_add_f32_dpp %14, %38, %38 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
-                "v_add_f32_dpp %15, %39, %39 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
-                "v_add_f32_dpp %24, %32, %32 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
-                "v_add_f32_dpp %25, %33, %33 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
-                "v_add_f32_dpp %26, %34, %34 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
-                "v_add_f32_dpp %27, %35, %35 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
-                "v_add_f32_dpp %28, %36, %36 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
-                "v_add_f32_dpp %29, %37, %37 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
-                "v_add_f32_dpp %30, %38, %38 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
-                "v_add_f32_dpp %31, %39, %39 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
-                "v_add_f32_dpp %16, %8, %32 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
-                "v_add_f32_dpp %17, %9, %33 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
-                "v_add_f32_dpp %18, %10, %34 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
-                "v_add_f32_dpp %19, %11, %35 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
-                "v_add_f32_dpp %20, %12, %36 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
-                "v_add_f32_dpp %21, %13, %37 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
-                "v_add_f32_dpp %22, %14, %38 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
-                "v_add_f32_dpp %23, %15, %39 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
-                "v_add_f32_dpp %0, %24, %16 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
-                "v_add_f32_dpp %1, %25, %17 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
-                "v_add_f32_dpp %2, %26, %18 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
-                "v_add_f32_dpp %3, %27, %19 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
-                "v_add_f32_dpp %4, %28, %20 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
-                "v_add_f32_dpp %5, %29, %21 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
-                "v_add_f32_dpp %6, %30, %22 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
-                "v_add_f32_dpp %7, %31, %23 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0"
-                : "=&v"(D[0]), "=&v"(D[1]), "=&v"(D[2]), "=&v"(D[3]), "=&v"(D[4]), "=&v"(D[5]), "=&v"(D[6]), "=&v"(D[7]),
-                  "=&v"(t1[0]), "=&v"(t1[1]), "=&v"(t1[2]), "=&v"(t1[3]), "=&v"(t1[4]), "=&v"(t1[5]), "=&v"(t1[6]), "=&v"(t1[7]),
-                  "=&v"(t2[0]), "=&v"(t2[1]), "=&v"(t2[2]), "=&v"(t2[3]), "=&v"(t2[4]), "=&v"(t2[5]), "=&v"(t2[6]), "=&v"(t2[7]),
-                  "=&v"(P[0]), "=&v"(P[1]), "=&v"(P[2]), "=&v"(P[3]), "=&v"(P[4]), "=&v"(P[5]), "=&v"(P[6]), "=&v"(P[7])
-                : "v"(c[0]), "v"(c[1]), "v"(c[2]), "v"(c[3]), "v"(c[4]), "v"(c[5]), "v"(c[6]), "v"(c[7]));
+            float D[2 * RQ], t1[2 * RQ], t2[2 * RQ], P[2 * RQ];
+            // t1 = c[i+1] + c[i], P = c[i-1] + c[i], t2 = t1[i+1] + c[i], D = P[i-1] + t2 (see above); one block per RQ
+            if constexpr (RQ == 4) {
+                asm("s_nop 1\n\t"
+                    "v_add_f32_dpp %8, %32, %32 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+                    "v_add_f32_dpp %9, %33, %33 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+                    "v_add_f32_dpp %10, %34, %34 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+                    "v_add_f32_dpp %11, %35, %35 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+                    "v_add_f32_dpp %12, %36, %36 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+                    "v_add_f32_dpp %13, %37, %37 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+                    "v_add_f32_dpp %14, %38, %38 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+                    "v_add_f32_dpp %15, %39, %39 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+                    "v_add_f32_dpp %24, %32, %32 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+                    "v_add_f32_dpp %25, %33, %33 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+                    "v_add_f32_dpp %26, %34, %34 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+                    "v_add_f32_dpp %27, %35, %35 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+                    "v_add_f32_dpp %28, %36, %36 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+                    "v_add_f32_dpp %29, %37, %37 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+                    "v_add_f32_dpp %30, %38, %38 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+                    "v_add_f32_dpp %31, %39, %39 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+                    "v_add_f32_dpp %16, %8, %32 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+                    "v_add_f32_dpp %17, %9, %33 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+                    "v_add_f32_dpp %18, %10, %34 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+                    "v_add_f32_dpp %19, %11, %35 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+                    "v_add_f32_dpp %20, %12, %36 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+                    "v_add_f32_dpp %21, %13, %37 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+                    "v_add_f32_dpp %22, %14, %38 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+                    "v_add_f32_dpp %23, %15, %39 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+                    "v_add_f32_dpp %0, %24, %16 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+                    "v_add_f32_dpp %1, %25, %17 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+                    "v_add_f32_dpp %2, %26, %18 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+                    "v_add_f32_dpp %3, %27, %19 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+                    "v_add_f32_dpp %4, %28, %20 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+                    "v_add_f32_dpp %5, %29, %21 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+                    "v_add_f32_dpp %6, %30, %22 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+                    "v_add_f32_dpp %7, %31, %23 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0"
+                    : "=&v"(D[0]), "=&v"(D[1]), "=&v"(D[2]), "=&v"(D[3]), "=&v"(D[4]), "=&v"(D[5]), "=&v"(D[6]), "=&v"(D[7]),
+                      "=&v"(t1[0]), "=&v"(t1[1]), "=&v"(t1[2]), "=&v"(t1[3]), "=&v"(t1[4]), "=&v"(t1[5]), "=&v"(t1[6]), "=&v"(t1[7]),
+                      "=&v"(t2[0]), "=&v"(t2[1]), "=&v"(t2[2]), "=&v"(t2[3]), "=&v"(t2[4]), "=&v"(t2[5]), "=&v"(t2[6]), "=&v"(t2[7]),
+                      "=&v"(P[0]), "=&v"(P[1]), "=&v"(P[2]), "=&v"(P[3]), "=&v"(P[4]), "=&v"(P[5]), "=&v"(P[6]), "=&v"(P[7])
+                    : "v"(c[0]), "v"(c[1]), "v"(c[2]), "v"(c[3]), "v"(c[4]), "v"(c[5]), "v"(c[6]), "v"(c[7]));
+            } else {
+                asm("s_nop 1\n\t"
+                    "v_add_f32_dpp %6, %24, %24 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+                    "v_add_f32_dpp %7, %25, %25 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+                    "v_add_f32_dpp %8, %26, %26 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+                    "v_add_f32_dpp %9, %27, %27 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+                    "v_add_f32_dpp %10, %28, %28 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+                    "v_add_f32_dpp %11, %29, %29 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+                    "v_add_f32_dpp %18, %24, %24 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+                    "v_add_f32_dpp %19, %25, %25 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+                    "v_add_f32_dpp %20, %26, %26 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+                    "v_add_f32_dpp %21, %27, %27 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+                    "v_add_f32_dpp %22, %28, %28 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+                    "v_add_f32_dpp %23, %29, %29 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+                    "v_add_f32_dpp %12, %6, %24 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+                    "v_add_f32_dpp %13, %7, %25 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+                    "v_add_f32_dpp %14, %8, %26 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+                    "v_add_f32_dpp %15, %9, %27 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+                    "v_add_f32_dpp %16, %10, %28 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+                    "v_add_f32_dpp %17, %11, %29 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+                    "v_add_f32_dpp %0, %18, %12 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+                    "v_add_f32_dpp %1, %19, %13 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+                    "v_add_f32_dpp %2, %20, %14 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+                    "v_add_f32_dpp %3, %21, %15 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+                    "v_add_f32_dpp %4, %22, %16 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+                    "v_add_f32_dpp %5, %23, %17 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0"
+                    : "=&v"(D[0]), "=&v"(D[1]), "=&v"(D[2]), "=&v"(D[3]), "=&v"(D[4]), "=&v"(D[5]),
+                      "=&v"(t1[0]), "=&v"(t1[1]), "=&v"(t1[2]), "=&v"(t1[3]), "=&v"(t1[4]), "=&v"(t1[5]),
+                      "=&v"(t2[0]), "=&v"(t2[1]), "=&v"(t2[2]), "=&v"(t2[3]), "=&v"(t2[4]), "=&v"(t2[5]),
+                      "=&v"(P[0]), "=&v"(P[1]), "=&v"(P[2]), "=&v"(P[3]), "=&v"(P[4]), "=&v"(P[5])
+                    : "v"(c[0]), "v"(c[1]), "v"(c[2]), "v"(c[3]), "v"(c[4]), "v"(c[5]));
+            }
             const v2f* rg = crg + (rb + SR - dy) * SP + lane + SR - dx;
             const v2f* bl = cb2 + (rb + SR - dy) * SP + lane + SR - dx;
 #pragma unroll
@@ -591,9 +630,12 @@ hipError_t launch_nlm(const Batch& a, hipStream_t s) {
         if (a.flags & ADAISP_NLM_SEP_V1)                 // the compiler-scheduled form of the same scheme (A/B, tests)
             hipLaunchKernelGGL(k_nlm_sep<false>, g, dim3(kThreads), 0, s, a.img, a.out, a.ids, a.uniform_op, a.params,
                                a.pstride, a.H, a.W, static_cast<const float*>(nullptr), static_cast<float*>(nullptr));
-        else
-            hipLaunchKernelGGL(k_nlm_fwd, g, dim3(kThreads), 0, s, a.img, a.out, a.ids, a.uniform_op, a.params, a.pstride,
+        else if (a.flags & ADAISP_NLM_TILE32)            // the 32-row tile (2 workgroups per CU): A/B, tests
+            hipLaunchKernelGGL(k_nlm_fwd<4>, g, dim3(kThreads), 0, s, a.img, a.out, a.ids, a.uniform_op, a.params, a.pstride,
                                a.H, a.W);
+        else
+            hipLaunchKernelGGL(k_nlm_fwd<3>, dim3(g.x, (a.H + 23) / 24, a.B), dim3(kThreads), 0, s, a.img, a.out, a.ids,
+                               a.uniform_op, a.params, a.pstride, a.H, a.W);
         return hipGetLastError();
     }
     dim3 grid((a.W + TW - 1) / TW, (a.H + TH - 1) / TH, a.B);

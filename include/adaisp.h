@@ -53,6 +53,8 @@ enum adaisp_op {
                                (isp/denoise.py:60-63) instead of the default 5x5 separable association; ~3.5x slower */
 #define ADAISP_NLM_SEP_V1 4u /* NLM: the compiler-scheduled form of the separable kernel (measurement / cross-check) */
 #define ADAISP_NO_USM 8u /* adaisp_forward: no image of the batch selects ADAISP_OP_USM (saves its empty launch) */
+#define ADAISP_NLM_TILE32 16u /* NLM: the 32-row tile of the default kernel (2 workgroups per CU) instead of the 24-row
+                                 one (3 per CU); same arithmetic, same results (measurement / cross-check) */
 
 /* error codes */
 #define ADAISP_OK          0

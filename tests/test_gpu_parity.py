@@ -83,7 +83,7 @@ def test_nlm_reference_order_kernel(golden, oracle_mod, tag):
 
 @pytest.mark.parametrize("shape", [(2, 64, 128), (1, 37, 53), (3, 5, 7), (1, 33, 260), (2, 96, 200)])
 def test_nlm_hand_scheduled_kernel_matches_compiled_form(oracle_mod, shape):
-    """The default forward kernel (packed row pairs, v_add_f32_dpp row sums in inline asm) against the compiler-
+    """The default forward kernel (packed row pairs, v_add_f32_dpp row sums in inline asm; both tile heights) against the compiler-
     scheduled form of the same scheme (ADAISP_NLM_SEP_V1) and the oracle, on ragged sizes; repeated launches must be
     bit-identical (a missing wait state around the inline asm shows up as run-to-run garbage)."""
     from adaptiveisp_amd import _lib
@@ -93,11 +93,15 @@ def test_nlm_hand_scheduled_kernel_matches_compiled_form(oracle_mod, shape):
     h = torch.linspace(0.02, 0.3, B, device=dev()).reshape(B, 1)
     fast = _lib.process(OPS["NLM"], img, h, clip=True)
     v1 = _lib.process(OPS["NLM"], img, h, clip=True, nlm_v1=True)
+    t32 = _lib.process(OPS["NLM"], img, h, clip=True, nlm_tile32=True)
     for _ in range(5):
         assert torch.equal(_lib.process(OPS["NLM"], img, h, clip=True), fast)
+        assert torch.equal(_lib.process(OPS["NLM"], img, h, clip=True, nlm_tile32=True), t32)
     ref = oracle_mod.forward(img.cpu().numpy(), OPS["NLM"], h.cpu().numpy(), clip=True)
     np.testing.assert_allclose(fast.cpu().numpy(), ref, rtol=RTOL, atol=ATOL)
     assert (fast - v1).abs().max().item() < 2e-6
+    # the 24-row (3 workgroups per CU, default) and the 32-row tile run the same per-pixel instruction sequence
+    assert torch.equal(fast, t32)
 
 
 @pytest.mark.parametrize("tag", ["a", "small", "exact", "hd"])
