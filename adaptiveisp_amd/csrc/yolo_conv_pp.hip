@@ -23,10 +23,15 @@
 // Restrictions (the launcher falls back otherwise): Cin % 64 == 0, Cout % 256 == 0.
 #include "yolo_internal.h"
 #include <type_traits>
+#include <cstdlib>
 #ifdef ADAYOLO_PLAIN_STORES   // A/B switch (measurement): keep the output lines in the XCD L2 instead of streaming them
 #define ADAYOLO_STORE(v, p) (*(p) = (v))
 #else
 #define ADAYOLO_STORE(v, p) __builtin_nontemporal_store((v), (p))
+#endif
+
+#ifndef PP_FUSE_HOIST
+#define PP_FUSE_HOIST 0      // weight fragments of the fused second layer requested ahead of the first layer's epilogue
 #endif
 
 namespace adayolo {
@@ -98,7 +103,15 @@ struct KPos {
 
 // ABL: 0 real kernel, 1 no DMA in the loop, 2 no LDS reads / MFMA, 3 no epilogue stores, 4 no k-loop, 5 no DMA
 // instructions in the loop, 6 no epilogue (measurement builds)
-template <int ABL>
+// FUSE: the tile holds ALL 256 output channels of its 256 pixels, so the 1x1 conv that consumes this layer's output
+// (Bottleneck.cv1 of the next block, 256 -> 128, HBM-bound on its own: it re-reads 60 MB that were just written) is
+// applied to the output tile while it sits in LDS: the epilogue puts the post-residual bf16 rows back into the waves'
+// regions, one barrier, then every wave computes 128 px x 32 ch of the second layer — its 32 weight rows (K = 256) are
+// loaded once into registers as the MFMA's channel operand (fragment-major copy of the weights, see below), the pixel
+// operand is read from the tile (pitch 144 B:
+// conflict-free ds_read_b128) — and writes it through its own region again. The second layer sees exactly the bf16 values
+// the unfused kernel would read back from memory.
+template <int ABL, bool FUSE>
 __global__ __launch_bounds__(512) void k_conv_pp(const ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float* bias_s = reinterpret_cast<float*>(smem + (kEpi > 2 * kBuf ? kEpi : 2 * kBuf));
@@ -189,6 +202,10 @@ __global__ __launch_bounds__(512) void k_conv_pp(const ConvArgs a) {
         return sel(live && ((amask[i] >> p.tap) & 1u), arow[i] + p.aoff, zaddr);
     };
     auto addr_w1 = [&](int h, int j, const KPos& p, bool live) { return sel(live, wrow[2 * h + j] + p.woff, zaddr); };
+    // (Measured and dropped: letting the twelve "dead" pieces a wave issues in a tile's last two k-tiles fetch residual
+    // rows instead of the zero page, as an L2 prefetch for the epilogue — with a residual the epilogue is 14.9k cycles
+    // instead of 6.4k, the 128 KB tile arriving cold at the per-CU streaming rate. The two extra 64-bit adds per piece
+    // in the load sections cost the k-loop 44.0k -> 57.8k cycles and bought the epilogue 1.3k.)
     auto stage_a = [&](int h, unsigned char* buf, const KPos& p, bool live) { stage_a1(h, 0, buf, p, live); stage_a1(h, 1, buf, p, live); };
     auto stage_w = [&](int h, unsigned char* buf, const KPos& p, bool live) { stage_w1(h, 0, buf, p, live); stage_w1(h, 1, buf, p, live); };
 
@@ -345,6 +362,10 @@ __global__ __launch_bounds__(512) void k_conv_pp(const ConvArgs a) {
         const long ostep = 8L * a.out_cs, rstep = kRes ? 8L * a.res_cs : 0;
         unsigned char* const wr = my + (lane & 31) * kEpiPitch + 8 * (lane >> 5);
         const unsigned char* const rd = my + r0 * kEpiPitch + chunk * 16;
+        // (With a residual this epilogue is 14.9k cycles instead of 6.4k: the 128 KB residual tile arrives cold from HBM at the
+        // per-CU streaming rate. Measured and dropped: requesting the rows 2 or 4 groups ahead instead of one — no change, the
+        // stream is rate-bound, not latency-bound — and starting the accumulators at the bias to free the registers for
+        // that — the k-loop lost 2-3k cycles to the changed register allocation.)
 #pragma unroll
         for (int mi = 0; mi < 4; ++mi) {
             u32x4 v[4], r[4];
@@ -384,8 +405,29 @@ __global__ __launch_bounds__(512) void k_conv_pp(const ConvArgs a) {
             for (int it = 0; it < 4; ++it)
                 if (ok[it] && !(ABL == 3 && v[it][0] != 0x12345678u))
                     ADAYOLO_STORE(v[it], reinterpret_cast<u32x4*>(op + (4 * mi + it) * ostep));
+            if (FUSE) {                                          // the rows the second layer reads: post-residual
+#pragma unroll
+                for (int it = 0; it < 4; ++it)
+                    *reinterpret_cast<u32x4*>(const_cast<unsigned char*>(rd) + (mi * 32 + it * 8) * kEpiPitch) = v[it];
+            }
         }
     };
+    // fused second layer: half of its weight fragments (32 registers: the k-loop's fragment registers are dead by now) are
+    // requested BEFORE the first layer's epilogue, which covers their latency
+    const int pm = wave >> 2, cq = wave & 3;
+    bf16x8 w2f[16];
+    float4 b2q[4];
+    if (FUSE) {
+        // w2 is stored fragment-major by the caller ([4 cq][16 kk][64 lanes][8]: lane (r, fq) of step kk holds
+        // w2[32 cq + r][16 kk + 8 fq .. + 8]): a wave's load is 1 KB contiguous. Read straight from the [128][256] matrix the
+        // same 16 loads touch 32 cache lines each — 4096 line lookups per workgroup on the CU's one texture-address path,
+        // measured +21 us per launch instead of +8.
+        // (the first half only: all sixteen next to the 128 accumulators of the epilogue spill; the second half is
+        // requested behind the epilogue and lands under the first eight steps of the second layer)
+        const unsigned short* wr2 = a.w2 + ((long)cq * 16 * 64 + lane) * 8;
+#pragma unroll
+        for (int kk = 0; kk < PP_FUSE_HOIST; ++kk) w2f[kk] = *reinterpret_cast<const bf16x8*>(wr2 + kk * 64 * 8);
+    }
     if (a.act == ADAYOLO_ACT_SILU) {
         if (a.res) epilogue(std::true_type{}, std::true_type{});
         else epilogue(std::true_type{}, std::false_type{});
@@ -394,13 +436,74 @@ __global__ __launch_bounds__(512) void k_conv_pp(const ConvArgs a) {
         else epilogue(std::false_type{}, std::false_type{});
     }
     PP_STAMP(6);
-    if (ABL == 7) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); PP_STAMP(7); }
+    if (ABL == 7 && !FUSE) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); PP_STAMP(7); }
+    if (FUSE) {
+        // ---- second layer: out2[px][n] = SiLU(bias2[n] + sum_k y[px][k] * w2[n][k]), k < 256, n < 128.
+        //      Wave -> pixel half pm (128 px = the regions of waves 4 pm .. 4 pm + 3, 64 channels of k each) x channel
+        //      quarter cq (32 ch). D[row = channel][col = pixel] as in the main loop.
+        {
+            const unsigned short* wr2 = a.w2 + ((long)cq * 16 * 64 + lane) * 8;
+#pragma unroll
+            for (int kk = PP_FUSE_HOIST; kk < 16; ++kk) w2f[kk] = *reinterpret_cast<const bf16x8*>(wr2 + kk * 64 * 8);
+        }
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) b2q[qd] = *reinterpret_cast<const float4*>(a.bias2 + cq * 32 + 8 * qd + 4 * (lane >> 5));
+        f32x16 acc2[4];
+#pragma unroll
+        for (int pf = 0; pf < 4; ++pf)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc2[pf][e] = 0.0f;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's rows are in LDS
+        barrier();                                           // ... and every other wave's
+        PP_STAMP(4);
+        const unsigned char* ybase = smem + pm * 4 * (128 * kEpiPitch) + (lane & 31) * kEpiPitch + 16 * (lane >> 5);
+        bf16x8 yf[2][4];                                     // pixel fragments of step kk / kk + 1
+#pragma unroll
+        for (int pf = 0; pf < 4; ++pf) yf[0][pf] = *reinterpret_cast<const bf16x8*>(ybase + pf * 32 * kEpiPitch);
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) {
+            if (kk + 1 < 16) {
+                const unsigned char* yk = ybase + ((kk + 1) >> 2) * (128 * kEpiPitch) + ((kk + 1) & 3) * 32;
+#pragma unroll
+                for (int pf = 0; pf < 4; ++pf) yf[(kk + 1) & 1][pf] = *reinterpret_cast<const bf16x8*>(yk + pf * 32 * kEpiPitch);
+            }
+#pragma unroll
+            for (int pf = 0; pf < 4; ++pf)
+                acc2[pf] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2f[kk], yf[kk & 1][pf], acc2[pf], 0, 0, 0);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        barrier();                                           // every wave has read the tile: the regions are free again
+        PP_STAMP(5);
+        {
+            unsigned char* const wr = my + (lane & 31) * kEpiPitch + 8 * (lane >> 5);
+#pragma unroll
+            for (int pf = 0; pf < 4; ++pf)
+#pragma unroll
+                for (int qd = 0; qd < 4; ++qd) {
+                    unsigned lo, hi;
+                    bias_act_pack4<true>(acc2[pf][4 * qd], acc2[pf][4 * qd + 1], acc2[pf][4 * qd + 2], acc2[pf][4 * qd + 3], b2q[qd], lo, hi);
+                    *reinterpret_cast<u32x2*>(wr + pf * 32 * kEpiPitch + 8 * qd * 2) = u32x2{lo, hi};
+                }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // same wave wrote and reads
+            // 128 px x 64 B: a lane takes 16 B (8 channels) of pixel (lane >> 2) + 16 it
+            const int c4 = lane & 3, r0 = lane >> 2;
+            const int mrow = m0 + pm * 128 + r0;
+            unsigned short* const op2 = a.out2 + (long)mrow * a.out2_cs + cq * 32 + c4 * 8;
+            u32x4 v2[8];
+#pragma unroll
+            for (int it = 0; it < 8; ++it) v2[it] = *reinterpret_cast<const u32x4*>(my + (r0 + 16 * it) * kEpiPitch + c4 * 16);
+#pragma unroll
+            for (int it = 0; it < 8; ++it)
+                if (mrow + 16 * it < a.M) ADAYOLO_STORE(v2[it], reinterpret_cast<u32x4*>(op2 + (long)(16 * it) * a.out2_cs));
+        }
+        if (ABL == 7) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); PP_STAMP(7); }
+    }
 }
 
-template <int ABL>
+template <int ABL, bool FUSE = false>
 static hipError_t launch(ConvArgs a, hipStream_t s) {
     static_assert(kSmem <= 160 * 1024, "LDS budget");
-    auto kern = k_conv_pp<ABL>;
+    auto kern = k_conv_pp<ABL, FUSE>;
     static bool configured = false;
     if (!configured) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -430,6 +533,13 @@ hipError_t launch_conv_pp(ConvArgs a, hipStream_t s, int variant) {
     if (variant == 57) return pp::launch<7>(a, s);
 #endif
     (void)variant;
+    if (a.w2) {                                          // fused 1x1 second layer: the tile must hold all channels
+        if (a.Cout != 256 || !a.bias2 || !a.out2) return hipErrorInvalidValue;
+#ifdef ADAYOLO_MEASURE
+        if (getenv("ADAYOLO_PP_STAMPS")) return pp::launch<7, true>(a, s);
+#endif
+        return pp::launch<0, true>(a, s);
+    }
     return pp::launch<0>(a, s);
 }
 

@@ -17,6 +17,10 @@ struct ConvArgs {
     // division by Ho*Wo and by Wo as multiply-high + shift (exact for 0 <= n < 2^31; sh < 0: divisor is 1)
     unsigned magic_hw, magic_w;
     int sh_hw, sh_w;
+    // fused second layer (yolo_conv_pp.hip, Cout == 256 only): a 1x1 conv 256 -> 128 + bias + SiLU applied to this conv's
+    // OUTPUT tile while it is in LDS (Bottleneck.cv1 of the next block); null = not fused
+    const unsigned short* w2; const float* bias2;
+    unsigned short* out2; int out2_cs;
 };
 
 // Epilogue math on channel pairs: packed fp32 (v_pk_add/mul_f32 do two channels per issue slot; the two transcendentals

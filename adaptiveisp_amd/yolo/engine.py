@@ -70,6 +70,7 @@ class YoloEngine:
         self.na, self.no, self.nc = det.na, det.no, det.nc
         self._keep = []          # tensors referenced by raw pointers in the plan
         self.plan = []
+        self.fused_pairs = 0
         self._build(model)
         if head_chunks is None and os.environ.get("ADAYOLO_HEAD_CHUNKS"):
             head_chunks = int(os.environ["ADAYOLO_HEAD_CHUNKS"])
@@ -249,6 +250,7 @@ class YoloEngine:
                     if kind == "conv":
                         args[16] = table[tuple(args[8:16])]
                 self.tuned = {k: table[k] for k in keys}
+                self.fuse_pairs()
                 return self.tuned
         with torch.cuda.device(self.dev):
             for kind, fn, args in entries:
@@ -281,6 +283,7 @@ class YoloEngine:
                     chosen[key] = best[0]
                 args[16] = chosen[key]
         self.tuned = chosen
+        self.fuse_pairs()
         if cache and write:
             try:
                 try:
@@ -298,6 +301,41 @@ class YoloEngine:
         return chosen
 
     # ------------------------------------------------------------------------------------------
+    _pair_fusion = True                                  # (the eval plan only: the training engine's tfwd / tbwd lists are separate)
+
+    def fuse_pairs(self):
+        """Bottleneck.cv2 of one block + Bottleneck.cv1 of the next in ONE launch (adayolo_conv_fused1x1_fwd) wherever the
+        first conv runs on the 256 x 256 kernel (variant 50) with all its 256 output channels in one tile and the second is
+        the 1x1 256 -> 128 + SiLU that reads exactly that output: the 1x1 layers of the C = 256 stage are HBM-bound on their
+        own. Runs after the variants are known (autotune); ADAYOLO_FUSE_1X1=0 keeps the layers separate. Returns the
+        number of fused pairs."""
+        self.fused_pairs = getattr(self, "fused_pairs", 0)
+        if not self._pair_fusion or os.environ.get("ADAYOLO_FUSE_1X1", "1") != "1":
+            return 0
+        out, i, n, P = [], 0, 0, self.plan
+        first_free = 3 if self._head_next is not None else 2      # the head's launches are addressed by plan index
+        while i < len(P):
+            kind, fn, a = P[i]
+            if i >= first_free and kind == "conv" and i + 1 < len(P) and P[i + 1][0] == "conv":
+                b = P[i + 1][2]
+                Ho, Wo = (a[9] - 1) // a[14] + 1, (a[10] - 1) // a[14] + 1
+                if (a[12] == 256 and a[16] == 50 and a[11] % 64 == 0 and b[11] == 256 and b[12] == 128 and b[13] == 1 and
+                        b[14] == 1 and b[15] == _lib.ACT_SILU and b[4] is None and b[0].value == a[6].value and
+                        b[1] == a[7] and (b[8], b[9], b[10]) == (a[8], Ho, Wo)):
+                    # the second layer's weights in the fragment-major order the fused epilogue loads (include/adayolo.h)
+                    w2 = next(o["w"] for o in self.ops if o["kind"] == "conv" and o["w"].data_ptr() == b[2].value)
+                    w2p = w2.reshape(4, 32, 16, 2, 8).permute(0, 2, 3, 1, 4).contiguous()
+                    self._keep.append(w2p)
+                    out.append(("conv2", self.L.adayolo_conv_fused1x1_fwd,
+                                list(a[:16]) + [ctypes.c_void_p(w2p.data_ptr()), b[3], b[6], b[7], 128]))
+                    i, n = i + 2, n + 1
+                    continue
+            out.append(P[i])
+            i += 1
+        self.plan = out
+        self.fused_pairs += n
+        return n
+
     def forward(self, img):
         """img: planar fp32 [B,3,H,W] in [0,1] on the engine's device -> pred fp32 [B, N, 85] (eval decode)."""
         if img.shape != (self.B, 3, self.H, self.W) or img.dtype != torch.float32 or img.device != self.dev:

@@ -34,7 +34,7 @@ TUNE_CACHE = os.path.join(ROOT, "adaptiveisp_amd", "yolo", "tuning", "mi355x.jso
 CONV_KERNEL_NAMES = {2: "dma::k_conv_igemm_dma<128,128,2,2,2>", 5: "dma2::k_conv_igemm_dma32<128,128,2,2,2,0,64,1>",
                      22: "dma2::k_conv_igemm_dma32<128,64,4,1,4,0,32,1>", 26: "dma2::k_conv_igemm_dma32<128,256,2,4,3,0,32,4>",
                      27: "dma2::k_conv_igemm_dma32<256,128,4,2,3,0,32,4>", 40: "smallk::k_conv3x3_small<...>",
-                     50: "pp::k_conv_pp<0>", 60: "pp128::k_conv_pp128<0>", 80: "pq::k_conv_pq<0>"}
+                     50: "pp::k_conv_pp<0, false>", 58: "pp::k_conv_pp<0, true>", 60: "pp128::k_conv_pp128<0>", 80: "pq::k_conv_pq<0>"}
 
 
 def parse():
@@ -168,11 +168,24 @@ def time_dominant_conv(engine, x, reps=3):
     bracketed by a HIP event pair on the launch stream (inputs come from the layer before, not from a warm repeat of
     the same layer — one launch at a time on hot caches reads 10 % faster). rocprofv3 --kernel-trace --stats of the same
     command (profiles/) reports the same kernel's average without the ~5 us the event pair adds."""
+    FUSED = 58                     # pseudo-variant: variant 50 with the next block's 1x1 fused into its epilogue
+
+    def entry(kind, args):
+        """(variant, flops) of a conv launch of the plan; (None, 0) for everything else."""
+        if kind not in ("conv", "conv2"):
+            return None, 0.0
+        B, H, W, cin, cout, k, s = args[8:15]
+        Ho, Wo = (H - 1) // s + 1, (W - 1) // s + 1
+        fl = 2.0 * B * Ho * Wo * cout * k * k * cin
+        if kind == "conv2":
+            return FUSED, fl + 2.0 * B * Ho * Wo * cout * args[20]
+        return args[16], fl
+
     by_variant = {}
     for kind, fn, args in engine.plan:
-        if kind == "conv":
-            Ho, Wo = (args[9] - 1) // args[14] + 1, (args[10] - 1) // args[14] + 1
-            by_variant[args[16]] = by_variant.get(args[16], 0.0) + 2.0 * args[8] * Ho * Wo * args[12] * args[13] ** 2 * args[11]
+        v, fl = entry(kind, args)
+        if v is not None:
+            by_variant[v] = by_variant.get(v, 0.0) + fl
     dominant = max(by_variant, key=by_variant.get)
     pairs = []
 
@@ -188,10 +201,9 @@ def time_dominant_conv(engine, x, reps=3):
 
     plan, wrapped, nsel = engine.plan, [], 0
     for kind, fn, args in plan:
-        if kind == "conv" and args[16] == dominant:
-            B, H, W, cin, cout, k, s = args[8:15]
-            Ho, Wo = (H - 1) // s + 1, (W - 1) // s + 1
-            wrapped.append((kind, bracket(fn, 2.0 * B * Ho * Wo * cout * k * k * cin), args))
+        v, fl = entry(kind, args)
+        if v == dominant:
+            wrapped.append((kind, bracket(fn, fl), args))
             nsel += 1
         else:
             wrapped.append((kind, fn, args))

@@ -50,6 +50,25 @@ int adayolo_conv_fwd(const void* in, int in_cstride,
                      int ksize, int stride, int act, void* stream);
 
 /*
+ * Two layers in one launch: Conv(Cin -> 256, k, stride) + bias + act (+ residual) -> `out`, and on that output tile, while
+ * it is in LDS, Conv(256 -> 128, k1) + bias2 + SiLU -> `out2`. This is Bottleneck.cv2 of one block followed by
+ * Bottleneck.cv1 of the next (yolov3/models/common.py:110-120): the 1x1 conv is HBM-bound on its own (it re-reads what
+ * was just written); fused, its input never comes back from memory. `out2` equals what adayolo_conv_fwd would produce
+ * from `out` (the second layer reads the bf16-rounded rows of `out`). bias2: fp32 [128]. weight2: the bf16 [128][256] matrix
+ * w2 stored FRAGMENT-MAJOR, [4][16][2][32][8]: element [c][kk][f][r][j] = w2[32 c + r][16 kk + 8 f + j] (a wave's MFMA
+ * operand load is then 1 KB contiguous; YoloEngine packs it once: view(4,32,16,2,8).permute(0,2,3,1,4)).
+ * Shapes: Cout == 256, Cout2 == 128, Cin % 64 == 0 (ADAYOLO_ESHAPE otherwise — the caller runs the two layers separately).
+ */
+int adayolo_conv_fused1x1_fwd(const void* in, int in_cstride,
+                              const void* weight, const float* bias,
+                              const void* residual, int res_cstride,
+                              void* out, int out_cstride,
+                              int B, int H, int W, int Cin, int Cout,
+                              int ksize, int stride, int act,
+                              const void* weight2, const float* bias2,
+                              void* out2, int out2_cstride, int Cout2, void* stream);
+
+/*
  * Same as adayolo_conv_fwd with an explicit kernel (what YoloEngine.autotune picks per layer; results agree to the
  * bf16 rounding of the output, tests/test_gpu_yolo_variants.py): 0 = library default (= 2); 2 = LDS-DMA ring, 16x16x32
  * MFMA; 5 / 22 / 26 / 27 = lean-address LDS-DMA ring on 32x32x16 MFMA with tiles 128x128 (by shape) / 128x64 /

@@ -162,6 +162,7 @@ def _tuned_engine_vs_module_tree(B, H, W, images):
     assert set(tuned.values()) - {2}, "the tuning table must route layers to the specialised kernels"
     if (B, H, W) == (8, 720, 1280):
         assert set(tuned.values()) >= {50, 60}, "BASELINE shape: table lost the ping-pong kernels"
+        assert eng.fused_pairs >= 8, f"BASELINE shape: only {eng.fused_pairs} 3x3 + 1x1 pairs run fused"
     pred = eng(x).clone()
     raws = [r.clone() for r in eng.raw_maps()]
     torch.cuda.synchronize()
@@ -178,6 +179,19 @@ def _tuned_engine_vs_module_tree(B, H, W, images):
         rel = ((pred[i:i + 1] - ref_pred).abs() / (ref_pred.abs() + 1.0)).max().item()
         assert rel < 2e-2, f"image {i}: decoded prediction rel err {rel}"
         del ref_pred, ref_raw
+    # the same engine with every layer launched separately: the fused pairs must not move the result beyond rounding
+    if eng.fused_pairs:
+        os.environ["ADAYOLO_FUSE_1X1"] = "0"
+        try:
+            eng2 = YoloEngine(m.to("cpu"), B, H, W, device=DEV)
+            eng2.autotune(cache=TUNE)
+            assert eng2.fused_pairs == 0
+            pred2 = eng2(x)
+            torch.cuda.synchronize()
+            rel = ((pred - pred2).abs() / (pred2.abs() + 1.0)).max().item()
+            assert rel < 2e-2, f"fused vs separate launches: rel err {rel}"
+        finally:
+            del os.environ["ADAYOLO_FUSE_1X1"]
     m.to("cpu")
     return tuned
 
@@ -191,3 +205,68 @@ def test_tuned_engine_baseline_size_vs_fp32_module_tree():
 def test_tuned_engine_4k_vs_fp32_module_tree():
     """Config 5 detector (4 x 2160 x 3840 -> letterboxed 2176): one image against the fp32 module tree."""
     _tuned_engine_vs_module_tree(4, 2160, 3840, images=(3,))
+
+
+FUSED_CASES = [  # B, H, W, Cin, k, s, residual — the first layer always has 256 output channels, the second is 1x1 256 -> 128
+    (8, 92, 160, 128, 3, 1, True), (8, 184, 320, 128, 3, 2, False), (2, 19, 33, 128, 3, 1, True), (1, 7, 9, 64, 3, 2, False),
+    (3, 9, 11, 64, 1, 1, False), (1, 5, 6, 512, 3, 1, True),
+]
+
+
+@pytest.mark.parametrize("case", FUSED_CASES, ids=lambda c: "x".join(map(str, c)))
+def test_fused_3x3_plus_1x1(case):
+    """adayolo_conv_fused1x1_fwd = Bottleneck.cv2 of one block + Bottleneck.cv1 of the next in one launch (reference:
+    yolov3/models/common.py:110-120). `out` must be BIT-IDENTICAL to the unfused kernel's, `out2` must equal the 1x1 conv of
+    that bf16 output (fp32 reference, <= 2e-2 of scale; and within bf16 rounding of the separate 1x1 launch), four
+    launches bit-identical, NaN-prefilled outputs fully written."""
+    from adaptiveisp_amd.yolo import _lib
+    L = _lib.load()
+    B, H, W, cin, k, s, use_res = case
+    g = torch.Generator(device="cpu").manual_seed(H * 31 + cin)
+    x = torch.randn(B, H, W, cin, generator=g).to(torch.bfloat16).to(DEV)
+    w = (torch.randn(256, k, k, cin, generator=g) / (k * k * cin) ** 0.5).to(torch.bfloat16).to(DEV)
+    b = torch.randn(256, generator=g).to(DEV)
+    w2 = (torch.randn(128, 1, 1, 256, generator=g) / 16.0).to(torch.bfloat16).to(DEV)
+    b2 = torch.randn(128, generator=g).to(DEV)
+    Ho, Wo = (H - 1) // s + 1, (W - 1) // s + 1
+    res = torch.randn(B, Ho, Wo, 256, generator=g).to(torch.bfloat16).to(DEV) if use_res else None
+    P = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None  # noqa: E731
+    w2p = w2.reshape(4, 32, 16, 2, 8).permute(0, 2, 3, 1, 4).contiguous()      # fragment-major (include/adayolo.h)
+    first = None
+    for _ in range(4):
+        out = torch.full((B, Ho, Wo, 256), float("nan"), dtype=torch.bfloat16, device=DEV)
+        out2 = torch.full((B, Ho, Wo, 128), float("nan"), dtype=torch.bfloat16, device=DEV)
+        rc = L.adayolo_conv_fused1x1_fwd(P(x), cin, P(w), P(b), P(res), 256 if use_res else 0, P(out), 256, B, H, W, cin, 256,
+                                         k, s, 1, P(w2p), P(b2), P(out2), 128, 128, _lib.stream_ptr())
+        _lib.check(rc, "fused conv")
+        torch.cuda.synchronize()
+        if first is None:
+            first = (out, out2)
+        else:
+            assert torch.equal(first[0].view(torch.int16), out.view(torch.int16)), "run-to-run difference (out)"
+            assert torch.equal(first[1].view(torch.int16), out2.view(torch.int16)), "run-to-run difference (out2)"
+    out, out2 = first
+    assert torch.isfinite(out.float()).all() and torch.isfinite(out2.float()).all(), "unwritten (NaN) outputs"
+    sep = _run_variant(x, w, b, res, k, s, 1, 50, reps=1)
+    assert torch.equal(sep.view(torch.int16), out.view(torch.int16)), "first layer differs from the unfused kernel"
+    ref2 = _reference(out, w2, b2, None, 1, 1, 1)                       # the second layer reads the bf16 output
+    scale = max(1.0, ref2.abs().max().item())
+    d = (out2.float() - ref2).abs()
+    assert d.max().item() <= 2e-2 * scale and d.mean().item() <= 2e-3 * scale, (d.max().item(), d.mean().item(), scale)
+    sep2 = _run_variant(out, w2, b2, None, 1, 1, 1, 80, reps=1)
+    assert (out2.float() - sep2.float()).abs().max().item() <= 2.0 ** -6 * scale     # two bf16 roundings of the same sum
+
+
+def test_fused_entry_rejects_other_shapes():
+    from adaptiveisp_amd.yolo import _lib
+    L = _lib.load()
+    t = torch.zeros(1, 8, 8, 256, dtype=torch.bfloat16, device=DEV)
+    f = torch.zeros(256, device=DEV)
+    P = lambda v: ctypes.c_void_p(v.data_ptr())  # noqa: E731
+    # first layer with 128 output channels: its tile does not hold what the second layer needs
+    rc = L.adayolo_conv_fused1x1_fwd(P(t), 256, P(t), P(f), None, 0, P(t), 128, 1, 8, 8, 256, 128, 1, 1, 1, P(t), P(f), P(t), 128, 128,
+                                     _lib.stream_ptr())
+    assert rc != 0
+    rc = L.adayolo_conv_fused1x1_fwd(P(t), 256, P(t), P(f), None, 0, P(t), 256, 1, 8, 8, 256, 256, 1, 1, 1, None, P(f), P(t), 128, 128,
+                                     _lib.stream_ptr())
+    assert rc != 0
