@@ -258,7 +258,9 @@ __global__ __launch_bounds__(kThreads) void k_pointwise(const float* __restrict_
                                                         const float* __restrict__ params, int pstride,
                                                         long plane, unsigned flags) {
     const int b = blockIdx.y;
-    const int op = ids ? ids[b] : uniform_op;
+    int op = ids ? ids[b] : uniform_op;
+    // an id no kernel family owns (the ids live on the device: the host cannot reject it) gives the zero image, like -1
+    if (!op_is_pointwise(op) && !op_is_conv(op) && op != ADAISP_OP_NLM) op = ADAISP_OP_ZERO;
     const float* in = img + (long)b * 3 * plane;
     float* o = out + (long)b * 3 * plane;
     const float* p = params + (long)b * pstride;

@@ -65,12 +65,14 @@ int adayolo_conv_fwd_variant(const void* in, int in_cstride, const void* weight,
         case 50: known = true; e = launch_conv_pp(a, s, variant); break;          // Cin % 64 == 0, Cout % 256 == 0 only
         case 60: known = true; e = launch_conv_pp128(a, s, variant); break;       // Cin % 64 == 0, Cout % 128 == 0 only
         case 80: known = true; e = launch_conv_pq(a, s, variant); break;          // Cin % 32 == 0, Cout % 128 == 0
+        case 90: known = true; e = launch_conv_ws(a, s, variant); break;          // 3x3 s1, Cin 32 / 64, Cout % 64 == 0, SiLU
         default: break;
     }
 #ifdef ADAYOLO_MEASURE
     if (!known) {
         known = true;
-        if (variant >= 80) e = launch_conv_pq(a, s, variant);
+        if (variant >= 90) e = launch_conv_ws(a, s, variant);
+        else if (variant >= 80) e = launch_conv_pq(a, s, variant);
         else if (variant >= 60) e = launch_conv_pp128(a, s, variant);
         else if (variant >= 50) e = launch_conv_pp(a, s, variant);
         else e = launch_conv_dma2(a, s, variant);

@@ -1,0 +1,258 @@
+// 3x3 stride-1 Conv + bias + SiLU (+ residual) for the SHALLOW layers (Cin = 32 or 64) — weights stationary in
+// REGISTERS, activations as a patch in LDS, persistent workgroups.
+//
+// What bounds the implicit-GEMM kernels is the L2 -> LDS byte rate a CU sustains (~27 B/clk); at
+// Cin = 64 a 256 x 128 tile moves 442 KB for 38 MFLOP — the early layers run at 430-640 TFLOP/s, 1.5-2x above their HBM
+// floor. Here almost nothing crosses that path:
+//   * K = 9 Cin <= 576: the weights of a wave's 32 output channels are 18 / 36 MFMA operand fragments = 72 / 144
+//     registers, loaded ONCE per workgroup; a workgroup keeps its 64 output channels for every tile it processes;
+//   * the activations of a 16 x 16 pixel tile are its 18 x 18 input patch (Cin = 64: 41 KB) staged once by LDS-DMA (buffer
+//     descriptor: pixels outside the image are out-of-range offsets, the DMA writes zeros) and read by all nine taps —
+//     a tap is a shifted patch row, i.e. address arithmetic; two patch buffers, the next tile's patch lands under this
+//     tile's MFMAs;
+//   * 8 waves = 4 pixel groups (4 tile rows = 64 px) x 2 channel groups (32 ch): per tile 72 MFMAs and 72 ds_read_b128
+//     per wave (Cin = 64), two waves per SIMD; the epilogue goes through one LDS tile (bias + SiLU + bf16 in the
+//     accumulator layout, then 128-byte pixel rows + residual), three barriers per tile.
+// Restrictions (the launcher falls back otherwise): ksize 3, stride 1, Cin in {32, 64}, Cout % 64 == 0, 32-bit offsets.
+#include "yolo_internal.h"
+#include <type_traits>
+
+namespace adayolo {
+namespace ws {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+constexpr int TH = 16, TW = 16, PH = TH + 2, PW = TW + 2, PROWS = PH * PW;   // 18 x 18 = 324 patch pixels
+constexpr int BN = 64;                               // output channels per workgroup
+constexpr int kOutPitch = 144;                       // bytes per pixel row of the output tile (64 ch + pad)
+constexpr int kOutBytes = TH * TW * kOutPitch;       // 36 KB
+constexpr unsigned kOOB = 0xFFFFFFFFu;
+constexpr unsigned kRecords = 0xFFFFFF00u;
+constexpr unsigned kDescFlags = 0x00020000u;
+
+__device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_pk{lo, hi}, bf16x2));
+}
+__device__ __forceinline__ void barrier() {
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+}
+// swizzle key of a patch row whose rows are CIN*2 bytes (64 B -> 4 rows per 256-B bank row, 128 B -> 2)
+template <int CIN>
+__device__ __forceinline__ int row_key(int r) { return CIN == 32 ? ((r >> 2) & 3) : ((r >> 1) & 7); }
+
+template <int CIN, bool RES>
+__global__ __launch_bounds__(512) void k_conv_ws(const ConvArgs a, const int tiles_x, const int tiles_y, const int nchunks) {
+    constexpr int RB = CIN * 2;                      // bytes per patch row (one pixel)
+    constexpr int CH = CIN / 8;                      // 16-byte chunks per row
+    constexpr int RPD = 64 / CH;                     // patch rows per DMA instruction (8 / 16)
+    constexpr int PINS = (PROWS + RPD - 1) / RPD;    // DMA instructions per patch (41 / 21)
+    constexpr int NP = (PINS + 7) / 8;               // ... per wave (6 / 3)
+    constexpr int PBYTES = PINS * RPD * RB;          // 41 984 / 21 504
+    constexpr int KK = CIN / 16;                     // MFMA k-steps per tap (4 / 2)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* const pbuf0 = smem;
+    unsigned char* const obuf = smem + 2 * PBYTES;
+    float* const bias_s = reinterpret_cast<float*>(smem + 2 * PBYTES + kOutBytes);   // [64]: re-read per tile (16 registers)
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int pg = wave & 3, cg = wave >> 2;         // pixel group (tile rows 4 pg .. 4 pg + 3), channel group (32 ch)
+    // the workgroup's channel chunk is fixed (weights stay in registers); it strides through the pixel tiles
+    const int nwg_per_chunk = gridDim.x / nchunks;
+    // the workgroups that take the same pixel tiles for different channel chunks sit on ONE XCD (block b runs on XCD b % 8):
+    // the second one reads the patch from that XCD's L2
+    int chunk, slot0;
+    if ((nwg_per_chunk & 7) == 0) {
+        const int q = blockIdx.x >> 3;
+        chunk = q % nchunks;
+        slot0 = (q / nchunks) * 8 + (blockIdx.x & 7);
+    } else {
+        chunk = blockIdx.x % nchunks;
+        slot0 = blockIdx.x / nchunks;
+    }
+    const int n0 = chunk * BN;
+    const int ntiles = a.B * tiles_y * tiles_x;
+
+    // ---- weights: fragment (tap, kk) of channel 32 cg + (lane & 31): k-chunk (lane >> 5) -> 8 consecutive input channels
+    bf16x8 wreg[9][KK];
+    {
+        const unsigned short* wp = a.w + (long)(n0 + cg * 32 + (lane & 31)) * (9 * CIN) + 8 * (lane >> 5);
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+            for (int kk = 0; kk < KK; ++kk) wreg[tap][kk] = *reinterpret_cast<const bf16x8*>(wp + tap * CIN + kk * 16);
+    }
+    if (tid < BN) bias_s[tid] = a.bias[n0 + tid];     // (visible behind the first barrier of the tile loop)
+
+    // ---- patch DMA: piece i of this wave covers patch rows [(wave + 8 i) RPD, + RPD); lane -> row, 16-byte slot
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, 0, kRecords, kDescFlags);
+    const int dslot = lane % CH, drow = lane / CH;
+    unsigned pinfo[NP];                              // this lane's row in piece i: patch y << 16 | patch x << 8 | source chunk
+#pragma unroll                                       // (after the swizzle); y >= PH: past the end of the patch
+    for (int i = 0; i < NP; ++i) {
+        const int rr = (wave + 8 * i) * RPD + drow;
+        const int py = rr / PW;
+        pinfo[i] = ((unsigned)py << 16) | ((unsigned)(rr - py * PW) << 8) | (unsigned)(dslot ^ row_key<CIN>(rr));
+    }
+    auto tile_coords = [&](int t, int& b, int& oy0, int& ox0) {
+        const int tx = t % tiles_x, r = t / tiles_x;
+        ox0 = tx * TW; oy0 = (r % tiles_y) * TH; b = r / tiles_y;
+    };
+    auto stage_patch = [&](int t, unsigned char* dst) {
+        int b, oy0, ox0;
+        tile_coords(t < ntiles ? t : ntiles - 1, b, oy0, ox0);
+        const bool live = t < ntiles;
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            if ((wave + 8 * i) < PINS) {             // (uniform) the last instruction slot of some waves is past the patch
+                const int py = (int)(pinfo[i] >> 16), px = (int)((pinfo[i] >> 8) & 0xFFu);
+                const int iy = oy0 - 1 + py, ix = ox0 - 1 + px;
+                const bool ok = (int)live & (py < PH) & (iy >= 0) & (iy < a.H) & (ix >= 0) & (ix < a.W);
+                const unsigned voff = ok ? 2u * (unsigned)(((b * a.H + iy) * a.W + ix) * a.in_cs) + 16u * (pinfo[i] & 0xFFu) : kOOB;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr_t)(dst + (wave + 8 * i) * RPD * RB), 16, voff, 0, 0, 0);
+            }
+        }
+    };
+
+    // ---- fragment addressing: MFMA column = pixel (lane & 31) of a 32-pixel fragment = tile rows (2 pf, 2 pf + 1) of this
+    //      wave's four, 16 px each; k-chunk fq = lane >> 5
+    const int fq = lane >> 5;
+    int prow0[2];                                    // patch row of the pixel's (kh = 0, kw = 0) tap
+#pragma unroll
+    for (int pf = 0; pf < 2; ++pf) prow0[pf] = (pg * 4 + pf * 2 + ((lane & 31) >> 4)) * PW + (lane & 15);
+
+    int t = slot0;
+    stage_patch(t, pbuf0);
+    stage_patch(t + nwg_per_chunk, pbuf0 + PBYTES);
+    int cur = 0;
+    for (; t < ntiles; t += nwg_per_chunk, cur ^= 1) {
+        unsigned char* const pb = pbuf0 + cur * PBYTES;
+        int b, oy0, ox0;
+        tile_coords(t, b, oy0, ox0);
+        // patch(t) was requested a whole tile ago (the first one: just now); everything this wave has in flight is older
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        barrier();
+        f32x16 acc[2];                                // start at the bias: channels 8 qd + 4 fq + (0..3) of the wave's 32
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) {
+            const float4 b4 = *reinterpret_cast<const float4*>(bias_s + cg * 32 + 8 * qd + 4 * fq);
+#pragma unroll
+            for (int pf = 0; pf < 2; ++pf) {
+                acc[pf][4 * qd] = b4.x; acc[pf][4 * qd + 1] = b4.y; acc[pf][4 * qd + 2] = b4.z; acc[pf][4 * qd + 3] = b4.w;
+            }
+        }
+        // (the fragment addresses of all nine taps are loop-invariant: left visible, hipcc hoists 72 of them out of the tile
+        // loop, spills them and reloads each one — scratch_load + vmcnt(0) — in front of its MFMA. Opaque per tile: ~10 VALU
+        // per tap in the loop instead.)
+        int p0[2] = {prow0[0], prow0[1]};
+        asm volatile("" : "+v"(p0[0]), "+v"(p0[1]));
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int toff = (tap / 3) * PW + (tap % 3);
+            int aoff[2], akey[2];
+#pragma unroll
+            for (int pf = 0; pf < 2; ++pf) {
+                const int rr = p0[pf] + toff;
+                aoff[pf] = rr * RB;
+                akey[pf] = row_key<CIN>(rr);
+            }
+            // one tap = 2 KK fragment reads, then their MFMAs; the fence keeps hipcc from hoisting the reads of all nine taps
+            // (it does: ~130 registers of fragments next to the 144 of weights -> spills); the SIMD's other wave covers the
+            // LDS latency at a tap's start
+            bf16x8 af[KK][2];
+#pragma unroll
+            for (int kk = 0; kk < KK; ++kk)
+#pragma unroll
+                for (int pf = 0; pf < 2; ++pf)
+                    af[kk][pf] = *reinterpret_cast<const bf16x8*>(pb + aoff[pf] + (((kk * 2 + fq) ^ akey[pf]) << 4));
+#pragma unroll
+            for (int kk = 0; kk < KK; ++kk)
+#pragma unroll
+                for (int pf = 0; pf < 2; ++pf)
+                    acc[pf] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wreg[tap][kk], af[kk][pf], acc[pf], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        barrier();                                   // every wave has read patch(t): its buffer takes patch(t + 2)
+        stage_patch(t + 2 * nwg_per_chunk, pb);
+        // ---- epilogue: D[row = channel][col = pixel]; lane holds pixel (lane & 31) and channels 8 qd + 4 fq + (0..3)
+#pragma unroll
+        for (int pf = 0; pf < 2; ++pf) {
+            const int px = (pg * 4 + pf * 2 + ((lane & 31) >> 4)) * TW + (lane & 15);          // pixel index in the tile
+            unsigned char* const wr = obuf + px * kOutPitch + (cg * 32 + 4 * fq) * 2;
+#pragma unroll
+            for (int qd = 0; qd < 4; ++qd) {
+                const f32x2_pk x0 = silu_pk(f32x2_pk{acc[pf][4 * qd], acc[pf][4 * qd + 1]});
+                const f32x2_pk x1 = silu_pk(f32x2_pk{acc[pf][4 * qd + 2], acc[pf][4 * qd + 3]});
+                *reinterpret_cast<u32x2*>(wr + 8 * qd * 2) = u32x2{pack_bf16x2(x0.x, x0.y), pack_bf16x2(x1.x, x1.y)};
+            }
+        }
+        barrier();
+        // 256 px x 128 B: thread -> 16 B (8 channels) of pixel (tid >> 3) + 64 it
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int px = (tid >> 3) + 64 * it, c8 = tid & 7;
+            const int oy = oy0 + px / TW, ox = ox0 + (px % TW);
+            if (oy < a.Ho && ox < a.Wo) {
+                u32x4 v = *reinterpret_cast<const u32x4*>(obuf + px * kOutPitch + c8 * 16);
+                const long m = ((long)b * a.Ho + oy) * a.Wo + ox;
+                if (RES) {
+                    const u32x4 r = *reinterpret_cast<const u32x4*>(a.res + m * a.res_cs + n0 + c8 * 8);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const f32x2_pk x = f32x2_pk{__uint_as_float(v[j] << 16), __uint_as_float(v[j] & 0xFFFF0000u)} +
+                                           f32x2_pk{__uint_as_float(r[j] << 16), __uint_as_float(r[j] & 0xFFFF0000u)};
+                        v[j] = pack_bf16x2(x.x, x.y);
+                    }
+                }
+                __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(a.out + m * a.out_cs + n0 + c8 * 8));
+            }
+        }
+        // (the next iteration's first barrier orders these LDS reads before the next tile's output writes)
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the tail's out-of-range patch requests
+}
+
+template <int CIN, bool RES>
+static hipError_t launch(ConvArgs a, hipStream_t s) {
+    constexpr int RPD = 64 / (CIN / 8), PINS = (PROWS + RPD - 1) / RPD, PBYTES = PINS * RPD * CIN * 2;
+    constexpr int smem = 2 * PBYTES + kOutBytes + BN * 4;
+    static_assert(smem <= 160 * 1024, "LDS budget");
+    auto kern = k_conv_ws<CIN, RES>;
+    static bool configured = false;
+    if (!configured) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        if (e != hipSuccess) return e;
+        configured = true;
+    }
+    const int tiles_x = (a.Wo + TW - 1) / TW, tiles_y = (a.Ho + TH - 1) / TH;
+    const int nchunks = a.Cout / BN;
+    const long ntiles = (long)a.B * tiles_y * tiles_x;
+    // one workgroup per CU (two for the 32-channel form would fit; the layer is HBM-bound either way); every channel chunk
+    // gets the same number of workgroups
+    long per_chunk = 256 / nchunks;
+    if (per_chunk < 1) per_chunk = 1;
+    if (per_chunk > ntiles) per_chunk = ntiles;
+    hipLaunchKernelGGL(kern, dim3((unsigned)(per_chunk * nchunks)), dim3(512), smem, s, a, tiles_x, tiles_y, nchunks);
+    return hipGetLastError();
+}
+
+}  // namespace ws
+
+// variant 90 (hipErrorInvalidValue -> the shape is not served, the caller falls back)
+hipError_t launch_conv_ws(ConvArgs a, hipStream_t s, int variant) {
+    (void)variant;
+    if (a.ks != 3 || a.stride != 1 || (a.Cin != 32 && a.Cin != 64) || a.Cout % 64 || a.act != ADAYOLO_ACT_SILU)
+        return hipErrorInvalidValue;
+    if (2ull * a.B * a.H * a.W * a.in_cs + 256 > 0xFFFFFF00ull) return hipErrorInvalidValue;
+    if (a.Cin == 32) return a.res ? ws::launch<32, true>(a, s) : ws::launch<32, false>(a, s);
+    return a.res ? ws::launch<64, true>(a, s) : ws::launch<64, false>(a, s);
+}
+
+}  // namespace adayolo

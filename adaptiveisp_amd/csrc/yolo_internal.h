@@ -50,6 +50,7 @@ hipError_t launch_conv_small(ConvArgs a, hipStream_t s, int variant); // 3x3, Ci
 hipError_t launch_conv_pp(ConvArgs a, hipStream_t s, int variant);    // 256x256 ping-pong wave groups (yolo_conv_pp.hip)
 hipError_t launch_conv_pp128(ConvArgs a, hipStream_t s, int variant); // 256x128 ping-pong, 3-deep ring (yolo_conv_pp128.hip)
 hipError_t launch_conv_pq(ConvArgs a, hipStream_t s, int variant);    // 256x128, 4 waves, two workgroups per CU (yolo_conv_pq.hip)
+hipError_t launch_conv_ws(ConvArgs a, hipStream_t s, int variant);    // 3x3 s1, Cin 32 / 64: weights in registers, patch in LDS, persistent (yolo_conv_ws.hip)
 hipError_t launch_stem(const float* img, const float* w, const float* bias, void* out, int out_cs, int B, int H,
                        int W, int Hp, int pad_top, float pad_value, int act, hipStream_t s);
 hipError_t launch_letterbox_pack(const float* img, void* out, int out_cs, int B, int H, int W, int Hp, int pad_top,

@@ -224,7 +224,7 @@ class YoloEngine:
         self.views = view
 
     # ------------------------------------------------------------------------------------------
-    TUNE_CANDIDATES = (2, 5, 22, 26, 27, 40, 50, 60, 80)
+    TUNE_CANDIDATES = (2, 5, 22, 26, 27, 40, 50, 60, 80, 90)
 
     def _plans(self):
         return [self.plan]
@@ -266,8 +266,11 @@ class YoloEngine:
                             continue                             # ping-pong kernel: Cin % 64 == 0, Cout % 256 == 0
                         if 60 <= v < 80 and (args[11] % 64 or args[12] % 128):
                             continue                             # 256x128 ping-pong kernel: Cin % 64 == 0, Cout % 128 == 0
-                        if v >= 80 and (args[11] % 32 or args[12] % 128):
+                        if 80 <= v < 90 and (args[11] % 32 or args[12] % 128):
                             continue                             # 256x128, two workgroups per CU: Cin % 32 == 0, Cout % 128 == 0
+                        if v >= 90 and not (args[13] == 3 and args[14] == 1 and args[11] in (32, 64) and args[12] % 64 == 0 and
+                                            args[15] == _lib.ACT_SILU):
+                            continue                             # weights-in-registers kernel: 3x3 s1, Cin 32 / 64
                         args[16] = v
                         fn(*args, st)
                         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

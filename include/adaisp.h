@@ -68,7 +68,8 @@ enum adaisp_op {
  * One RL step of the ISP: image b is filtered by op filter_id[b] with params[b].
  * Replaces the reference's "run all filters, stack, one-hot select" of Agent.forward
  * (agent.py:103-116,154) — only the selected filter is computed.
- * `filter_id` lives on the device (no host sync is needed to pick the work); -1 writes zeros.
+ * `filter_id` lives on the device (no host sync is needed to pick the work); -1 — and any id outside enum adaisp_op —
+ * writes zeros (the reference's all-zero one-hot row).
  * If `pooled64_next` != NULL it receives AdaptiveAvgPool2d((64,64)) of `out`
  * ([B,3,64,64]; agent.py:97 / value.py:63) for the next step's policy input.
  * `out` must not alias `img`.

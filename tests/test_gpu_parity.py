@@ -163,6 +163,12 @@ def test_mixed_ids_one_call(oracle_mod):
         one = _lib.process(int(op), torch.from_numpy(img[b:b + 1]).to(dev()), torch.from_numpy(params[b:b + 1]).to(dev()),
                            clip=True)
         assert torch.equal(one[0], out[b]), f"op {op}"
+    # an id outside enum adaisp_op (the ids are device data: no host-side rejection is possible): zero image, not garbage
+    bad = torch.tensor([99, 0, -7], dtype=torch.int32, device=dev())
+    x3 = torch.from_numpy(img[:3]).to(dev())
+    o3 = torch.full_like(x3, float("nan"))
+    _lib.forward(x3, bad, torch.from_numpy(params[:3]).to(dev()), clip=True, out=o3)
+    assert not o3[0].any() and not o3[2].any() and torch.isfinite(o3[1]).all()
 
 
 def test_error_paths():
