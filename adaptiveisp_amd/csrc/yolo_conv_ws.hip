@@ -43,10 +43,19 @@ __device__ __forceinline__ void barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
 }
-// swizzle key of a patch row whose rows are CIN*2 bytes (64 B -> 4 rows per 256-B bank row, 128 B -> 2)
+// swizzle key of a patch pixel: a function of its x coordinate in the 18-wide patch, (x >> 1) & (chunks per row - 1).
+// A ds_read_b128 lane group holds pixels x in {0-3, 12-15} of one tile row and {4-11} of the next (+ the tap's kw): keyed
+// by the linear patch row, rows 16 apart share a bank slot (2-way conflicts on every fragment read: the LDS time doubles
+// and equals the MFMA time); keyed by x every group is conflict-free for all nine taps (checked exhaustively).
 template <int CIN>
-__device__ __forceinline__ int row_key(int r) { return CIN == 32 ? ((r >> 2) & 3) : ((r >> 1) & 7); }
+__device__ __forceinline__ int px_key(int x) { return (x >> 1) & (CIN / 8 - 1); }
 
+#ifdef ADAYOLO_MEASURE
+__device__ unsigned long long g_ws_dbg[16];          // workgroup 0: cycles per phase summed over its tiles, tile count
+#define WS_T(i) do { const unsigned long long n_ = __builtin_readcyclecounter(); ph[i] += n_ - tprev; tprev = n_; } while (0)
+#else
+#define WS_T(i) do { } while (0)
+#endif
 template <int CIN, bool RES>
 __global__ __launch_bounds__(512) void k_conv_ws(const ConvArgs a, const int tiles_x, const int tiles_y, const int nchunks) {
     constexpr int RB = CIN * 2;                      // bytes per patch row (one pixel)
@@ -93,13 +102,17 @@ __global__ __launch_bounds__(512) void k_conv_ws(const ConvArgs a, const int til
 
     // ---- patch DMA: piece i of this wave covers patch rows [(wave + 8 i) RPD, + RPD); lane -> row, 16-byte slot
     const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, 0, kRecords, kDescFlags);
+    const __amdgpu_buffer_rsrc_t rsO = __builtin_amdgcn_make_buffer_rsrc((void*)a.out, 0, kRecords, kDescFlags);
+    const unsigned long long resp = (unsigned long long)(RES ? (const void*)a.res : (const void*)a.out);
+    const u32x4 dR = {(unsigned)resp, (unsigned)(resp >> 32) & 0xFFFFu, kRecords, kDescFlags};
+    constexpr int NPMIN = PINS / 8;                  // DMA pieces EVERY wave issues per patch
     const int dslot = lane % CH, drow = lane / CH;
     unsigned pinfo[NP];                              // this lane's row in piece i: patch y << 16 | patch x << 8 | source chunk
 #pragma unroll                                       // (after the swizzle); y >= PH: past the end of the patch
     for (int i = 0; i < NP; ++i) {
         const int rr = (wave + 8 * i) * RPD + drow;
         const int py = rr / PW;
-        pinfo[i] = ((unsigned)py << 16) | ((unsigned)(rr - py * PW) << 8) | (unsigned)(dslot ^ row_key<CIN>(rr));
+        pinfo[i] = ((unsigned)py << 16) | ((unsigned)(rr - py * PW) << 8) | (unsigned)(dslot ^ px_key<CIN>(rr - py * PW));
     }
     auto tile_coords = [&](int t, int& b, int& oy0, int& ox0) {
         const int tx = t % tiles_x, r = t / tiles_x;
@@ -131,14 +144,23 @@ __global__ __launch_bounds__(512) void k_conv_ws(const ConvArgs a, const int til
     int t = slot0;
     stage_patch(t, pbuf0);
     stage_patch(t + nwg_per_chunk, pbuf0 + PBYTES);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPMIN) : "memory");       // the first patch (the second one stays in flight)
     int cur = 0;
+#ifdef ADAYOLO_MEASURE
+    unsigned long long ph[6] = {0, 0, 0, 0, 0, 0}, tprev = __builtin_readcyclecounter(), ntl = 0;
+#endif
     for (; t < ntiles; t += nwg_per_chunk, cur ^= 1) {
         unsigned char* const pb = pbuf0 + cur * PBYTES;
         int b, oy0, ox0;
         tile_coords(t, b, oy0, ox0);
-        // patch(t) was requested a whole tile ago (the first one: just now); everything this wave has in flight is older
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // Every VMEM operation of a tile is issued unconditionally (masked pixels are out-of-range buffer offsets), in the
+        // order [4 residual loads][patch(t + 2): >= NPMIN pieces][4 stores], so the counted wait is exact: patch(t) — requested
+        // a whole tile ago — is complete when at most this tile's predecessor's patch pieces and stores are outstanding. A
+        // plain vmcnt(0) here waits for the previous tile's STORES to be acknowledged by HBM.
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPMIN + 4) : "memory");
+        WS_T(0);
         barrier();
+        WS_T(1);
         f32x16 acc[2];                                // start at the bias: channels 8 qd + 4 fq + (0..3) of the wave's 32
 #pragma unroll
         for (int qd = 0; qd < 4; ++qd) {
@@ -151,35 +173,60 @@ __global__ __launch_bounds__(512) void k_conv_ws(const ConvArgs a, const int til
         // (the fragment addresses of all nine taps are loop-invariant: left visible, hipcc hoists 72 of them out of the tile
         // loop, spills them and reloads each one — scratch_load + vmcnt(0) — in front of its MFMA. Opaque per tile: ~10 VALU
         // per tap in the loop instead.)
-        int p0[2] = {prow0[0], prow0[1]};
-        asm volatile("" : "+v"(p0[0]), "+v"(p0[1]));
-#pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-            const int toff = (tap / 3) * PW + (tap % 3);
-            int aoff[2], akey[2];
+        int p0[2] = {prow0[0], prow0[1]}, x0 = lane & 15;
+        asm volatile("" : "+v"(p0[0]), "+v"(p0[1]), "+v"(x0));
+        // steps of 4 MFMAs (one pair of k-chunks x the two pixel fragments); the four fragments of step s + 1 are requested
+        // before the MFMAs of step s, and a fence per step keeps hipcc from hoisting more (all 72 reads next to the 144 weight
+        // registers spill)
+        constexpr int SPT = KK / 2, NSTEP = 9 * SPT;          // steps per tap, steps per tile
+        bf16x8 fr[2][2][2];                                   // [step parity][k-chunk of the pair][pixel fragment]
+        auto load_step = [&](auto stag) __attribute__((always_inline)) {
+            constexpr int st = decltype(stag)::value, tap = st / SPT, kp = st % SPT;
+            constexpr int toff = (tap / 3) * PW + (tap % 3);
 #pragma unroll
             for (int pf = 0; pf < 2; ++pf) {
                 const int rr = p0[pf] + toff;
-                aoff[pf] = rr * RB;
-                akey[pf] = row_key<CIN>(rr);
+                const unsigned char* base = pb + rr * RB;
+                const int key = px_key<CIN>(x0 + tap % 3);
+#pragma unroll
+                for (int k2 = 0; k2 < 2; ++k2)
+                    fr[st & 1][k2][pf] = *reinterpret_cast<const bf16x8*>(base + ((((kp * 2 + k2) * 2 + fq) ^ key) << 4));
             }
-            // one tap = 2 KK fragment reads, then their MFMAs; the fence keeps hipcc from hoisting the reads of all nine taps
-            // (it does: ~130 registers of fragments next to the 144 of weights -> spills); the SIMD's other wave covers the
-            // LDS latency at a tap's start
-            bf16x8 af[KK][2];
+        };
+        auto run_steps = [&](auto self, auto stag) __attribute__((always_inline)) -> void {
+            constexpr int st = decltype(stag)::value;
+            if constexpr (st < NSTEP) {
+                if constexpr (st + 1 < NSTEP) load_step(std::integral_constant<int, st + 1>{});
+                constexpr int tap = st / SPT, kp = st % SPT;
 #pragma unroll
-            for (int kk = 0; kk < KK; ++kk)
+                for (int k2 = 0; k2 < 2; ++k2)
 #pragma unroll
-                for (int pf = 0; pf < 2; ++pf)
-                    af[kk][pf] = *reinterpret_cast<const bf16x8*>(pb + aoff[pf] + (((kk * 2 + fq) ^ akey[pf]) << 4));
-#pragma unroll
-            for (int kk = 0; kk < KK; ++kk)
-#pragma unroll
-                for (int pf = 0; pf < 2; ++pf)
-                    acc[pf] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wreg[tap][kk], af[kk][pf], acc[pf], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-        }
+                    for (int pf = 0; pf < 2; ++pf)
+                        acc[pf] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wreg[tap][kp * 2 + k2], fr[st & 1][k2][pf], acc[pf], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                self(self, std::integral_constant<int, st + 1>{});
+            }
+        };
+        load_step(std::integral_constant<int, 0>{});
+        run_steps(run_steps, std::integral_constant<int, 0>{});
+        WS_T(2);
         barrier();                                   // every wave has read patch(t): its buffer takes patch(t + 2)
+        WS_T(3);
+        // this thread's four output rows: 16 B (8 channels) of pixel (tid >> 3) + 64 it
+        unsigned ovoff[4];
+        u32x4 rv[4];
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int px = (tid >> 3) + 64 * it;
+            const int oy = oy0 + px / TW, ox = ox0 + (px % TW);
+            const bool ok = (oy < a.Ho) & (ox < a.Wo);
+            const unsigned m = (unsigned)((b * a.Ho + oy) * a.Wo + ox);
+            ovoff[it] = ok ? 2u * (m * (unsigned)a.out_cs + (unsigned)(n0 + (tid & 7) * 8)) : kOOB;
+            if (RES) {
+                const unsigned rvoff = ok ? 2u * (m * (unsigned)a.res_cs + (unsigned)(n0 + (tid & 7) * 8)) : kOOB;
+                asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(rv[it]) : "v"(rvoff), "s"(dR) : "memory");
+            }
+        }
         stage_patch(t + 2 * nwg_per_chunk, pb);
         // ---- epilogue: D[row = channel][col = pixel]; lane holds pixel (lane & 31) and channels 8 qd + 4 fq + (0..3)
 #pragma unroll
@@ -194,29 +241,36 @@ __global__ __launch_bounds__(512) void k_conv_ws(const ConvArgs a, const int til
             }
         }
         barrier();
-        // 256 px x 128 B: thread -> 16 B (8 channels) of pixel (tid >> 3) + 64 it
+        WS_T(4);
+        if (RES)       // the residual rows are older than the patch pieces issued behind them
+            asm volatile("s_waitcnt vmcnt(%4)" : "+v"(rv[0]), "+v"(rv[1]), "+v"(rv[2]), "+v"(rv[3]) : "n"(NPMIN) : "memory");
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
-            const int px = (tid >> 3) + 64 * it, c8 = tid & 7;
-            const int oy = oy0 + px / TW, ox = ox0 + (px % TW);
-            if (oy < a.Ho && ox < a.Wo) {
-                u32x4 v = *reinterpret_cast<const u32x4*>(obuf + px * kOutPitch + c8 * 16);
-                const long m = ((long)b * a.Ho + oy) * a.Wo + ox;
-                if (RES) {
-                    const u32x4 r = *reinterpret_cast<const u32x4*>(a.res + m * a.res_cs + n0 + c8 * 8);
+            const int px = (tid >> 3) + 64 * it;
+            u32x4 v = *reinterpret_cast<const u32x4*>(obuf + px * kOutPitch + (tid & 7) * 16);
+            if (RES) {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const f32x2_pk x = f32x2_pk{__uint_as_float(v[j] << 16), __uint_as_float(v[j] & 0xFFFF0000u)} +
-                                           f32x2_pk{__uint_as_float(r[j] << 16), __uint_as_float(r[j] & 0xFFFF0000u)};
-                        v[j] = pack_bf16x2(x.x, x.y);
-                    }
+                for (int j = 0; j < 4; ++j) {
+                    const f32x2_pk x = f32x2_pk{__uint_as_float(v[j] << 16), __uint_as_float(v[j] & 0xFFFF0000u)} +
+                                       f32x2_pk{__uint_as_float(rv[it][j] << 16), __uint_as_float(rv[it][j] & 0xFFFF0000u)};
+                    v[j] = pack_bf16x2(x.x, x.y);
                 }
-                __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(a.out + m * a.out_cs + n0 + c8 * 8));
             }
+            __builtin_amdgcn_raw_buffer_store_b128(v, rsO, ovoff[it], 0, 2);       // nt; a masked pixel is out of range: dropped
         }
+        WS_T(5);
+#ifdef ADAYOLO_MEASURE
+        ++ntl;
+#endif
         // (the next iteration's first barrier orders these LDS reads before the next tile's output writes)
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the tail's out-of-range patch requests
+#ifdef ADAYOLO_MEASURE
+    if (blockIdx.x == 0 && tid == 0) {
+        for (int i = 0; i < 6; ++i) g_ws_dbg[i] = ph[i];
+        g_ws_dbg[6] = ntl;
+    }
+#endif
 }
 
 template <int CIN, bool RES>
@@ -243,6 +297,11 @@ static hipError_t launch(ConvArgs a, hipStream_t s) {
     return hipGetLastError();
 }
 
+#ifdef ADAYOLO_MEASURE
+extern "C" int adayolo_debug_ws(unsigned long long* dst) {
+    return hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_ws_dbg), sizeof(unsigned long long) * 16) == hipSuccess ? 0 : -1;
+}
+#endif
 }  // namespace ws
 
 // variant 90 (hipErrorInvalidValue -> the shape is not served, the caller falls back)
@@ -250,7 +309,9 @@ hipError_t launch_conv_ws(ConvArgs a, hipStream_t s, int variant) {
     (void)variant;
     if (a.ks != 3 || a.stride != 1 || (a.Cin != 32 && a.Cin != 64) || a.Cout % 64 || a.act != ADAYOLO_ACT_SILU)
         return hipErrorInvalidValue;
-    if (2ull * a.B * a.H * a.W * a.in_cs + 256 > 0xFFFFFF00ull) return hipErrorInvalidValue;
+    if (2ull * a.B * a.H * a.W * a.in_cs + 256 > 0xFFFFFF00ull || 2ull * a.M * a.out_cs + 256 > 0xFFFFFF00ull ||
+        (a.res && 2ull * a.M * a.res_cs + 256 > 0xFFFFFF00ull))
+        return hipErrorInvalidValue;
     if (a.Cin == 32) return a.res ? ws::launch<32, true>(a, s) : ws::launch<32, false>(a, s);
     return a.res ? ws::launch<64, true>(a, s) : ws::launch<64, false>(a, s);
 }

@@ -42,6 +42,8 @@ def main():
     variants = [int(v) for v in (sys.argv[1] if len(sys.argv) > 1 else "2,5,27,50,60").split(",")]
     B = 8
     L = _lib.load()
+    if len(sys.argv) > 2 and sys.argv[2] == "small":        # the shallow 3x3 layers (Cin 32 / 64)
+        SHAPES[:] = [sh for sh in SHAPES if sh[4] == 3 and sh[2] <= 64]
     if len(sys.argv) > 2 and sys.argv[2] == "big":          # the MFMA-bound 3x3 layers only
         SHAPES[:] = [sh for sh in SHAPES if sh[4] == 3 and sh[2] >= 128]
     tot = {v: 0.0 for v in variants}
@@ -64,6 +66,17 @@ def main():
         totfl += fl * cnt
         dmax = max([(outs[variants[0]].float() - outs[v].float()).abs().max().item() for v in variants[1:]] + [0.0])
         print(f"{H}x{W} {cin:4d}->{cout:4d} k{k} s{s} x{cnt:<2d}          " + "  ".join(row) + f"  maxdiff {dmax:.3g}")
+        if 90 in variants and k == 3 and s == 1 and cin in (32, 64):
+            try:
+                d = (ctypes.c_ulonglong * 16)()
+                torch.cuda.synchronize()
+                if L.adayolo_debug_ws(d) == 0 and d[6]:
+                    names = ["wait patch", "barrier A", "MFMA steps", "barrier B", "issue + SiLU + obuf + barrier C", "rows + stores"]
+                    print("      ws wg0, cycles per tile: " + ", ".join(f"{n} {d[i] / d[6]:.0f}" for i, n in enumerate(names)) + f"  ({d[6]} tiles)")
+            except AttributeError:
+                pass
+    if hasattr(L, "adayolo_debug_ws") and 90 in variants:
+        pass
     print("network conv total (ms), TF/s: " + "  ".join(f"v{v}: {tot[v]:.3f} ms {totfl / tot[v] / 1e9:.1f}" for v in variants))
 
 

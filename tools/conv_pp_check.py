@@ -18,7 +18,8 @@ for (B, H, W, cin, cout, k, s, use_res) in [(8, 92, 160, 128, 256, 3, 1, True), 
                                             (3, 9, 11, 64, 256, 1, 1, False), (1, 7, 9, 64, 256, 3, 2, False),
                                             (8, 184, 320, 128, 256, 3, 2, False), (8, 92, 160, 256, 128, 1, 1, False),
                                             (4, 184, 320, 64, 128, 3, 1, True), (2, 37, 53, 64, 128, 3, 2, False),
-                                            (1, 9, 7, 192, 384, 3, 1, True)]:
+                                            (1, 9, 7, 192, 384, 3, 1, True), (8, 368, 640, 32, 64, 3, 1, True), (2, 33, 47, 64, 128, 3, 1, True),
+                                            (1, 16, 16, 32, 64, 3, 1, False), (3, 17, 5, 64, 64, 3, 1, False)]:
     g = torch.Generator(device="cpu").manual_seed(H * 131 + cin)
     x = torch.randn(B, H, W, cin, generator=g).to(torch.bfloat16).cuda()
     w = (torch.randn(cout, k, k, cin, generator=g) / (k * k * cin) ** 0.5).to(torch.bfloat16).cuda()
