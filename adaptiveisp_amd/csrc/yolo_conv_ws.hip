@@ -12,7 +12,7 @@
 //     tile's MFMAs;
 //   * 8 waves = 4 pixel groups (4 tile rows = 64 px) x 2 channel groups (32 ch): per tile 72 MFMAs and 72 ds_read_b128
 //     per wave (Cin = 64), two waves per SIMD; the epilogue goes through one LDS tile (bias + SiLU + bf16 in the
-//     accumulator layout, then 128-byte pixel rows + residual), three barriers per tile.
+//     accumulator layout, then 128-byte pixel rows + residual), two barriers per tile.
 // Restrictions (the launcher falls back otherwise): ksize 3, stride 1, Cin in {32, 64}, Cout % 64 == 0, 32-bit offsets.
 #include "yolo_internal.h"
 #include <type_traits>
@@ -73,6 +73,7 @@ __global__ __launch_bounds__(512) void k_conv_ws(const ConvArgs a, const int til
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int pg = wave & 3, cg = wave >> 2;         // pixel group (tile rows 4 pg .. 4 pg + 3), channel group (32 ch)
+    if (cg == 0) __builtin_amdgcn_s_setprio(2);      // waves w and w + 4 share a SIMD: see the epilogue
     // the workgroup's channel chunk is fixed (weights stay in registers); it strides through the pixel tiles
     const int nwg_per_chunk = gridDim.x / nchunks;
     // the workgroups that take the same pixel tiles for different channel chunks sit on ONE XCD (block b runs on XCD b % 8):
@@ -210,9 +211,8 @@ __global__ __launch_bounds__(512) void k_conv_ws(const ConvArgs a, const int til
         load_step(std::integral_constant<int, 0>{});
         run_steps(run_steps, std::integral_constant<int, 0>{});
         WS_T(2);
-        barrier();                                   // every wave has read patch(t): its buffer takes patch(t + 2)
-        WS_T(3);
-        // this thread's four output rows: 16 B (8 channels) of pixel (tid >> 3) + 64 it
+        // this thread's four output rows: 16 B (8 channels) of pixel (tid >> 3) + 64 it; the residual rows are requested now
+        // (the fragment registers are dead) and land under the SiLU math
         unsigned ovoff[4];
         u32x4 rv[4];
 #pragma unroll
@@ -227,8 +227,10 @@ __global__ __launch_bounds__(512) void k_conv_ws(const ConvArgs a, const int til
                 asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(rv[it]) : "v"(rvoff), "s"(dR) : "memory");
             }
         }
-        stage_patch(t + 2 * nwg_per_chunk, pb);
-        // ---- epilogue: D[row = channel][col = pixel]; lane holds pixel (lane & 31) and channels 8 qd + 4 fq + (0..3)
+        // ---- epilogue math BEFORE the barrier: the two waves of a SIMD are the two channel groups of the same pixels and the
+        //      first group has priority (s_setprio above), so it finishes its MFMA steps first and computes its SiLUs beside
+        //      the second group's MFMAs instead of behind the barrier.
+        //      D[row = channel][col = pixel]; lane holds pixel (lane & 31) and channels 8 qd + 4 fq + (0..3)
 #pragma unroll
         for (int pf = 0; pf < 2; ++pf) {
             const int px = (pg * 4 + pf * 2 + ((lane & 31) >> 4)) * TW + (lane & 15);          // pixel index in the tile
@@ -240,7 +242,9 @@ __global__ __launch_bounds__(512) void k_conv_ws(const ConvArgs a, const int til
                 *reinterpret_cast<u32x2*>(wr + 8 * qd * 2) = u32x2{pack_bf16x2(x0.x, x0.y), pack_bf16x2(x1.x, x1.y)};
             }
         }
-        barrier();
+        WS_T(3);
+        barrier();                                   // every wave has read patch(t) (its buffer takes patch(t + 2)) and written its
+        stage_patch(t + 2 * nwg_per_chunk, pb);      // part of the output tile
         WS_T(4);
         if (RES)       // the residual rows are older than the patch pieces issued behind them
             asm volatile("s_waitcnt vmcnt(%4)" : "+v"(rv[0]), "+v"(rv[1]), "+v"(rv[2]), "+v"(rv[3]) : "n"(NPMIN) : "memory");

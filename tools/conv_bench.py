@@ -71,7 +71,7 @@ def main():
                 d = (ctypes.c_ulonglong * 16)()
                 torch.cuda.synchronize()
                 if L.adayolo_debug_ws(d) == 0 and d[6]:
-                    names = ["wait patch", "barrier A", "MFMA steps", "barrier B", "issue + SiLU + obuf + barrier C", "rows + stores"]
+                    names = ["wait patch", "barrier A", "MFMA steps", "residual issue + SiLU + output tile", "barrier B + patch issue", "rows + stores"]
                     print("      ws wg0, cycles per tile: " + ", ".join(f"{n} {d[i] / d[6]:.0f}" for i, n in enumerate(names)) + f"  ({d[6]} tiles)")
             except AttributeError:
                 pass
