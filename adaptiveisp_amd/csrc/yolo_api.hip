@@ -64,7 +64,7 @@ int adayolo_conv_fwd_variant(const void* in, int in_cstride, const void* weight,
         case 40: known = true; e = launch_conv_small(a, s, variant); break;       // 3x3, Cin 32 / 64 only
         case 50: known = true; e = launch_conv_pp(a, s, variant); break;          // Cin % 64 == 0, Cout % 256 == 0 only
         case 60: known = true; e = launch_conv_pp128(a, s, variant); break;       // Cin % 64 == 0, Cout % 128 == 0 only
-        case 80: known = true; e = launch_conv_pq(a, s, variant); break;          // Cin % 32 == 0, Cout % 128 == 0
+        case 80: case 85: known = true; e = launch_conv_pq(a, s, variant); break; // Cin % 32 == 0, Cout % 128 == 0 (85: 128-pixel tile)
         case 90: known = true; e = launch_conv_ws(a, s, variant); break;          // 3x3 s1, Cin 32 / 64, Cout % 64 == 0, SiLU
         default: break;
     }

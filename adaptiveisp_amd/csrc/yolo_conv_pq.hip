@@ -40,14 +40,21 @@ typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 template <int N> using IC = std::integral_constant<int, N>;
 
-constexpr int BM = 256, BN = 128, BK = 32;
+constexpr int BN = 128, BK = 32;
 constexpr int kRow = BK * 2;                  // 64 bytes per tile row
-constexpr int kATile = BM * kRow;             // 16 KB
-constexpr int kBuf = (BM + BN) * kRow;        // one k-tile: 24 KB
-constexpr int kRing = 3 * kBuf;               // 72 KB
 constexpr int kEpiPitch = 144;                // bytes per pixel row of a wave's private epilogue region (64 ch + pad)
-constexpr int kSmem = kRing;                  // the epilogue (4 x 128 x 144 B = 72 KB) overlays the finished ring
-static_assert(4 * 128 * kEpiPitch <= kRing, "epilogue overlay");
+// MI = 32-pixel fragments per wave: 4 -> 256 px tile (24 KB per k-tile, 72 KB ring), 2 -> 128 px tile (16 KB, 48 KB): the
+// small maps (8x23x40: 29 tiles of 256 px) get twice the workgroups
+template <int MI> struct Geo {
+    static constexpr int BM = 64 * MI;
+    static constexpr int kATile = BM * kRow;
+    static constexpr int kBuf = (BM + BN) * kRow;
+    static constexpr int kRing = 3 * kBuf;
+    static constexpr int kEpi = 4 * 32 * MI * kEpiPitch;       // the epilogue overlays the finished ring
+    static constexpr int kSmem = kRing > kEpi ? kRing : kEpi;
+    static constexpr int NA = MI;                              // activation DMA pieces per wave and k-tile (16 rows each)
+    static constexpr int NP = MI + 2;                          // ... + 2 weight pieces
+};
 constexpr unsigned kOOB = 0xFFFFFFFFu;
 constexpr unsigned kRecords = 0xFFFFFF00u;
 constexpr unsigned kDescFlags = 0x00020000u;
@@ -63,8 +70,10 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 #define PQ_SGB(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
 
 // ABL (measurement builds): 0 the kernel, 1 no LDS-DMA in the k-loop, 2 no epilogue
-template <int ABL>
+template <int ABL, int MI>
 __global__ __launch_bounds__(256, 2) void k_conv_pq(const ConvArgs a) {
+    constexpr int BM = Geo<MI>::BM, kATile = Geo<MI>::kATile, kBuf = Geo<MI>::kBuf, NA = Geo<MI>::NA, NP = Geo<MI>::NP;
+    constexpr int H1 = NP / 2;                           // pieces issued behind the barrier (step 1); the rest in step 0
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -83,6 +92,8 @@ __global__ __launch_bounds__(256, 2) void k_conv_pq(const ConvArgs a) {
     //      (lane & 3) whose source chunk is pos ^ ((row >> 2) & 3). Per k-tile a wave issues 4 activation pieces (rows
     //      [64 wave, 64 wave + 64)) and 2 weight pieces (rows [32 wave, 32 wave + 32)).
     const int slot = lane & 3, rsub = lane >> 2;
+    // (arrays the lambdas capture keep a FIXED size — the 256-pixel form's — and the loops run to MI / NA: sized by the template
+    // parameter they make hipcc drop the kernel's host-side launch stub without a diagnostic; the unused elements are dead)
     unsigned wvoff[2], vsel[4], msel[4];
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
@@ -90,8 +101,8 @@ __global__ __launch_bounds__(256, 2) void k_conv_pq(const ConvArgs a) {
         wvoff[u] = 2u * (unsigned)(n0 + r) * (unsigned)Kw + 16u * (unsigned)(slot ^ ((r >> 2) & 3));
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int r = wave * 64 + i * 16 + rsub;
+    for (int i = 0; i < NA; ++i) {
+        const int r = wave * (16 * NA) + i * 16 + rsub;
         const int q = slot ^ ((r >> 2) & 3);
         const int m = m0 + r;
         const int mc = m < a.M ? m : a.M - 1;
@@ -127,14 +138,14 @@ __global__ __launch_bounds__(256, 2) void k_conv_pq(const ConvArgs a) {
     auto issue = [&](auto ptag, int dst) __attribute__((always_inline)) {
         constexpr int p = decltype(ptag)::value;
         if (ABL == 1) return;
-        if (ABL == 3 && p < 4) return;                 // measurement: weights only (what a patch-resident activation operand would leave)
-        if constexpr (p < 4)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr_t)(smem + dst + (wave * 64 + p * 16) * kRow), 16,
+        if (ABL == 3 && p < NA) return;                // measurement: weights only (what a patch-resident activation operand would leave)
+        if constexpr (p < NA)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr_t)(smem + dst + (wave * (16 * NA) + p * 16) * kRow), 16,
                                                      vsel[p] | (unsigned)__builtin_amdgcn_sbfe((int)msel[p], (unsigned)c_tap, 1u) | c_dead,
                                                      c_soffA, 0, 0);
         else
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (lds_ptr_t)(smem + dst + kATile + (wave * 32 + (p - 4) * 16) * kRow), 16,
-                                                     wvoff[p - 4] | c_dead, c_soffW, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (lds_ptr_t)(smem + dst + kATile + (wave * 32 + (p - NA) * 16) * kRow), 16,
+                                                     wvoff[p - NA] | c_dead, c_soffW, 0, 0);
     };
     // fragments (32x32x16): lane -> tile row (lane & 31), 16-byte k-chunk 2 kk + (lane >> 5), XOR key (row >> 2) & 3
     const int frow = lane & 31, fq = lane >> 5, key = (frow >> 2) & 3;
@@ -142,7 +153,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_pq(const ConvArgs a) {
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
         const int ko = ((2 * kk + fq) ^ key) << 4;
-        aoffk[kk] = (wm * 128 + frow) * kRow + ko;
+        aoffk[kk] = (wm * (32 * MI) + frow) * kRow + ko;
         woffk[kk] = kATile + (wn * 64 + frow) * kRow + ko;
     }
     auto read_frags = [&](int buf, auto kktag, bf16x8 (&ra)[4], bf16x8 (&rw)[2]) __attribute__((always_inline)) {
@@ -150,14 +161,20 @@ __global__ __launch_bounds__(256, 2) void k_conv_pq(const ConvArgs a) {
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni) rw[ni] = *reinterpret_cast<const bf16x8*>(smem + buf + woffk[kk] + ni * 32 * kRow);
 #pragma unroll
-        for (int mi = 0; mi < 4; ++mi) ra[mi] = *reinterpret_cast<const bf16x8*>(smem + buf + aoffk[kk] + mi * 32 * kRow);
+        for (int mi = 0; mi < MI; ++mi) ra[mi] = *reinterpret_cast<const bf16x8*>(smem + buf + aoffk[kk] + mi * 32 * kRow);
     };
 
     // ---- prologue
     int b0 = 0, b1 = kBuf, b2 = 2 * kBuf;
-    auto all6 = [&](int dst) __attribute__((always_inline)) {
-        issue(IC<0>{}, dst); issue(IC<1>{}, dst); issue(IC<2>{}, dst); issue(IC<3>{}, dst); issue(IC<4>{}, dst); issue(IC<5>{}, dst);
+    auto issue_first = [&](int dst) __attribute__((always_inline)) {          // pieces [0, H1)
+        issue(IC<0>{}, dst); issue(IC<1>{}, dst);
+        if constexpr (H1 > 2) issue(IC<2>{}, dst);
     };
+    auto issue_rest = [&](int dst) __attribute__((always_inline)) {           // pieces [H1, NP)
+        issue(IC<H1>{}, dst); issue(IC<H1 + 1>{}, dst);
+        if constexpr (NP - H1 > 2) issue(IC<H1 + 2>{}, dst);
+    };
+    auto all6 = [&](int dst) __attribute__((always_inline)) { issue_first(dst); issue_rest(dst); };
     // bias of channel 32 ni + (lane & 31) of the wave's 64 — ordinary loads, issued AHEAD of the DMA stream so that the
     // compiler's wait for them leaves the stream in flight
     float bias_f[2];
@@ -167,9 +184,9 @@ __global__ __launch_bounds__(256, 2) void k_conv_pq(const ConvArgs a) {
     // k-tiles 0 and 1 complete, the first three pieces of k-tile 2 (what step 1 of the k-tile before would have staged)
     all6(b0); cursor_advance();
     all6(b1); cursor_advance();
-    issue(IC<0>{}, b2); issue(IC<1>{}, b2); issue(IC<2>{}, b2);          // cursor stays at k-tile 2
+    issue_first(b2);                                                     // cursor stays at k-tile 2
 
-    f32x16 acc[2][4];                                    // [channel frag][pixel frag]
+    f32x16 acc[2][4];                                    // [channel frag][pixel frag < MI]
     {
         // bias = hi + mid + lo, three bf16 terms (exact), in k-slots 0..2 of the channel operand of the lanes that hold
         // k-chunk 0; the pixel operand has ones there: acc = bias without 128 register writes
@@ -187,12 +204,12 @@ __global__ __launch_bounds__(256, 2) void k_conv_pq(const ConvArgs a) {
             const float r2 = r1 - __uint_as_float(mid);
             const u32x4 wb = {((hi >> 16) | mid) & on, (__float_as_uint(r2) >> 16) & on, 0u, 0u};
 #pragma unroll
-            for (int mi = 0; mi < 4; ++mi)
+            for (int mi = 0; mi < MI; ++mi)
                 acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wb), __builtin_bit_cast(bf16x8, ones), zero, 0, 0, 0);
         }
     }
     fence();
-    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(ABL == 1 ? 0 : ABL == 3 ? 2 : 9) : "memory");   // k-tile 0 landed
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(ABL == 1 ? 0 : ABL == 3 ? 2 : NP + H1) : "memory");   // k-tile 0 landed
     fence();
     bf16x8 fa[4], fw[2];
     read_frags(b0, IC<0>{}, fa, fw);
@@ -201,7 +218,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_pq(const ConvArgs a) {
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
-            for (int mi = 0; mi < 4; ++mi)
+            for (int mi = 0; mi < MI; ++mi)
                 acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[ni], fa[mi], acc[ni][mi], 0, 0, 0);
     };
     // ---- k-loop. Step 0: MFMAs of chunk 0 beside the reads of chunk 1 and pieces 3..5 of k-tile t+2 (its buffer was
@@ -211,36 +228,36 @@ __global__ __launch_bounds__(256, 2) void k_conv_pq(const ConvArgs a) {
         bf16x8 na[4], nw[2];
         fence();
         read_frags(b0, IC<1>{}, na, nw);
-        issue(IC<3>{}, b2); issue(IC<4>{}, b2); issue(IC<5>{}, b2);
+        issue_rest(b2);
         mma();
 #pragma unroll
-        for (int n = 0; n < 8; ++n) {
+        for (int n = 0; n < 2 * MI; ++n) {
             PQ_SGB(0x008, 1);
-            if (n < 3) PQ_SGB(0x100, 2);
-            else if (n < 6) { PQ_SGB(0x004, 1); PQ_SGB(0x020, 1); }
+            if (n < (MI + 3) / 2) PQ_SGB(0x100, 2);
+            else if (n < (MI + 3) / 2 + 3) { PQ_SGB(0x004, 1); PQ_SGB(0x020, 1); }
             PQ_SGB(0x002, 2);
         }
         fence();
 #pragma unroll
-        for (int i = 0; i < 4; ++i) fa[i] = na[i];
+        for (int i = 0; i < MI; ++i) fa[i] = na[i];
         fw[0] = nw[0]; fw[1] = nw[1];
         cursor_advance();
         fence();
-        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(ABL == 1 ? 0 : ABL == 3 ? 2 : 6) : "memory");
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(ABL == 1 ? 0 : ABL == 3 ? 2 : NP) : "memory");
         fence();
         read_frags(b1, IC<0>{}, na, nw);
-        issue(IC<0>{}, b0); issue(IC<1>{}, b0); issue(IC<2>{}, b0);
+        issue_first(b0);
         mma();
 #pragma unroll
-        for (int n = 0; n < 8; ++n) {
+        for (int n = 0; n < 2 * MI; ++n) {
             PQ_SGB(0x008, 1);
-            if (n < 3) PQ_SGB(0x100, 2);
-            else if (n < 6) { PQ_SGB(0x004, 1); PQ_SGB(0x020, 1); }
+            if (n < (MI + 3) / 2) PQ_SGB(0x100, 2);
+            else if (n < (MI + 3) / 2 + 3) { PQ_SGB(0x004, 1); PQ_SGB(0x020, 1); }
             PQ_SGB(0x002, 2);
         }
         fence();
 #pragma unroll
-        for (int i = 0; i < 4; ++i) fa[i] = na[i];
+        for (int i = 0; i < MI; ++i) fa[i] = na[i];
         fw[0] = nw[0]; fw[1] = nw[1];
         const int t0 = b0; b0 = b1; b1 = b2; b2 = t0;
     }
@@ -252,24 +269,24 @@ __global__ __launch_bounds__(256, 2) void k_conv_pq(const ConvArgs a) {
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
-            for (int mi = 0; mi < 4; ++mi) asm volatile("" ::"v"(acc[ni][mi]));
+            for (int mi = 0; mi < MI; ++mi) asm volatile("" ::"v"(acc[ni][mi]));
         return;
     }
 
     // ---- epilogue (see yolo_conv_pp.hip): D[row = channel][col = pixel]; each wave transposes its 128 px x 64 ch through a
     //      private LDS region (pitch 144 B) and writes 128-byte row segments; activation / residual are compile-time copies
-    unsigned char* my = smem + wave * (128 * kEpiPitch);
+    unsigned char* my = smem + wave * (32 * MI * kEpiPitch);
     auto epilogue = [&](auto silu_tag, auto res_tag) __attribute__((always_inline)) {
         constexpr bool kSilu = decltype(silu_tag)::value, kRes = decltype(res_tag)::value;
         const int chunk = lane & 7, r0 = lane >> 3;
-        const int mrow = m0 + wm * 128 + r0, n = n0 + wn * 64 + chunk * 8;
+        const int mrow = m0 + wm * (32 * MI) + r0, n = n0 + wn * 64 + chunk * 8;
         unsigned short* const op = a.out + (long)mrow * a.out_cs + n;
         const unsigned short* const rp = kRes ? a.res + (long)mrow * a.res_cs + n : nullptr;
         const long ostep = 8L * a.out_cs, rstep = kRes ? 8L * a.res_cs : 0;
         unsigned char* const wr = my + (lane & 31) * kEpiPitch + 8 * (lane >> 5);
         const unsigned char* const rd = my + r0 * kEpiPitch + chunk * 16;
 #pragma unroll
-        for (int mi = 0; mi < 4; ++mi) {
+        for (int mi = 0; mi < MI; ++mi) {
             u32x4 v[4], r[4];
             bool ok[4];
 #pragma unroll
@@ -317,10 +334,12 @@ __global__ __launch_bounds__(256, 2) void k_conv_pq(const ConvArgs a) {
     }
 }
 
-template <int ABL>
+template <int ABL, int MI = 4>
 static hipError_t launch(ConvArgs a, hipStream_t s) {
+    constexpr int kSmem = Geo<MI>::kSmem;
     static_assert(2 * kSmem <= 160 * 1024, "two workgroups per CU");
-    auto kern = k_conv_pq<ABL>;
+    a.mtiles = (a.M + Geo<MI>::BM - 1) / Geo<MI>::BM;
+    auto kern = k_conv_pq<ABL, MI>;
     static bool configured = false;
     if (!configured) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -340,21 +359,21 @@ static hipError_t launch(ConvArgs a, hipStream_t s) {
 
 }  // namespace pq
 
-// variant 80 = the kernel; with -DADAYOLO_MEASURE 81 / 82 = measurement builds. hipErrorInvalidValue -> not served.
+// variant 80 = the kernel (256-pixel tile), 85 = its 128-pixel form; with -DADAYOLO_MEASURE 81 .. 83 = measurement builds.
+// hipErrorInvalidValue -> not served.
 hipError_t launch_conv_pq(ConvArgs a, hipStream_t s, int variant) {
     const long nK = (long)a.ks * a.ks * a.Cin / 32;
     if (a.Cin % 32 || a.Cout % 128 || nK < 3 || a.sh_hw < 0 || a.sh_w < 0) return hipErrorInvalidValue;
     const unsigned long long lim = 0xFFFFFF00ull - 64;
     const unsigned long long in_b = 2ull * a.B * a.H * a.W * a.in_cs + 4ull * (a.W + 1) * a.in_cs + 2ull * a.Cin;
     if (in_b > lim || 2ull * a.Cout * a.ks * a.ks * a.Cin > lim) return hipErrorInvalidValue;
-    a.mtiles = (a.M + pq::BM - 1) / pq::BM;
     a.ntiles = a.Cout / pq::BN;
 #ifdef ADAYOLO_MEASURE
     if (variant == 81) return pq::launch<1>(a, s);
     if (variant == 82) return pq::launch<2>(a, s);
     if (variant == 83) return pq::launch<3>(a, s);
 #endif
-    (void)variant;
+    if (variant == 85) return pq::launch<0, 2>(a, s);  // 128-pixel tile
     return pq::launch<0>(a, s);
 }
 

@@ -224,7 +224,7 @@ class YoloEngine:
         self.views = view
 
     # ------------------------------------------------------------------------------------------
-    TUNE_CANDIDATES = (2, 5, 22, 26, 27, 40, 50, 60, 80, 90)
+    TUNE_CANDIDATES = (2, 5, 22, 26, 27, 40, 50, 60, 80, 85, 90)
 
     def _plans(self):
         return [self.plan]

@@ -74,7 +74,7 @@ int adayolo_conv_fused1x1_fwd(const void* in, int in_cstride,
  * MFMA; 5 / 22 / 26 / 27 = lean-address LDS-DMA ring on 32x32x16 MFMA with tiles 128x128 (by shape) / 128x64 /
  * 128x256 / 256x128 px x ch; 40 = whole-K-resident 3x3 for Cin 32 / 64; 50 = 256x256 ping-pong wave groups
  * (Cin % 64 == 0, Cout % 256 == 0); 60 = 256x128 ping-pong (Cin % 64 == 0, Cout % 128 == 0); 80 = 256x128 with four
- * waves and two workgroups per CU (Cin % 32 == 0, Cout % 128 == 0, K >= 96); 90 = 3x3 stride 1 with Cin 32 / 64 and SiLU:
+ * waves and two workgroups per CU (Cin % 32 == 0, Cout % 128 == 0, K >= 96), 85 = the same with a 128-pixel tile; 90 = 3x3 stride 1 with Cin 32 / 64 and SiLU:
  * weights stationary in registers, activation patch in LDS, persistent workgroups (Cout % 64 == 0). A specialised kernel
  * asked for a shape it does not serve runs the default instead; any other number is ADAYOLO_EINVAL.
  */

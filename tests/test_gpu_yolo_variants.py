@@ -33,7 +33,7 @@ def _serves(v, cin, cout, k, s):
         return cin % 64 == 0 and cout % 256 == 0
     if 60 <= v < 80:
         return cin % 64 == 0 and cout % 128 == 0
-    if 80 <= v < 90:
+    if 80 <= v < 90:                                   # 80: 256-pixel tile, 85: 128-pixel tile
         return cin % 32 == 0 and cout % 128 == 0 and k * k * cin >= 96
     if v >= 90:
         return k == 3 and s == 1 and cin in (32, 64) and cout % 64 == 0

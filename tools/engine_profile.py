@@ -21,7 +21,12 @@ for kind, fn, args in eng.plan:
         e0.record(); fn(*args, st); e1.record(); e1.synchronize()
         ts.append(e0.elapsed_time(e1))
     t = sorted(ts)[2] * 1e3
-    if kind == "conv":
+    if kind == "conv2":                                   # fused 3x3 + next 1x1 (adayolo_conv_fused1x1_fwd)
+        B, H, W, cin, cout, k, s = args[8:15]
+        Ho, Wo = (H - 1) // s + 1, (W - 1) // s + 1
+        fl = 2.0 * B * Ho * Wo * cout * (k * k * cin + args[20])
+        rows.append((t, f"conv {H}x{W} {cin}->{cout} k{k}s{s} + 1x1 {cout}->{args[20]} fused: {t:7.1f} us {fl / t / 1e6:7.1f} TF"))
+    elif kind == "conv":
         B, H, W, cin, cout, k, s, act, v = args[8:17]
         Ho, Wo = (H - 1) // s + 1, (W - 1) // s + 1
         fl = 2.0 * B * Ho * Wo * cout * k * k * cin
