@@ -4,7 +4,7 @@
 // it makes the stem (170 us) and the first conv (240 us) HBM-bound at ~3 TB/s. Here it never leaves the CU: a
 // workgroup owns an 8 x 16 tile of the SECOND conv's output, computes the 17 x 33 stem pixels under it into LDS
 // (10 % of them are recomputed by a neighbour) and runs the 3x3 stride-2 conv from there.
-//   A  image patch 19 x 35 x 3 fp32 -> LDS (letterbox value / zero padding resolved here, like k_stem)
+//   A  image patch 19 x 35 x 3 -> LDS as bf16 (letterbox value / zero padding resolved here, like k_stem)
 //   B  stem conv on the patch: K = 27 padded to 32 = one v_mfma_f32_16x16x32_bf16 step per 16 pixels and channel half
 //      (weights in registers, same row permutation as k_stem so that a lane owns 8 consecutive channels), bias + SiLU,
 //      bf16, 16-byte chunks XOR-swizzled by the pixel index; stem pixels outside the frame are the second conv's zero pad
@@ -37,18 +37,19 @@ constexpr int TY = 8, TX = 16;                       // output tile of the secon
 constexpr int SH = 2 * TY + 1, SW = 2 * TX + 1;      // stem pixels under it: 17 x 33
 constexpr int IH = SH + 2, IW = SW + 2;              // image pixels under those: 19 x 35
 constexpr int NSP = SH * SW;                         // 561
-constexpr int kImgBytes = ((3 * IH * IW * 4 + 15) / 16) * 16;
+constexpr int kImgBytes = ((3 * IH * IW * 2 + 15) / 16) * 16;   // the image patch as bf16 (what the stem's MFMA consumes): with fp32 the
+                                                                  // workgroup is 43.9 KB and only three fit a CU; 39.9 KB: four
 constexpr int kPatchBytes = NSP * 64;                // 32 ch bf16 per stem pixel; the 128 px x 128 B output tile overlays it
 constexpr int kSmem = kImgBytes + kPatchBytes;
 
-__global__ __launch_bounds__(256) void k_stem_down(const float* __restrict__ img, const float* __restrict__ w0,
+__global__ __launch_bounds__(256, 4) void k_stem_down(const float* __restrict__ img, const float* __restrict__ w0,
                                                    const float* __restrict__ b0, const unsigned short* __restrict__ w1,
                                                    const float* __restrict__ b1, unsigned short* __restrict__ out,
                                                    int out_cs, int H, int W, int Hp, int pad_top, float pad_value,
                                                    const unsigned short* __restrict__ w2, const float* __restrict__ b2,
                                                    unsigned short* __restrict__ out2, int out2_cs) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    float* tile = reinterpret_cast<float*>(smem);
+    unsigned short* tile = reinterpret_cast<unsigned short*>(smem);
     unsigned char* patch = smem + kImgBytes;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -91,7 +92,7 @@ __global__ __launch_bounds__(256) void k_stem_down(const float* __restrict__ img
         for (int it = 0; it < NI; ++it) asm volatile("" : "+v"(v[it]));      // the loads above stay unconditional
 #pragma unroll
         for (int it = 0; it < NI; ++it)
-            if (tid + 256 * it < 3 * IH * IW) tile[tid + 256 * it] = m[it] != 0.0f ? v[it] : padc[it];
+            if (tid + 256 * it < 3 * IH * IW) tile[tid + 256 * it] = (unsigned short)(pack2(m[it] != 0.0f ? v[it] : padc[it], 0.0f) & 0xFFFFu);
     }
 
     // ---- stem weights as two MFMA A fragments (rows permuted: row 4g+i of fragment t = channel 8g + 4t + i)
@@ -126,11 +127,11 @@ __global__ __launch_bounds__(256) void k_stem_down(const float* __restrict__ img
         const int P = grp * 16 + p;
         const int Pc = P < NSP ? P : NSP - 1;
         const int sy = Pc / SW, sx = Pc - sy * SW;
-        const float* t0 = tile + sy * IW + sx;
-        float a[8];
+        const unsigned short* t0 = tile + sy * IW + sx;
+        unsigned a[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) a[e] = (8 * g + e < 27) ? t0[off[e]] : 0.0f;
-        const u32x4 pk = {pack2(a[0], a[1]), pack2(a[2], a[3]), pack2(a[4], a[5]), pack2(a[6], a[7])};
+        for (int e = 0; e < 8; ++e) a[e] = (8 * g + e < 27) ? (unsigned)t0[off[e]] : 0u;
+        const u32x4 pk = {a[0] | (a[1] << 16), a[2] | (a[3] << 16), a[4] | (a[5] << 16), a[6] | (a[7] << 16)};
         const bf16x8 af = __builtin_bit_cast(bf16x8, pk);
         const f32x4 z = {0.f, 0.f, 0.f, 0.f};
         const f32x4 d0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[0], af, z, 0, 0, 0);
