@@ -115,6 +115,9 @@ def forward(img, op_ids, params, clip=True, pooled=None, out=None, nlm_exact=Fal
     op_ids = op_ids.contiguous()
     if out is None:
         out = torch.empty_like(img)
+    elif (out.shape != img.shape or out.dtype != torch.float32 or out.device != img.device or not out.is_contiguous()):
+        raise ValueError(f"out must be a contiguous float32 {tuple(img.shape)} tensor on {img.device}, got {out.dtype} "
+                         f"{tuple(out.shape)} on {out.device}")
     with torch.cuda.device(img.device):
         rc = L.adaisp_forward(img.data_ptr(), out.data_ptr(), pooled.data_ptr() if pooled is not None else None,
                               op_ids.data_ptr(), params.data_ptr(), params.shape[1], B, H, W,

@@ -123,6 +123,13 @@ def test_fused_eval_forced_and_highres(golden):
             np.testing.assert_allclose(x.cpu().numpy(), g[f"forced{k}.x"], rtol=2e-4, atol=2e-5)
         (x, ns, hr), _, _ = ag(inp, 1.0, high_res=T(g["hr.in"]).to(dev), selected_filter_id=5)
         np.testing.assert_allclose(hr.cpu().numpy(), g["hr.out"], rtol=2e-4, atol=2e-5)
+        # `out=`: the retouched batch lands in the caller's buffer (the bench's double-buffered hand-over), same values
+        buf = torch.full_like(inp[0], float("nan"))
+        (x2, _, _, _), _, _ = ag(inp, 1.0, selected_filter_id=3, out=buf)
+        (x3, _, _, _), _, _ = ag(inp, 1.0, selected_filter_id=3)
+        assert x2.data_ptr() == buf.data_ptr() and torch.equal(buf, x3)
+        with pytest.raises(ValueError):
+            ag(inp, 1.0, selected_filter_id=3, out=buf[:, :, :-1])
         # weights are re-snapshotted after an in-place update
         with torch.no_grad():
             ag.fc2.bias.add_(torch.tensor([0, 0, 0, 0, 0, 0, 0, 0, 50.0, 0], device=dev))
