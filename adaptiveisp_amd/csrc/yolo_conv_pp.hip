@@ -239,6 +239,10 @@ __global__ __launch_bounds__(512) void k_conv_pp(const ConvArgs a) {
     stage_a(1, smem, p0, true);
     stage_w(0, smem + kBuf, p1, 1 < nK);
     stage_a(0, smem + kBuf, p1, 1 < nK);
+    // (Measured and dropped: touching the tile's whole input region into L2 here, one 4-byte LDS-DMA per 128-byte line — L2-
+    // resident data streams into LDS at 51.6 B/clk/CU for any row stride (tools/dma_pattern.hip) while the k-loop moves 27,
+    // and about a quarter of its activation rows are first touches. The k-loop did not move: 44.1k -> 43.9k cycles,
+    // prologue + 1.0k. First-touch latency is not what holds it.)
     wait_vm<4>();                                        // k-tile 0 landed (this wave's share)
     barrier();
 
