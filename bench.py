@@ -82,13 +82,16 @@ def build_workload(a, dev):
     s0 = torch.zeros(a.batch, cfg.num_state_dim, device=dev)
     sched = SCHEDULES[a.schedule]
 
-    def isp_chain(out=None):
-        """The 5-step episode; `out`: where the last step writes the retouched batch (the pipeline's hand-over buffer)."""
-        x, st = x0, s0
+    def isp_chain(out=None, start=0, stop=None, x=None, st=None, with_state=False):
+        """The 5-step episode (or its steps [start, stop) continuing from (x, st)); `out`: where the last of these steps
+        writes its retouched batch (the pipeline's hand-over / mid-episode buffer)."""
+        stop = len(sched) if stop is None else stop
+        x = x0 if x is None else x
+        st = s0 if st is None else st
         with torch.no_grad():
-            for i, k in enumerate(sched):
-                (x, st, _, _), _, _ = agent((x, z, st), 1.0, selected_filter_id=k, out=out if i == len(sched) - 1 else None)
-        return x
+            for i in range(start, stop):
+                (x, st, _, _), _, _ = agent((x, z, st), 1.0, selected_filter_id=sched[i], out=out if i == stop - 1 else None)
+        return (x, st) if with_state else x
 
     def step():
         x = isp_chain()
@@ -96,20 +99,45 @@ def build_workload(a, dev):
             return engine(x)
 
     step.isp_chain = isp_chain
+    step.sched = sched
     return step, engine, agent, x0, sched
 
 
-def build_pipeline(step, engine, x0):
+def build_pipeline(step, engine, x0, split=None):
     """Two-stage software pipeline over consecutive batches, captured as two hipGraphs (even / odd): one replay runs
-    the ISP episode of batch i+1 (latency-bound: pooling, policy heads, one filter kernel per RL step) on one stream
+    one ISP episode's worth of work (latency-bound: pooling, policy heads, one filter kernel per RL step) on one stream
     BESIDE the detector forward of batch i (MFMA-bound) on another. Every replay still does one whole ISP pass and
     one whole detector pass; the hand-over tensor is double-buffered. Returns (prime, run): `prime()` fills the
-    pipeline (ISP of the first batch, untimed), `run()` advances it by one step."""
+    pipeline (untimed), `run()` advances it by one step.
+
+    split = 0: the ISP stream runs the episode of batch i+1 from its first step. split = s > 0: it runs steps s.. of
+    batch i+1 and then steps 0..s-1 of batch i+2 (the episode is cut at a step boundary, image and state wait in a
+    double-buffered mid-episode slot) — the phase of the ISP work against the detector's layers is chosen, not its amount.
+    Default: the cut is in front of the episode's NLM step, so that the one compute-heavy filter starts with the
+    detector's head and the latency-bound policy steps run beside the deep layers (tools/pipeline_phase_ab.py, interleaved in
+    one process at config 2: 4.56-4.57 ms per step against 4.60 for every other cut)."""
+    if split is None:
+        split = step.sched.index(4) if 4 in step.sched else 0         # 4 = NLM
     xbuf = [torch.empty_like(x0), torch.empty_like(x0)]
+    nsteps = len(step.sched)
+    if not 0 <= split < nsteps:
+        raise ValueError(f"split={split} outside the {nsteps}-step episode")
+    mid = [torch.empty_like(x0), torch.empty_like(x0)] if split else None
+    mid_st = [None, None]
     side = torch.cuda.Stream()
     # both stages on ordinary-priority streams: a high-priority stream for the ISP chain was measured 26 % SLOWER
     # (1039 vs 1407 images/s) — its NLM workgroups then pre-empt the detector's at every CU hand-over
     hp = torch.cuda.Stream()
+
+    def head(p):                                          # steps 0 .. split-1 of a fresh batch -> mid-episode slot p
+        _, st = step.isp_chain(out=mid[p], stop=split, with_state=True)
+        if mid_st[p] is None:
+            mid_st[p] = torch.empty_like(st)
+        mid_st[p].copy_(st)
+
+    if split:                                             # slots exist before capture (their addresses are baked in)
+        head(0); head(1)
+        torch.cuda.synchronize()
     graphs = []
     for p in range(2):
         g = torch.cuda.CUDAGraph()
@@ -118,19 +146,26 @@ def build_pipeline(step, engine, x0):
             side.wait_stream(cur)
             with torch.cuda.stream(side), torch.no_grad():
                 engine(xbuf[1 - p])                      # detector of the batch the previous replay retouched
-            step.isp_chain(out=xbuf[p])                  # ISP episode of the next batch, written into the hand-over buffer
+            if split:
+                step.isp_chain(out=xbuf[p], start=split, x=mid[1 - p], st=mid_st[1 - p])   # rest of batch i+1
+                head(p)                                                                    # first steps of batch i+2
+            else:
+                step.isp_chain(out=xbuf[p])              # ISP episode of the next batch, written into the hand-over buffer
             cur.wait_stream(side)
         graphs.append(g)
     state = {"i": 0}
 
     def prime():
         step.isp_chain(out=xbuf[1])
+        if split:
+            head(1)
         state["i"] = 0
 
     def run():
         graphs[state["i"] & 1].replay()
         state["i"] += 1
 
+    run.xbuf, run.state = xbuf, state                    # (for the race screens: replay k leaves its episode in xbuf[k & 1])
     return prime, run
 
 
@@ -411,7 +446,8 @@ def main():
                                f"{[NAMES[k] for k in sched]} (teacher-forced, policy/heads evaluated every step) + YOLOv3 "
                                f"forward @{a.width}x{engine.Hp} bf16 (random-init weights)",
                    "per_gpu_batch": a.batch, "global_batch": a.batch * world, "parallelism": f"replicas x{world}",
-                   "launch": ("hipGraph replay, 2-stage pipeline: ISP episode of batch i+1 beside the detector of batch i "
+                   "launch": ("hipGraph replay, 2-stage pipeline: one ISP episode's worth of steps (the rest of batch i+1 from "
+                              "its NLM step on, then the first steps of batch i+2) beside the detector of batch i "
                               "(two streams; every step = one full ISP pass + one full detector pass)") if pipelined
                    else ("hipGraph replay" if graphed else "eager")},
     }

@@ -11,7 +11,9 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_pipelined_replay_equals_sequential_step():
+@pytest.mark.parametrize("split", [None, 0, 1, 4])
+def test_pipelined_replay_equals_sequential_step(split):
+    """split: where the episode is cut between two replays (None = bench.py's default, in front of the NLM step)."""
     sys.path.insert(0, ROOT)
     import bench
     a = argparse.Namespace(batch=2, height=96, width=128, schedule="mixed", retune=False)
@@ -19,9 +21,9 @@ def test_pipelined_replay_equals_sequential_step():
     step, engine, agent, x0, sched = bench.build_workload(a, torch.device("cuda:0"))
     ref = step().clone()                                      # eager: ISP episode then detector
     torch.cuda.synchronize()
-    prime, run = bench.build_pipeline(step, engine, x0)
+    prime, run = bench.build_pipeline(step, engine, x0, split=split)
     prime()
-    for _ in range(3):                                        # even and odd graphs, steady state
+    for _ in range(4):                                        # even and odd graphs, steady state
         run()
         torch.cuda.synchronize()
         assert torch.equal(engine.pred, ref)

@@ -18,24 +18,12 @@ xref = step.isp_chain().clone()
 torch.cuda.synchronize()
 for _ in range(3):
     assert torch.equal(step(), ref), "eager forward is not deterministic"
-# the same xbuf mechanics as bench.build_pipeline, but keeping a handle on the hand-over buffers
-xbuf = [torch.empty_like(x0), torch.empty_like(x0)]
-side, hp = torch.cuda.Stream(), torch.cuda.Stream()
-graphs = []
-for p in range(2):
-    g = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(g, stream=hp):
-        cur = torch.cuda.current_stream()
-        side.wait_stream(cur)
-        with torch.cuda.stream(side), torch.no_grad():
-            engine(xbuf[1 - p])
-        xbuf[p].copy_(step.isp_chain())
-        cur.wait_stream(side)
-    graphs.append(g)
-xbuf[1].copy_(step.isp_chain())
+prime, run = bench.build_pipeline(step, engine, x0, split=int(os.environ["SPLIT"]) if "SPLIT" in os.environ else None)
+prime()
+xbuf = run.xbuf
 bad = badx = 0
 for i in range(n):
-    graphs[i & 1].replay()
+    run()
     torch.cuda.synchronize()
     if not torch.equal(xbuf[i & 1], xref):
         badx += 1
