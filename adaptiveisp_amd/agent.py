@@ -87,15 +87,28 @@ class Agent(nn.Module):
         return isp_apply_selected(img, packed, op_ids, clip=True)
 
     # ------------------------------------------------------------------------------------------
-    def _forward_fast(self, x, z, states, progress, high_res, selected_filter_id, out=None):
-        """Eval-mode step on the fused kernels: 7 launches instead of ~250 (see policy_fast.py)."""
+    def plan_step(self, inp, progress, selected_filter_id=None):
+        """First half of an eval step on the fused kernels: 64x64 pooling + the policy (trunks, heads, selection, state
+        update, penalties). Returns the step's decision — a dict of device tensors (`op_ids`, `packed` parameter rows,
+        `new_states`, `selected`, `pdf`, `params_all`, `surrogate`, `penalty`) — without touching the full-resolution
+        image. `apply_step` is the other half; `forward` in eval mode is the two in sequence (agent.py:88-285)."""
+        x, z, states = inp
         if self._fast is None:
             from .policy_fast import FastPolicy
             self._fast = FastPolicy(self)
-        o = self._fast.run(self.down_sample(x), z, states, progress, selected_filter_id)
+        return self._fast.run(self.down_sample(x), z, states, progress, selected_filter_id)
+
+    def apply_step(self, x, plan, out=None):
+        """Second half: the selected filter of every image on the full-resolution batch (one adaisp_forward call; `plan`
+        needs `op_ids` and `packed` only, so a caller may carry just those two between the halves)."""
         no_usm = _lib.OP_USM not in self._op_table_host
-        x_out = _lib.forward(x, o["op_ids"], o["packed"], clip=True, no_usm=no_usm, out=out)
-        hr_out = _lib.forward(high_res, o["op_ids"], o["packed"], clip=True, no_usm=no_usm) if high_res is not None else None
+        return _lib.forward(x, plan["op_ids"], plan["packed"], clip=True, no_usm=no_usm, out=out)
+
+    def _forward_fast(self, x, z, states, progress, high_res, selected_filter_id, out=None):
+        """Eval-mode step on the fused kernels: 7 launches instead of ~250 (see policy_fast.py)."""
+        o = self.plan_step((x, z, states), progress, selected_filter_id)
+        x_out = self.apply_step(x, o, out=out)
+        hr_out = self.apply_step(high_res, o) if high_res is not None else None
         mask = self._ones_mask                      # Filter.get_mask with masking off (isp/filters.py:161-173): ones(1,1,1,1)
         if mask is None or mask.device != x.device:
             mask = self._ones_mask = torch.ones((1, 1, 1, 1), dtype=torch.float32, device=x.device)

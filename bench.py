@@ -82,16 +82,23 @@ def build_workload(a, dev):
     s0 = torch.zeros(a.batch, cfg.num_state_dim, device=dev)
     sched = SCHEDULES[a.schedule]
 
-    def isp_chain(out=None, start=0, stop=None, x=None, st=None, with_state=False):
-        """The 5-step episode (or its steps [start, stop) continuing from (x, st)); `out`: where the last of these steps
-        writes its retouched batch (the pipeline's hand-over / mid-episode buffer)."""
-        stop = len(sched) if stop is None else stop
-        x = x0 if x is None else x
-        st = s0 if st is None else st
+    def isp_chain(out=None, start=0, stop=None, carry=None, with_carry=False):
+        """The 5-step episode, or a slice of it in HALF-steps: half-step 2i is step i's pooling + policy
+        (Agent.plan_step), 2i+1 its filter on the full-resolution batch (Agent.apply_step); `carry` = (image, states,
+        pending plan) continues a slice. `out`: where the slice's last filter writes (the pipeline's hand-over /
+        mid-episode buffer). Half-steps [0, 2*len(sched)) in order are exactly Agent.forward step by step."""
+        stop = 2 * len(sched) if stop is None else stop
+        x, st, plan = carry if carry is not None else (x0, s0, None)
+        last_apply = max((h for h in range(start, stop) if h & 1), default=-1)
         with torch.no_grad():
-            for i in range(start, stop):
-                (x, st, _, _), _, _ = agent((x, z, st), 1.0, selected_filter_id=sched[i], out=out if i == stop - 1 else None)
-        return (x, st) if with_state else x
+            for h in range(start, stop):
+                if h & 1:
+                    x = agent.apply_step(x, plan, out=out if h == last_apply else None)
+                    plan = None
+                else:
+                    plan = agent.plan_step((x, z, st), 1.0, selected_filter_id=sched[h >> 1])
+                    st = plan["new_states"]
+        return (x, st, plan) if with_carry else x
 
     def step():
         x = isp_chain()
@@ -103,39 +110,52 @@ def build_workload(a, dev):
     return step, engine, agent, x0, sched
 
 
-def build_pipeline(step, engine, x0, split=None):
+def build_pipeline(step, engine, x0, cut=None, gate=None):
     """Two-stage software pipeline over consecutive batches, captured as two hipGraphs (even / odd): one replay runs
     one ISP episode's worth of work (latency-bound: pooling, policy heads, one filter kernel per RL step) on one stream
-    BESIDE the detector forward of batch i (MFMA-bound) on another. Every replay still does one whole ISP pass and
-    one whole detector pass; the hand-over tensor is double-buffered. Returns (prime, run): `prime()` fills the
-    pipeline (untimed), `run()` advances it by one step.
+    and the detector forward of batch i (MFMA-bound) on another. Every replay still does one whole ISP pass and one
+    whole detector pass; the hand-over tensor is double-buffered. Returns (prime, run): `prime()` fills the pipeline
+    (untimed), `run()` advances it by one step.
 
-    split = 0: the ISP stream runs the episode of batch i+1 from its first step. split = s > 0: it runs steps s.. of
-    batch i+1 and then steps 0..s-1 of batch i+2 (the episode is cut at a step boundary, image and state wait in a
-    double-buffered mid-episode slot) — the phase of the ISP work against the detector's layers is chosen, not its amount.
-    Default: the cut is in front of the episode's NLM step, so that the one compute-heavy filter starts with the
-    detector's head and the latency-bound policy steps run beside the deep layers (tools/pipeline_phase_ab.py, interleaved in
-    one process at config 2: 4.56-4.57 ms per step against 4.60 for every other cut)."""
-    if split is None:
-        split = step.sched.index(4) if 4 in step.sched else 0         # 4 = NLM
+    cut (in half-steps, see isp_chain): the ISP stream runs half-steps cut.. of batch i+1 and then 0..cut-1 of batch
+    i+2 — the episode is cut there, image / states / pending plan wait in a double-buffered mid-episode slot; the PHASE
+    of the ISP work against the detector's layers is chosen, not its amount. gate: how many of the ISP stream's
+    half-steps run before the detector stream is released (0: both start together).
+    Default: the cut is in front of the NLM step and both streams start together. tools/pipeline_phase_ab.py, interleaved
+    in one process at config 2 (ms per step): no cut 4.36; cut in front of the NLM step 4.32 (either side of its policy
+    half); NLM alone first, detector released after it 4.365; two or three half-steps alone 4.44-4.46. The step is the
+    sum of the CU time of detector, NLM and the pointwise kernels in every arrangement — running NLM alone buys nothing,
+    so the two do not fragment each other's CUs either."""
+    sched = step.sched
+    nh = 2 * len(sched)
+    if cut is None:
+        cut = 2 * sched.index(4) if 4 in sched else 0               # 4 = NLM
+    gate = 0 if gate is None else gate
+    if not 0 <= cut < nh:
+        raise ValueError(f"cut={cut} outside the {nh} half-steps of the episode")
     xbuf = [torch.empty_like(x0), torch.empty_like(x0)]
-    nsteps = len(step.sched)
-    if not 0 <= split < nsteps:
-        raise ValueError(f"split={split} outside the {nsteps}-step episode")
-    mid = [torch.empty_like(x0), torch.empty_like(x0)] if split else None
-    mid_st = [None, None]
+    mid = [None, None]                                    # per slot: (image, states, op ids, packed parameter rows)
     side = torch.cuda.Stream()
     # both stages on ordinary-priority streams: a high-priority stream for the ISP chain was measured 26 % SLOWER
     # (1039 vs 1407 images/s) — its NLM workgroups then pre-empt the detector's at every CU hand-over
     hp = torch.cuda.Stream()
 
-    def head(p):                                          # steps 0 .. split-1 of a fresh batch -> mid-episode slot p
-        _, st = step.isp_chain(out=mid[p], stop=split, with_state=True)
-        if mid_st[p] is None:
-            mid_st[p] = torch.empty_like(st)
-        mid_st[p].copy_(st)
+    def head(p):                                          # half-steps 0 .. cut-1 of a fresh batch -> mid-episode slot p
+        if mid[p] is None:
+            x, st, plan = step.isp_chain(stop=cut, with_carry=True)
+            mid[p] = [torch.empty_like(x0) if cut > 1 else None, torch.empty_like(st),
+                      torch.empty_like(plan["op_ids"]) if plan else None, torch.empty_like(plan["packed"]) if plan else None]
+        x, st, plan = step.isp_chain(out=mid[p][0], stop=cut, with_carry=True)
+        mid[p][1].copy_(st)
+        if plan:
+            mid[p][2].copy_(plan["op_ids"])
+            mid[p][3].copy_(plan["packed"])
 
-    if split:                                             # slots exist before capture (their addresses are baked in)
+    def carry(p):
+        img, st, ids, packed = mid[p]
+        return (img if img is not None else x0, st, {"op_ids": ids, "packed": packed} if ids is not None else None)
+
+    if cut:                                               # slots exist before capture (their addresses are baked in)
         head(0); head(1)
         torch.cuda.synchronize()
     graphs = []
@@ -143,21 +163,24 @@ def build_pipeline(step, engine, x0, split=None):
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g, stream=hp):
             cur = torch.cuda.current_stream()
+            c = carry(1 - p) if cut else None
+            if gate:                                     # the ISP stream's first half-steps run alone
+                c = step.isp_chain(out=xbuf[p] if cut + gate >= nh else None, start=cut, stop=min(cut + gate, nh), carry=c,
+                                   with_carry=True)
             side.wait_stream(cur)
             with torch.cuda.stream(side), torch.no_grad():
                 engine(xbuf[1 - p])                      # detector of the batch the previous replay retouched
-            if split:
-                step.isp_chain(out=xbuf[p], start=split, x=mid[1 - p], st=mid_st[1 - p])   # rest of batch i+1
-                head(p)                                                                    # first steps of batch i+2
-            else:
-                step.isp_chain(out=xbuf[p])              # ISP episode of the next batch, written into the hand-over buffer
+            if cut + gate < nh:
+                step.isp_chain(out=xbuf[p], start=cut + gate, carry=c)   # rest of batch i+1 -> hand-over buffer
+            if cut:
+                head(p)                                  # first half-steps of batch i+2 -> mid-episode slot
             cur.wait_stream(side)
         graphs.append(g)
     state = {"i": 0}
 
     def prime():
         step.isp_chain(out=xbuf[1])
-        if split:
+        if cut:
             head(1)
         state["i"] = 0
 
@@ -446,8 +469,8 @@ def main():
                                f"{[NAMES[k] for k in sched]} (teacher-forced, policy/heads evaluated every step) + YOLOv3 "
                                f"forward @{a.width}x{engine.Hp} bf16 (random-init weights)",
                    "per_gpu_batch": a.batch, "global_batch": a.batch * world, "parallelism": f"replicas x{world}",
-                   "launch": ("hipGraph replay, 2-stage pipeline: one ISP episode's worth of steps (the rest of batch i+1 from "
-                              "its NLM step on, then the first steps of batch i+2) beside the detector of batch i "
+                   "launch": ("hipGraph replay, 2-stage pipeline: one ISP episode's worth of steps (batch i+1 from its NLM "
+                              "step on, then the first steps of batch i+2) beside the detector of batch i "
                               "(two streams; every step = one full ISP pass + one full detector pass)") if pipelined
                    else ("hipGraph replay" if graphed else "eager")},
     }

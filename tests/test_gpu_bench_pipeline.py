@@ -11,9 +11,10 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("split", [None, 0, 1, 4])
-def test_pipelined_replay_equals_sequential_step(split):
-    """split: where the episode is cut between two replays (None = bench.py's default, in front of the NLM step)."""
+@pytest.mark.parametrize("cut,gate", [(None, None), (0, 0), (0, 3), (2, 0), (5, 0), (5, 1), (4, 3), (9, 1), (1, 9)])
+def test_pipelined_replay_equals_sequential_step(cut, gate):
+    """cut: the half-step at which the episode is split between two replays; gate: half-steps that run before the
+    detector stream is released (None, None = bench.py's default: cut in front of the NLM launch, detector after it)."""
     sys.path.insert(0, ROOT)
     import bench
     a = argparse.Namespace(batch=2, height=96, width=128, schedule="mixed", retune=False)
@@ -21,7 +22,7 @@ def test_pipelined_replay_equals_sequential_step(split):
     step, engine, agent, x0, sched = bench.build_workload(a, torch.device("cuda:0"))
     ref = step().clone()                                      # eager: ISP episode then detector
     torch.cuda.synchronize()
-    prime, run = bench.build_pipeline(step, engine, x0, split=split)
+    prime, run = bench.build_pipeline(step, engine, x0, cut=cut, gate=gate)
     prime()
     for _ in range(4):                                        # even and odd graphs, steady state
         run()

@@ -18,7 +18,8 @@ xref = step.isp_chain().clone()
 torch.cuda.synchronize()
 for _ in range(3):
     assert torch.equal(step(), ref), "eager forward is not deterministic"
-prime, run = bench.build_pipeline(step, engine, x0, split=int(os.environ["SPLIT"]) if "SPLIT" in os.environ else None)
+prime, run = bench.build_pipeline(step, engine, x0, cut=int(os.environ["CUT"]) if "CUT" in os.environ else None,
+                                  gate=int(os.environ["GATE"]) if "GATE" in os.environ else None)
 prime()
 xbuf = run.xbuf
 bad = badx = 0
