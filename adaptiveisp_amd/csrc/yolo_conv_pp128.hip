@@ -77,7 +77,8 @@ struct KPos {                                 // wave-uniform position of a k-ti
     long aoff, woff;
 };
 
-// ABL: 0 real kernel, 5 no DMA instructions in the k-loop, 6 no epilogue (measurement builds)
+// ABL: 0 real kernel, 5 no DMA instructions in the k-loop, 6 no epilogue, 7 activation DMA for one tap in nine
+// (measurement builds; profiles/round2_conv_pp_ablation.txt)
 template <int ABL>
 __global__ __launch_bounds__(512) void k_conv_pp128(const ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -256,7 +257,7 @@ __global__ __launch_bounds__(512) void k_conv_pp128(const ConvArgs a) {
             asm volatile("" : "+v"(g[0]), "+v"(g[1]), "+v"(g[2]), "+v"(g[3]));
             barrier();
             unsigned char* const dc[4] = {d[0], d[1], d[2], d[3]};
-            mma(1, w1, g, dc, 4);
+            mma(1, w1, g, dc, (ABL == 7 && p3.tap != 0) ? 0 : 4);   // ABL 7 (measurement): activation DMA for one tap in nine
         }
         wait_vm<10>();
         barrier();
@@ -375,6 +376,7 @@ hipError_t launch_conv_pp128(ConvArgs a, hipStream_t s, int variant) {
 #ifdef ADAYOLO_MEASURE
     if (variant == 65) return pp128::launch<5>(a, s);
     if (variant == 66) return pp128::launch<6>(a, s);
+    if (variant == 67) return pp128::launch<7>(a, s);
 #endif
     (void)variant;
     return pp128::launch<0>(a, s);
