@@ -130,6 +130,14 @@ def test_fused_eval_forced_and_highres(golden):
         assert x2.data_ptr() == buf.data_ptr() and torch.equal(buf, x3)
         with pytest.raises(ValueError):
             ag(inp, 1.0, selected_filter_id=3, out=buf[:, :, :-1])
+        # the two halves of the eval step (pooling + policy, then the filter launch) are the step
+        for k in (None, 4):
+            plan = ag.plan_step(inp, 1.0, selected_filter_id=k)
+            (xr, nsr, surr, penr), dbgr, _ = ag(inp, 1.0, selected_filter_id=k)
+            assert torch.equal(ag.apply_step(inp[0], plan), xr) and torch.equal(plan["new_states"], nsr)
+            assert torch.equal(plan["selected"], dbgr["selected_filter"]) and torch.equal(plan["penalty"], penr)
+            carried = {"op_ids": plan["op_ids"].clone(), "packed": plan["packed"].clone()}      # what a caller must carry
+            assert torch.equal(ag.apply_step(inp[0], carried, out=buf), xr) and torch.equal(buf, xr)
         # weights are re-snapshotted after an in-place update
         with torch.no_grad():
             ag.fc2.bias.add_(torch.tensor([0, 0, 0, 0, 0, 0, 0, 0, 50.0, 0], device=dev))
