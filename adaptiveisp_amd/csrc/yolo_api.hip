@@ -238,4 +238,29 @@ int adayolo_nms(const float* boxes_xyxy, int n, float iou_thres, int max_det, vo
                       static_cast<hipStream_t>(stream)) == hipSuccess ? ADAYOLO_OK : ADAYOLO_ELAUNCH;
 }
 
+static int detloss_check(const adayolo_loss_args* a, bool bwd) {
+    if (!a || a->nl < 1 || a->nl > 4 || a->B < 1 || a->B > 65535 || a->na < 1 || a->nc < 1 || a->no != a->nc + 5 || !a->loss)
+        return ADAYOLO_EINVAL;
+    if (bwd && !a->grad_loss) return ADAYOLO_EINVAL;
+    for (int i = 0; i < a->nl; ++i) {
+        const adayolo_loss_layer& L = a->layer[i];
+        if (!L.raw || !L.tobj || !L.cnt || L.n < 0 || (L.n > 0 && (!L.idx || !L.box || !L.iou))) return ADAYOLO_EINVAL;
+        if (L.ny < 1 || L.nx < 1 || L.cs < a->na * a->no) return ADAYOLO_ESHAPE;
+        if (bwd && (!L.grad || L.grad_cs % 8 || L.grad_cs < a->na * a->no)) return ADAYOLO_ESHAPE;
+    }
+    return ADAYOLO_OK;
+}
+
+int adayolo_detloss_fwd(const adayolo_loss_args* args, void* stream) {
+    const int rc = detloss_check(args, false);
+    if (rc != ADAYOLO_OK) return rc;
+    return launch_detloss_fwd(*args, static_cast<hipStream_t>(stream)) == hipSuccess ? ADAYOLO_OK : ADAYOLO_ELAUNCH;
+}
+
+int adayolo_detloss_bwd(const adayolo_loss_args* args, void* stream) {
+    const int rc = detloss_check(args, true);
+    if (rc != ADAYOLO_OK) return rc;
+    return launch_detloss_bwd(*args, static_cast<hipStream_t>(stream)) == hipSuccess ? ADAYOLO_OK : ADAYOLO_ELAUNCH;
+}
+
 }  // extern "C"

@@ -73,6 +73,8 @@ hipError_t launch_upsample_bwd(const void* gy, int gy_cs, void* gx, int gx_cs, i
                                hipStream_t s);
 hipError_t launch_image_grad(const void* g, int g_cs, float* grad_img, int B, int H, int W, int Hp, int pad_top,
                              hipStream_t s);
+hipError_t launch_detloss_fwd(const adayolo_loss_args& a, hipStream_t s);   // yolo_loss.hip
+hipError_t launch_detloss_bwd(const adayolo_loss_args& a, hipStream_t s);
 hipError_t launch_nms(const float* boxes, int n, float thr, int max_det, unsigned long long* mask_ws, int* keep,
                       int* num_keep, hipStream_t s);
 

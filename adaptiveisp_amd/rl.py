@@ -5,6 +5,8 @@ The literal semantics are kept, including the `truncated` flag: the bootstrap te
 (1 - truncated) where truncated = 1 for images whose mean brightness is inside (0.01, max_bri), i.e. the value
 bootstrap survives only for too-dark / too-bright results (train.py:287-291).
 """
+import os
+
 import torch
 
 from .util import STATE_STEP_DIM, STATE_STOPPED_DIM
@@ -52,12 +54,19 @@ def train_iteration(cfg, agent, value, detector, loss_fn, imgs, z, states, label
     from . import dist as adist
     from .yolo.loss import batched_per_sample_loss as per_sample_loss
     (retouch, new_states, surrogate, penalty), _, _ = agent((imgs, z, states), progress)
-    from .yolo.loss import assign_labels
-    with torch.no_grad():
-        p_in = detector(imgs)
-        assigned = assign_labels(loss_fn, p_in, labels)      # same labels, same map shapes for both batches
-        l_in = per_sample_loss(loss_fn, p_in, labels, assigned)
-    l_re = per_sample_loss(loss_fn, detector(retouch), labels, assigned)
+    from .yolo.loss import assign_labels, pack_assigned
+    if getattr(detector, "per_sample_loss", None) is not None and os.environ.get("ADAYOLO_FUSED_LOSS", "1") == "1":
+        # HIP training engine: detector forward + one loss launch on its bf16 head maps (csrc/yolo_loss.hip), no fp32 copies
+        with torch.no_grad():
+            packed = pack_assigned(assign_labels(loss_fn, detector.head_shapes(), labels))
+            l_in = detector.per_sample_loss(loss_fn, imgs, packed)
+        l_re = detector.per_sample_loss(loss_fn, retouch, packed)
+    else:
+        with torch.no_grad():
+            p_in = detector(imgs)
+            assigned = assign_labels(loss_fn, p_in, labels)      # same labels, same map shapes for both batches
+            l_in = per_sample_loss(loss_fn, p_in, labels, assigned)
+        l_re = per_sample_loss(loss_fn, detector(retouch), labels, assigned)
     old_value = value(imgs, states)
     new_value = value(retouch, new_states)
     out = td_losses(cfg, l_in, l_re, penalty, surrogate, new_states, old_value, new_value,

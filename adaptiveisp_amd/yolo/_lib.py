@@ -9,13 +9,28 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libadayolo.so")
 ABI_VERSION = 1
 ACT_NONE, ACT_SILU = 0, 1
 EXPORTS = ("adayolo_conv_fwd", "adayolo_conv_fwd_variant", "adayolo_conv_fused1x1_fwd", "adayolo_stem_fwd", "adayolo_upsample2x", "adayolo_detect_decode", "adayolo_nms", "adayolo_nms_workspace_bytes", "adayolo_stem_fwd_act", "adayolo_stem_down_fwd", "adayolo_letterbox_pack", "adayolo_silu_fwd", "adayolo_silu_bwd",
-           "adayolo_zero_insert2x", "adayolo_upsample2x_bwd", "adayolo_image_grad", "adayolo_strerror",
+           "adayolo_zero_insert2x", "adayolo_upsample2x_bwd", "adayolo_image_grad", "adayolo_detloss_fwd", "adayolo_detloss_bwd",
+           "adayolo_strerror",
            "adayolo_abi_version")
 _lib = None
 
 
 class AdayoloError(RuntimeError):
     pass
+
+
+class LossLayer(ctypes.Structure):                 # adayolo_loss_layer (include/adayolo.h)
+    _fields_ = [("raw", ctypes.c_void_p), ("cs", ctypes.c_int), ("ny", ctypes.c_int), ("nx", ctypes.c_int),
+                ("balance", ctypes.c_float), ("idx", ctypes.c_void_p), ("box", ctypes.c_void_p), ("n", ctypes.c_int),
+                ("iou", ctypes.c_void_p), ("tobj", ctypes.c_void_p), ("cnt", ctypes.c_void_p),
+                ("grad", ctypes.c_void_p), ("grad_cs", ctypes.c_int)]
+
+
+class LossArgs(ctypes.Structure):                  # adayolo_loss_args
+    _fields_ = [("layer", LossLayer * 4), ("nl", ctypes.c_int), ("B", ctypes.c_int), ("na", ctypes.c_int),
+                ("nc", ctypes.c_int), ("no", ctypes.c_int), ("hyp_box", ctypes.c_float), ("hyp_obj", ctypes.c_float),
+                ("hyp_cls", ctypes.c_float), ("cp", ctypes.c_float), ("cn", ctypes.c_float), ("cls_pw", ctypes.c_float),
+                ("obj_pw", ctypes.c_float), ("loss", ctypes.c_void_p), ("grad_loss", ctypes.c_void_p)]
 
 
 def load():
@@ -48,6 +63,9 @@ def load():
     L.adayolo_image_grad.argtypes = [vp, ci, vp, ci, ci, ci, ci, ci, vp]
     for n in ("adayolo_stem_fwd_act", "adayolo_stem_down_fwd", "adayolo_letterbox_pack", "adayolo_silu_fwd", "adayolo_silu_bwd", "adayolo_zero_insert2x",
               "adayolo_upsample2x_bwd", "adayolo_image_grad"):
+        getattr(L, n).restype = ci
+    for n in ("adayolo_detloss_fwd", "adayolo_detloss_bwd"):
+        getattr(L, n).argtypes = [ctypes.POINTER(LossArgs), vp]
         getattr(L, n).restype = ci
     L.adayolo_nms.argtypes = [vp, ci, cf, ci, vp, vp, vp, vp]
     L.adayolo_nms.restype = ci

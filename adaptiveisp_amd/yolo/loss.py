@@ -136,6 +136,17 @@ def assign_labels(loss_fn, preds, labels):
     return loss_fn.assign(preds, targets)
 
 
+def pack_assigned(assigned):
+    """The target assignment in the form the fused loss kernels read (include/adayolo.h, adayolo_loss_layer): per layer
+    idx int32 [n,5] = (image, anchor, gj, gi, class) and box fp32 [n,6] = (tx, ty, tw, th, anchor_w, anchor_h)."""
+    packed = []
+    for m in assigned:
+        idx = torch.stack((m["b"], m["a"], m["gj"], m["gi"], m["cls"]), 1).to(torch.int32).contiguous()
+        box = torch.cat((m["box"], m["anchors"]), 1).float().contiguous()
+        packed.append((idx, box))
+    return packed
+
+
 def batched_per_sample_loss(loss_fn, preds, labels, assigned=None):
     """The same [B,1] per-image losses as `per_sample_loss` in ONE batched pass (the reference loops over the samples
     in Python, train.py:184-196: 2*B loss evaluations of ~150 tiny launches each per iteration). Every reduction the

@@ -198,11 +198,91 @@ class YoloTrainEngine(YoloEngine):
             self._run(self.tbwd, grad_img=grad_img)
         return grad_img
 
+    # ---- fused per-image detection loss on the raw maps (csrc/yolo_loss.hip) -----------------------------------
+    def head_shapes(self):
+        """Stand-ins for the three head maps where only their SHAPES are needed (loss.assign_labels)."""
+        import types
+        return [types.SimpleNamespace(shape=(self.B, self.na, v.H, v.W, self.no), device=self.dev) for v in self.raw]
+
+    def _loss_args(self, loss_fn, packed):
+        """adayolo_loss_args over this engine's raw maps / gradient buffers and the packed target assignment."""
+        dev, nl = self.dev, len(self.raw)
+        ws = getattr(self, "_loss_ws", None)
+        if ws is None:
+            ws = self._loss_ws = dict(
+                tobj=[torch.empty((self.B, self.na, v.H, v.W), dtype=torch.float32, device=dev) for v in self.raw],
+                cnt=[torch.empty((self.B,), dtype=torch.float32, device=dev) for _ in self.raw], iou=[None] * nl)
+        a = _lib.LossArgs()
+        keep = []
+        for i, (v, gv, (idx, box)) in enumerate(zip(self.raw, self._graw, packed)):
+            n = int(idx.shape[0])
+            if ws["iou"][i] is None or ws["iou"][i].numel() < max(n, 1):
+                ws["iou"][i] = torch.empty((max(n, 256),), dtype=torch.float32, device=dev)
+            L = a.layer[i]
+            L.raw, L.cs, L.ny, L.nx, L.balance = v.ptr, v.cs, v.H, v.W, float(loss_fn.balance[i])
+            L.idx, L.box, L.n = idx.data_ptr() if n else None, box.data_ptr() if n else None, n
+            L.iou, L.tobj, L.cnt = ws["iou"][i].data_ptr(), ws["tobj"][i].data_ptr(), ws["cnt"][i].data_ptr()
+            L.grad, L.grad_cs = gv.ptr, gv.cs
+            keep += [idx, box]
+        a.nl, a.B, a.na, a.nc, a.no = nl, self.B, self.na, loss_fn.nc, self.no
+        h = loss_fn.hyp
+        a.hyp_box, a.hyp_obj, a.hyp_cls = float(h["box"]), float(h["obj"]), float(h["cls"])
+        a.cp, a.cn, a.cls_pw, a.obj_pw = float(loss_fn.cp), float(loss_fn.cn), float(h["cls_pw"]), float(h["obj_pw"])
+        return a, keep
+
+    def _loss_forward(self, loss_fn, img, packed):
+        if img.shape != (self.B, 3, self.H, self.W) or img.dtype != torch.float32 or img.device != self.dev:
+            raise ValueError(f"expected fp32 {(self.B, 3, self.H, self.W)} on {self.dev}")
+        if loss_fn.nc + 5 != self.no or len(packed) != len(self.raw) or loss_fn.hyp.get("fl_gamma", 0.0) != 0.0:
+            raise ValueError("loss / detector mismatch (classes, layers) or focal loss requested: use the PyTorch loss")
+        img = img.contiguous()
+        loss = torch.empty((self.B,), dtype=torch.float32, device=self.dev)
+        with torch.cuda.device(self.dev):
+            self._run(self.tfwd, img=img)
+            self._gen += 1
+            a, keep = self._loss_args(loss_fn, packed)
+            a.loss = loss.data_ptr()
+            _lib.check(self.L.adayolo_detloss_fwd(ctypes.byref(a), _lib.stream_ptr()), "adayolo_detloss_fwd")
+        return loss.view(self.B, 1)
+
+    def per_sample_loss(self, loss_fn, img, packed):
+        """[B,1] per-image detection losses of `img` through the detector (reference train.py:175-197, 262-271) with the
+        target assignment `packed` (loss.pack_assigned(loss.assign_labels(...))), on the fused HIP kernels: detector forward,
+        one loss launch on the bf16 head maps; with autograd: two launches write the head-map gradients, then the detector's
+        backward. The same numbers as `loss.batched_per_sample_loss(loss_fn, engine(img), ...)` (tests/test_gpu_yolo_train.py)."""
+        if torch.is_grad_enabled() and img.requires_grad:
+            return _DetectorLossFn.apply(img, self, loss_fn, packed)
+        return self._loss_forward(loss_fn, img, packed)
+
     def __call__(self, img):
         """Differentiable detector: raw maps with autograd to `img` (the frozen reward model of the RL loop)."""
         if torch.is_grad_enabled() and img.requires_grad:
             return list(_DetectorFn.apply(img, self))
         return self.forward_train(img)
+
+
+class _DetectorLossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, img, engine, loss_fn, packed):
+        loss = engine._loss_forward(loss_fn, img, packed)
+        ctx.engine, ctx.gen, ctx.loss_fn, ctx.packed = engine, engine._gen, loss_fn, packed
+        return loss
+
+    @staticmethod
+    def backward(ctx, grad_loss):
+        eng = ctx.engine
+        if ctx.gen != eng._gen:
+            raise RuntimeError("YoloTrainEngine: backward after a newer forward overwrote the saved pre-activations "
+                               "(one engine holds one set of buffers; use a second engine for interleaved graphs)")
+        g = grad_loss.reshape(eng.B).float().contiguous()
+        grad_img = torch.empty((eng.B, 3, eng.H, eng.W), dtype=torch.float32, device=eng.dev)
+        with torch.cuda.device(eng.dev):
+            a, keep = eng._loss_args(ctx.loss_fn, ctx.packed)
+            scratch = torch.empty((eng.B,), dtype=torch.float32, device=eng.dev)
+            a.loss, a.grad_loss = scratch.data_ptr(), g.data_ptr()
+            _lib.check(eng.L.adayolo_detloss_bwd(ctypes.byref(a), _lib.stream_ptr()), "adayolo_detloss_bwd")
+            eng._run(eng.tbwd, grad_img=grad_img)
+        return grad_img, None, None, None
 
 
 class _DetectorFn(torch.autograd.Function):

@@ -167,6 +167,37 @@ size_t adayolo_nms_workspace_bytes(int n);
 int adayolo_nms(const float* boxes_xyxy, int n, float iou_thres, int max_det, void* workspace,
                 int32_t* keep, int32_t* num_keep, void* stream);
 
+/*
+ * Per-image detection loss of the RL reward on the RAW head maps, with its gradient (training path). Replaces the
+ * caller-side Python of train.py:175-197 — `ComputeLossBatch` called once per sample with the image index of its targets
+ * set to 0 — i.e. ComputeLoss.__call__ (yolov3/utils/loss.py:115-170 / :262-318) and bbox_iou(CIoU=True)
+ * (yolov3/utils/metrics.py:222-260). The target assignment (build_targets, loss.py:320-380) stays with the caller:
+ * per layer it hands over n matches, idx[j] = (image, anchor, gj, gi, class) and box[j] = (tx, ty, tw, th, anchor_w,
+ * anchor_h) in cell units (tx, ty relative to the cell).
+ *   loss[b] = hyp_box * sum_l mean_{matches of b in l}(1 - CIoU)  +  hyp_cls * sum_l mean_{matches x classes} BCE(cls)
+ *           + hyp_obj * sum_l balance_l * mean_{anchors x cells of b} BCE(obj, tobj),  tobj = clamp(CIoU, 0) at matched cells
+ *   (a cell matched more than once keeps its LAST match's value, the result of a sequential index assignment).
+ * raw: the detector's head map, NHWC bf16 [B][ny][nx][cs], channel = anchor * no + (x, y, w, h, obj, classes...).
+ * Scratch per layer (device, caller-owned, written by _fwd and read by _bwd): iou fp32 [n], tobj fp32 [B][na][ny][nx],
+ * cnt fp32 [B]. adayolo_detloss_bwd writes EVERY element of grad (NHWC bf16 [B][ny][nx][grad_cs], grad_cs % 8 == 0,
+ * >= na*no; channels past na*no are zeroed): d (sum_b grad_loss[b] * loss[b]) / d raw. Both are bit-reproducible.
+ */
+typedef struct adayolo_loss_layer {
+    const void* raw; int cs; int ny, nx; float balance;
+    const int32_t* idx; const float* box; int n;
+    float* iou; float* tobj; float* cnt;
+    void* grad; int grad_cs;
+} adayolo_loss_layer;
+typedef struct adayolo_loss_args {
+    adayolo_loss_layer layer[4];
+    int nl, B, na, nc, no;
+    float hyp_box, hyp_obj, hyp_cls, cp, cn, cls_pw, obj_pw;
+    float* loss;                 /* [B] */
+    const float* grad_loss;      /* [B], _bwd only */
+} adayolo_loss_args;
+int adayolo_detloss_fwd(const adayolo_loss_args* args, void* stream);
+int adayolo_detloss_bwd(const adayolo_loss_args* args, void* stream);
+
 const char* adayolo_strerror(int code);
 int adayolo_abi_version(void);
 

@@ -68,3 +68,32 @@ def test_adayolo_argument_checks_without_gpu():
         assert conv(p, 8, p, p, None, 0, p, 8, 1, 4, 4, 8, 8, 3, 1, 1, bogus, None) == -1, bogus
     assert L.adayolo_letterbox_pack(None, p, 8, 1, 4, 4, 4, 0, 0.5, None) == -1
     assert L.adayolo_letterbox_pack(p, p, 6, 1, 4, 4, 4, 0, 0.5, None) == -2
+
+
+def test_detloss_argument_checks_without_gpu():
+    """adayolo_detloss_fwd / _bwd (include/adayolo.h) refuse malformed argument blocks before any launch, and the
+    ctypes mirror of the structs has the header's layout (88 / 416 bytes on LP64)."""
+    from adaptiveisp_amd.yolo import _lib
+    L = _lib.load()
+    assert ctypes.sizeof(_lib.LossLayer) == 88 and ctypes.sizeof(_lib.LossArgs) == 416
+    assert L.adayolo_detloss_fwd(None, None) == -1
+    buf = (ctypes.c_float * 64)()
+    p = ctypes.cast(buf, ctypes.c_void_p).value
+    a = _lib.LossArgs()
+    a.nl, a.B, a.na, a.nc, a.no, a.loss = 1, 1, 3, 80, 85, p
+    lay = a.layer[0]
+    lay.raw, lay.cs, lay.ny, lay.nx, lay.tobj, lay.cnt, lay.n = p, 256, 2, 2, p, p, 0
+    lay.cs = 248                                               # narrower than na * no
+    assert L.adayolo_detloss_fwd(ctypes.byref(a), None) == -2
+    lay.cs = 256
+    a.no = 84                                                  # no != nc + 5
+    assert L.adayolo_detloss_fwd(ctypes.byref(a), None) == -1
+    a.no = 85
+    lay.n = 3                                                  # matches announced, no arrays
+    assert L.adayolo_detloss_fwd(ctypes.byref(a), None) == -1
+    lay.n = 0
+    assert L.adayolo_detloss_bwd(ctypes.byref(a), None) == -1  # no upstream gradient
+    a.grad_loss = p
+    assert L.adayolo_detloss_bwd(ctypes.byref(a), None) == -2  # no gradient map
+    lay.grad, lay.grad_cs = p, 252                             # not a multiple of 8
+    assert L.adayolo_detloss_bwd(ctypes.byref(a), None) == -2

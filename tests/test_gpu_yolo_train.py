@@ -127,3 +127,96 @@ def test_backward_to_image_vs_fp32_autograd(B, H, W):
     eng.forward_train(x)
     with pytest.raises(RuntimeError):
         sum(r.sum() for r in stale).backward()
+
+
+def _labels(B, g, dup=False):
+    """Per-image [n,6] labels (image, class, x, y, w, h) with 0..4 boxes; `dup`: two boxes of different classes on the same
+    spot (the same cells / anchors are matched twice: last-match-wins objectness target, summed gradients)."""
+    out = []
+    for b in range(B):
+        n = int(torch.randint(0, 5, (1,), generator=g))
+        t = torch.zeros(n, 6)
+        t[:, 1] = torch.randint(0, 80, (n,), generator=g).float()
+        t[:, 2:4] = torch.rand(n, 2, generator=g) * 0.8 + 0.1
+        t[:, 4:6] = torch.rand(n, 2, generator=g) * 0.5 + 0.04
+        if dup and n:
+            extra = t[:1].clone()
+            extra[:, 1] = (extra[:, 1] + 7) % 80
+            extra[:, 4:6] *= 1.05
+            t = torch.cat([t, extra], 0)
+        out.append(t)
+    if all(t.shape[0] == 0 for t in out):
+        out[0] = torch.tensor([[0, 3, 0.5, 0.5, 0.3, 0.4]])
+    return out
+
+
+@pytest.mark.parametrize("B,H,W,dup", [(2, 64, 96, False), (3, 96, 96, True), (8, 512, 512, True)])
+def test_fused_detection_loss_matches_the_pytorch_loss(B, H, W, dup):
+    """csrc/yolo_loss.hip (one forward launch, two backward launches on the bf16 head maps) against
+    loss.batched_per_sample_loss — the PyTorch restatement of ComputeLossBatch that tests/test_yolo_cpu.py pins on the
+    reference's own numbers (detloss.npz) — on the SAME engine: loss values to 2e-5, the head-map gradients element by
+    element (both round to bf16: equal up to one bf16 ulp of rounding ties), the image gradient, bit-reproducible."""
+    from _synth import synth_yolo_state_dict, test_image
+    from adaptiveisp_amd.yolo import YoloTrainEngine, yolov3
+    from adaptiveisp_amd.yolo.loss import DetectionLoss, assign_labels, batched_per_sample_loss, default_hyp, pack_assigned
+    det = yolov3()
+    det.load_state_dict(synth_yolo_state_dict(det, seed=2))
+    det = det.to(DEV).train()
+    for m in det.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.eval()
+    for p in det.parameters():
+        p.requires_grad_(False)
+    eng = YoloTrainEngine(det, B, H, W, device=DEV)
+    loss_fn = DetectionLoss(det.model[-1].anchors, nc=80, hyp=default_hyp(80, max(H, W)), device=DEV)
+    g = torch.Generator().manual_seed(B * 1000 + H)
+    labels = _labels(B, g, dup)
+    x = torch.from_numpy(test_image(B, H, W, seed=17, special=False)).to(DEV)
+    wgt = (torch.rand(B, 1, generator=g) + 0.5).to(DEV)                     # upstream gradient of the per-image losses
+
+    # PyTorch loss on fp32 copies of the engine's raw maps, evaluated on the CPU: a cell matched twice gets its objectness
+    # target from a sequential index assignment there (the last match wins — what the kernels implement); on the GPU
+    # torch's index_put_ leaves the winner undefined
+    cpu_fn = DetectionLoss(det.model[-1].anchors.cpu(), nc=80, hyp=default_hyp(80, max(H, W)), device="cpu")
+    raws = [r.cpu().requires_grad_(True) for r in eng.forward_train(x)]
+    assigned = assign_labels(cpu_fn, raws, labels)
+    l_ref = batched_per_sample_loss(cpu_fn, raws, labels, assigned)
+    (l_ref * wgt.cpu()).sum().backward()
+    g_maps_ref = [r.grad.to(DEV) for r in raws]
+    g_img_ref = eng.backward_image(g_maps_ref).clone()
+    l_ref = l_ref.detach().to(DEV)
+
+    # fused path
+    packed = pack_assigned(assign_labels(loss_fn, eng.head_shapes(), labels))
+    for (idx, box), m in zip(packed, assigned):
+        assert idx.shape[0] == m["b"].shape[0] and idx.dtype == torch.int32 and box.shape[1] == 6 and idx.is_cuda
+    with torch.no_grad():
+        l_ng = eng.per_sample_loss(loss_fn, x, packed)
+    xh = x.clone().requires_grad_(True)
+    l_hip = eng.per_sample_loss(loss_fn, xh, packed)
+    assert torch.equal(l_hip.detach(), l_ng)                                 # bit-reproducible, with or without autograd
+    torch.testing.assert_close(l_hip.detach(), l_ref, rtol=2e-5, atol=1e-6)
+    (l_hip * wgt).sum().backward()
+    torch.cuda.synchronize()
+    # head-map gradients as the kernels left them in the engine's bf16 buffers
+    worst = 0.0
+    for gv, v, gref in zip(eng._graw, eng.raw, g_maps_ref):
+        got = gv.buf[..., : eng.na * eng.no].float().view(B, v.H, v.W, eng.na, eng.no).permute(0, 3, 1, 2, 4)
+        want = gref.to(torch.bfloat16).float()                               # what backward_image feeds the detector's backward
+        assert (gv.buf[..., eng.na * eng.no:] == 0).all()
+        scale = want.abs().max().item()
+        err = (got - want).abs().max().item()
+        worst = max(worst, err / max(scale, 1e-30))
+        # one bf16 ulp (2^-8 relative) of each element, plus the fp32 summation-order noise of the per-image means
+        assert ((got - want).abs() <= want.abs() * 2 ** -7 + 1e-6 * scale).all(), (err, scale)
+    rel = ((xh.grad - g_img_ref).norm() / g_img_ref.norm()).item()
+    assert rel < 2e-2, (rel, worst)
+    if dup:                                                                  # the duplicate-cell paths were exercised
+        per_layer = [[tuple(r) for r in idx[:, :4].cpu().tolist()] for idx, _ in packed]
+        assert any(len(k) != len(set(k)) for k in per_layer)
+    # stale backward fails loudly here too
+    xs = x.clone().requires_grad_(True)
+    stale = eng.per_sample_loss(loss_fn, xs, packed)
+    eng.forward_train(x)
+    with pytest.raises(RuntimeError):
+        stale.sum().backward()

@@ -81,3 +81,28 @@ def test_batched_per_sample_loss_equals_the_loop(golden):
     other = [torch.randn(p.shape, generator=gen) for p in preds4]
     for pr in (preds4, other):
         assert torch.equal(batched_per_sample_loss(crit, pr, labels4, shared), batched_per_sample_loss(crit, pr, labels4))
+
+
+def test_pack_assigned_layout():
+    """The form in which the target assignment reaches csrc/yolo_loss.hip: idx int32 [n,5] = (image, anchor, gj, gi,
+    class), box fp32 [n,6] = (tx, ty, tw, th, anchor_w, anchor_h), one pair per head layer, rows in assignment order."""
+    from adaptiveisp_amd.yolo import yolov3
+    from adaptiveisp_amd.yolo.loss import DetectionLoss, assign_labels, default_hyp, pack_assigned
+    det = yolov3()
+    loss_fn = DetectionLoss(det.model[-1].anchors, nc=80, hyp=default_hyp(80, 128))
+    import types
+    shapes = [types.SimpleNamespace(shape=(2, 3, 16 // k, 16 // k, 85), device=torch.device("cpu")) for k in (1, 2, 4)]
+    labels = [torch.tensor([[0, 5, 0.5, 0.5, 0.3, 0.4], [0, 9, 0.2, 0.7, 0.1, 0.2]]), torch.zeros(0, 6)]
+    assigned = assign_labels(loss_fn, shapes, labels)
+    packed = pack_assigned(assigned)
+    assert len(packed) == 3
+    for (idx, box), m, sh in zip(packed, assigned, shapes):
+        n = m["b"].shape[0]
+        assert idx.shape == (n, 5) and idx.dtype == torch.int32 and box.shape == (n, 6) and box.dtype == torch.float32
+        assert idx.is_contiguous() and box.is_contiguous()
+        if n:
+            assert torch.equal(idx[:, 0].long(), m["b"]) and torch.equal(idx[:, 4].long(), m["cls"])
+            assert (idx[:, 0] == 0).all()                      # image 1 has no labels
+            assert (idx[:, 2] < sh.shape[2]).all() and (idx[:, 3] < sh.shape[3]).all() and (idx[:, 1] < 3).all()
+            assert torch.equal(box[:, :4], m["box"]) and torch.equal(box[:, 4:], m["anchors"])
+    assert sum(p[0].shape[0] for p in packed) > 0
