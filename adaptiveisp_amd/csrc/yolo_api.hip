@@ -239,12 +239,13 @@ int adayolo_nms(const float* boxes_xyxy, int n, float iou_thres, int max_det, vo
 }
 
 static int detloss_check(const adayolo_loss_args* a, bool bwd) {
-    if (!a || a->nl < 1 || a->nl > 4 || a->B < 1 || a->B > 65535 || a->na < 1 || a->nc < 1 || a->no != a->nc + 5 || !a->loss)
+    if (!a || a->nl < 1 || a->nl > 4 || a->B < 1 || a->B > 65535 || a->na < 1 || a->nc < 1 || a->no != a->nc + 5 || !a->loss || !a->ticket)
         return ADAYOLO_EINVAL;
     if (bwd && !a->grad_loss) return ADAYOLO_EINVAL;
+    if (a->nc > 128) return ADAYOLO_ESHAPE;                                       // two classes per lane in the per-match pass
     for (int i = 0; i < a->nl; ++i) {
         const adayolo_loss_layer& L = a->layer[i];
-        if (!L.raw || !L.tobj || !L.cnt || L.n < 0 || (L.n > 0 && (!L.idx || !L.box || !L.iou))) return ADAYOLO_EINVAL;
+        if (!L.raw || !L.tobj || !L.cnt || !L.part || L.n < 0 || (L.n > 0 && (!L.idx || !L.box))) return ADAYOLO_EINVAL;
         if (L.ny < 1 || L.nx < 1 || L.cs < a->na * a->no) return ADAYOLO_ESHAPE;
         if (bwd && (!L.grad || L.grad_cs % 8 || L.grad_cs < a->na * a->no)) return ADAYOLO_ESHAPE;
     }

@@ -9,9 +9,10 @@
 // (build_targets, loss.py:320-380) depends on the labels and the map SHAPES only and stays with the caller; what it
 // yields per layer — (image, anchor, gj, gi, class) and (target box, anchor size) per match — is this file's input.
 //
-// One workgroup per image walks the three layers: matches of its image (CIoU, class BCE; per-match CIoU kept), the
-// objectness targets (a cell matched more than once keeps the LAST match's value, as a sequential index assignment
-// does), then the dense objectness BCE. Every sum is a fixed-order tree: the loss is bit-reproducible. The backward
+// One workgroup per image and layer: the image's matches, one per wave (lanes split the 80 classes and share the scans
+// of the match list: CIoU, class BCE), the objectness targets (a cell matched more than once keeps the LAST match's
+// value, as a sequential index assignment does), then the dense objectness BCE; the last workgroup of an image adds the
+// layers. Every sum is a fixed-order tree: the loss is bit-reproducible. The backward
 // pass is two launches: a dense one that writes the WHOLE gradient map (zeros + the objectness channel) and a
 // per-match one that recomputes CIoU with its analytic gradient and adds the box / class terms (duplicates of a cell
 // are summed in match order by the first of them). The maps are the detector's own bf16 NHWC buffers — no fp32
@@ -116,65 +117,100 @@ __device__ __forceinline__ void load_box_logits(const unsigned short* cell, floa
 #pragma unroll
     for (int k = 0; k < 4; ++k) lg[k] = bf(cell[k]);
 }
+__device__ __forceinline__ float wave_sum(float v) {                    // fixed xor tree: every lane gets the sum
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
 
+// The matches of a layer are walked one per WAVE (wave w of the workgroup takes matches w, w + 4, ...): the lanes share
+// the scans over the match list (is a later / an earlier match on the same cell?) and split the classes. The list of
+// (image, anchor, gj, gi, class) rows is staged in LDS when it fits (kMaxStage rows), otherwise read from memory.
+constexpr int kMaxStage = 2048;
+struct IdxList {
+    const int* g;                 // [n][5] in memory
+    const int* s;                 // LDS copy or nullptr
+    __device__ __forceinline__ const int* row(int j) const { return (s ? s : g) + 5 * j; }
+};
+__device__ __forceinline__ bool same_cell(const int* p, const int* q) {
+    return p[0] == q[0] && p[1] == q[1] && p[2] == q[2] && p[3] == q[3];
+}
+// any j2 in [lo, hi) on the same cell as `id`? (wave-cooperative, wave-uniform result)
+__device__ __forceinline__ bool any_same(const IdxList& L, const int* id, int lo, int hi, int lane) {
+    bool hit = false;
+    for (int j2 = lo + lane; j2 < hi; j2 += 64) hit |= same_cell(L.row(j2), id);
+    return __ballot(hit) != 0ull;
+}
+
+// grid (B, nl): one workgroup per image and layer; the last of an image's workgroups adds the layers up (fixed order)
 __global__ __launch_bounds__(kThreads) void k_detloss_fwd(const adayolo_loss_args a) {
     __shared__ float red[kThreads / 64];
-    const int b = blockIdx.x, tid = threadIdx.x;
-    float lbox = 0.0f, lobj = 0.0f, lcls = 0.0f;
-    for (int i = 0; i < a.nl; ++i) {
-        const adayolo_loss_layer L = a.layer[i];
-        const int plane = L.ny * L.nx, cells = a.na * plane;
-        float* tobj = L.tobj + (long)b * cells;
-        const unsigned short* raw = static_cast<const unsigned short*>(L.raw) + (long)b * plane * L.cs;
-        for (int c = tid; c < cells; c += kThreads) tobj[c] = 0.0f;
-        float sbox = 0.0f, scls = 0.0f, cnt = 0.0f;
-        for (int j = tid; j < L.n; j += kThreads) {
-            const int* id = L.idx + 5 * j;
-            if (id[0] != b) continue;
-            const float* bx = L.box + 6 * j;
-            const unsigned short* cell = raw + ((long)id[2] * L.nx + id[3]) * L.cs + id[1] * a.no;
-            float lg[4];
-            load_box_logits(cell, lg);
-            const Match m = ciou_match<false>(lg, bx[4], bx[5], bx[0], bx[1], bx[2], bx[3]);
-            L.iou[j] = m.ciou;
-            sbox += 1.0f - m.ciou;
-            if (a.nc > 1) {
-                float s = 0.0f;
-                for (int c = 0; c < a.nc; ++c) s += bce(bf(cell[5 + c]), c == id[4] ? a.cp : a.cn, a.cls_pw);
-                scls += s;
-            }
-            cnt += 1.0f;
-        }
-        __syncthreads();                                    // tobj zeroed, per-match CIoU written (workgroup scope)
-        for (int j = tid; j < L.n; j += kThreads) {
-            const int* id = L.idx + 5 * j;
-            if (id[0] != b) continue;
-            bool last = true;                               // a later match of the same cell overwrites this one
-            for (int j2 = j + 1; j2 < L.n; ++j2) {
-                const int* id2 = L.idx + 5 * j2;
-                if (id2[0] == b && id2[1] == id[1] && id2[2] == id[2] && id2[3] == id[3]) { last = false; break; }
-            }
-            if (last) tobj[(id[1] * L.ny + id[2]) * L.nx + id[3]] = fmaxf(L.iou[j], 0.0f);
-        }
-        __syncthreads();
-        float sobj = 0.0f;
-        for (int c = tid; c < cells; c += kThreads) {
-            const int an = c / plane, p = c - an * plane;
-            sobj += bce(bf(raw[(long)p * L.cs + an * a.no + 4]), tobj[c], a.obj_pw);
-        }
-        sbox = block_sum(sbox, red);
-        scls = block_sum(scls, red);
-        cnt = block_sum(cnt, red);
-        sobj = block_sum(sobj, red);
-        if (cnt > 0.0f) {
-            lbox += sbox / cnt;
-            lcls += scls / cnt / (float)a.nc;
-        }
-        lobj += sobj / (float)cells * L.balance;
-        if (tid == 0) L.cnt[b] = cnt;
-        __syncthreads();
+    __shared__ int sidx[5 * kMaxStage];
+    __shared__ int ticket;
+    const int b = blockIdx.x, i = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const adayolo_loss_layer L = a.layer[i];
+    const int plane = L.ny * L.nx, cells = a.na * plane;
+    float* tobj = L.tobj + (long)b * cells;
+    const unsigned short* raw = static_cast<const unsigned short*>(L.raw) + (long)b * plane * L.cs;
+    IdxList idx{L.idx, nullptr};
+    if (L.n <= kMaxStage) {
+        for (int t = tid; t < 5 * L.n; t += kThreads) sidx[t] = L.idx[t];
+        idx.s = sidx;
     }
-    if (tid == 0) a.loss[b] = lbox * a.hyp_box + lobj * a.hyp_obj + lcls * a.hyp_cls;
+    for (int c = tid; c < cells; c += kThreads) tobj[c] = 0.0f;
+    __syncthreads();                                        // list staged, objectness targets zeroed (workgroup scope)
+    float sbox = 0.0f, scls = 0.0f, cnt = 0.0f;             // lane 0 of each wave accumulates its wave's matches in order
+    for (int j = wave; j < L.n; j += kThreads / 64) {
+        const int* id = idx.row(j);
+        if (id[0] != b) continue;                           // wave-uniform
+        const float* bx = L.box + 6 * j;
+        const unsigned short* cell = raw + ((long)id[2] * L.nx + id[3]) * L.cs + id[1] * a.no;
+        float lg[4];
+        load_box_logits(cell, lg);
+        const Match m = ciou_match<false>(lg, bx[4], bx[5], bx[0], bx[1], bx[2], bx[3]);
+        float s = 0.0f;
+        if (a.nc > 1)
+            for (int c = lane; c < a.nc; c += 64) s += bce(bf(cell[5 + c]), c == id[4] ? a.cp : a.cn, a.cls_pw);
+        s = wave_sum(s);
+        // a later match of the same cell overwrites this one's objectness target (sequential index assignment)
+        const bool last = !any_same(idx, id, j + 1, L.n, lane);
+        if (lane == 0) {
+            sbox += 1.0f - m.ciou;
+            scls += s;
+            cnt += 1.0f;
+            if (last) tobj[(id[1] * L.ny + id[2]) * L.nx + id[3]] = fmaxf(m.ciou, 0.0f);
+        }
+    }
+    __syncthreads();
+    float sobj = 0.0f;
+    for (int c = tid; c < cells; c += kThreads) {
+        const int an = c / plane, p = c - an * plane;
+        sobj += bce(bf(raw[(long)p * L.cs + an * a.no + 4]), tobj[c], a.obj_pw);
+    }
+    sbox = block_sum(sbox, red);
+    scls = block_sum(scls, red);
+    cnt = block_sum(cnt, red);
+    sobj = block_sum(sobj, red);
+    if (tid == 0) {
+        L.cnt[b] = cnt;
+        float* part = L.part + 3 * b;                       // (lbox, lobj, lcls) of this image in this layer
+        part[0] = cnt > 0.0f ? sbox / cnt : 0.0f;
+        part[1] = sobj / (float)cells * L.balance;
+        part[2] = cnt > 0.0f ? scls / cnt / (float)a.nc : 0.0f;
+        __threadfence();
+        ticket = atomicAdd(a.ticket + b, 1);
+    }
+    __syncthreads();
+    if (ticket == a.nl - 1 && tid == 0) {                   // every layer of this image is in: add them in layer order
+        __threadfence();
+        float lbox = 0.0f, lobj = 0.0f, lcls = 0.0f;
+        for (int l = 0; l < a.nl; ++l) {
+            const volatile float* part = a.layer[l].part + 3 * b;
+            lbox += part[0]; lobj += part[1]; lcls += part[2];
+        }
+        a.loss[b] = lbox * a.hyp_box + lobj * a.hyp_obj + lcls * a.hyp_cls;
+        a.ticket[b] = 0;                                    // ready for the next call on this stream
+    }
 }
 
 // dense part of the backward pass: every 16-byte chunk of the gradient maps (zeros, and the objectness channel of each anchor)
@@ -206,56 +242,53 @@ __global__ __launch_bounds__(kThreads) void k_detloss_bwd_dense(const adayolo_lo
 
 // per-match part: box and class terms of the matched cells; the first match of a cell sums all matches of that cell
 __global__ __launch_bounds__(kThreads) void k_detloss_bwd_match(const adayolo_loss_args a) {
+    __shared__ int sidx[5 * kMaxStage];
     const adayolo_loss_layer L = a.layer[blockIdx.y];
-    const int b = blockIdx.x, tid = threadIdx.x;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float cnt = L.cnt[b];
     if (cnt <= 0.0f) return;
+    IdxList idx{L.idx, nullptr};
+    if (L.n <= kMaxStage) {
+        for (int t = tid; t < 5 * L.n; t += kThreads) sidx[t] = L.idx[t];
+        idx.s = sidx;
+    }
+    __syncthreads();
     const int plane = L.ny * L.nx;
     const unsigned short* raw = static_cast<const unsigned short*>(L.raw) + (long)b * plane * L.cs;
     unsigned short* grad = static_cast<unsigned short*>(L.grad) + (long)b * plane * L.grad_cs;
     const float gbox = -a.grad_loss[b] * a.hyp_box / cnt;                // d (1 - ciou)
     const float gcls = a.grad_loss[b] * a.hyp_cls / cnt / (float)a.nc;
-    for (int j = tid; j < L.n; j += kThreads) {
-        const int* id = L.idx + 5 * j;
-        if (id[0] != b) continue;
-        bool first = true;
-        for (int j2 = 0; j2 < j; ++j2) {
-            const int* id2 = L.idx + 5 * j2;
-            if (id2[0] == b && id2[1] == id[1] && id2[2] == id[2] && id2[3] == id[3]) { first = false; break; }
-        }
-        if (!first) continue;
+    for (int j = wave; j < L.n; j += kThreads / 64) {
+        const int* id = idx.row(j);
+        if (id[0] != b) continue;                                       // wave-uniform
+        if (any_same(idx, id, 0, j, lane)) continue;                    // an earlier match of this cell does the work
         const long off = ((long)id[2] * L.nx + id[3]);
         const unsigned short* cell = raw + off * L.cs + id[1] * a.no;
         unsigned short* gcell = grad + off * L.grad_cs + id[1] * a.no;
         float lg[4], gb[4] = {0.0f, 0.0f, 0.0f, 0.0f};
         load_box_logits(cell, lg);
-        int members = 0;
-        for (int j2 = j; j2 < L.n; ++j2) {                              // the cell's matches in match order
-            const int* id2 = L.idx + 5 * j2;
-            if (!(id2[0] == b && id2[1] == id[1] && id2[2] == id[2] && id2[3] == id[3])) continue;
-            const float* bx = L.box + 6 * j2;
-            const Match m = ciou_match<true>(lg, bx[4], bx[5], bx[0], bx[1], bx[2], bx[3]);
+        const float x0 = lane < a.nc ? bf(cell[5 + lane]) : 0.0f, x1 = lane + 64 < a.nc ? bf(cell[5 + lane + 64]) : 0.0f;
+        float g0 = 0.0f, g1 = 0.0f;
+        for (int base = j; base < L.n; base += 64) {                    // the cell's matches in match order
+            const int j2 = base + lane;
+            unsigned long long mask = __ballot(j2 < L.n && same_cell(idx.row(j2 < L.n ? j2 : j), id));
+            while (mask) {
+                const int k = __ffsll((long long)mask) - 1;
+                mask &= mask - 1;
+                const int jm = base + k;
+                const float* bx = L.box + 6 * jm;
+                const Match m = ciou_match<true>(lg, bx[4], bx[5], bx[0], bx[1], bx[2], bx[3]);
 #pragma unroll
-            for (int k = 0; k < 4; ++k) gb[k] += gbox * m.g[k];
-            ++members;
-        }
-#pragma unroll
-        for (int k = 0; k < 4; ++k) gcell[k] = to_bf(gb[k]);
-        if (a.nc > 1) {
-            for (int c = 0; c < a.nc; ++c) {
-                const float x = bf(cell[5 + c]);
-                float g = 0.0f;
-                if (members == 1) {
-                    g = gcls * bce_grad(x, c == id[4] ? a.cp : a.cn, a.cls_pw);
-                } else {
-                    for (int j2 = j; j2 < L.n; ++j2) {
-                        const int* id2 = L.idx + 5 * j2;
-                        if (id2[0] == b && id2[1] == id[1] && id2[2] == id[2] && id2[3] == id[3])
-                            g += gcls * bce_grad(x, c == id2[4] ? a.cp : a.cn, a.cls_pw);
-                    }
-                }
-                gcell[5 + c] = to_bf(g);
+                for (int q = 0; q < 4; ++q) gb[q] += gbox * m.g[q];
+                const int cls = idx.row(jm)[4];
+                g0 += gcls * bce_grad(x0, lane == cls ? a.cp : a.cn, a.cls_pw);
+                g1 += gcls * bce_grad(x1, lane + 64 == cls ? a.cp : a.cn, a.cls_pw);
             }
+        }
+        if (lane < 4) gcell[lane] = to_bf(lane == 0 ? gb[0] : lane == 1 ? gb[1] : lane == 2 ? gb[2] : gb[3]);
+        if (a.nc > 1) {
+            if (lane < a.nc) gcell[5 + lane] = to_bf(g0);
+            if (lane + 64 < a.nc) gcell[5 + lane + 64] = to_bf(g1);
         }
     }
 }
@@ -263,7 +296,7 @@ __global__ __launch_bounds__(kThreads) void k_detloss_bwd_match(const adayolo_lo
 }  // namespace dl
 
 hipError_t launch_detloss_fwd(const adayolo_loss_args& a, hipStream_t s) {
-    hipLaunchKernelGGL(dl::k_detloss_fwd, dim3(a.B), dim3(dl::kThreads), 0, s, a);
+    hipLaunchKernelGGL(dl::k_detloss_fwd, dim3(a.B, a.nl), dim3(dl::kThreads), 0, s, a);
     return hipGetLastError();
 }
 

@@ -107,4 +107,4 @@ def synced_step(models, optimizers, buckets, max_grad_norm=1e-5):
         torch.nn.utils.clip_grad_norm_(m.parameters(), max_grad_norm)
     for o in optimizers:
         o.step()
-        o.zero_grad(set_to_none=False)
+        o.zero_grad(set_to_none=True)       # (the reference's default too: the next backward writes the gradients instead of adding to zeros)

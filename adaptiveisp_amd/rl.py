@@ -54,11 +54,11 @@ def train_iteration(cfg, agent, value, detector, loss_fn, imgs, z, states, label
     from . import dist as adist
     from .yolo.loss import batched_per_sample_loss as per_sample_loss
     (retouch, new_states, surrogate, penalty), _, _ = agent((imgs, z, states), progress)
-    from .yolo.loss import assign_labels, pack_assigned
+    from .yolo.loss import assign_labels, assign_labels_packed
     if getattr(detector, "per_sample_loss", None) is not None and os.environ.get("ADAYOLO_FUSED_LOSS", "1") == "1":
         # HIP training engine: detector forward + one loss launch on its bf16 head maps (csrc/yolo_loss.hip), no fp32 copies
         with torch.no_grad():
-            packed = pack_assigned(assign_labels(loss_fn, detector.head_shapes(), labels))
+            packed = assign_labels_packed(loss_fn, detector.head_shapes(), labels, imgs.device)   # host-side build_targets
             l_in = detector.per_sample_loss(loss_fn, imgs, packed)
         l_re = detector.per_sample_loss(loss_fn, retouch, packed)
     else:

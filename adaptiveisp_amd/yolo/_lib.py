@@ -22,7 +22,7 @@ class AdayoloError(RuntimeError):
 class LossLayer(ctypes.Structure):                 # adayolo_loss_layer (include/adayolo.h)
     _fields_ = [("raw", ctypes.c_void_p), ("cs", ctypes.c_int), ("ny", ctypes.c_int), ("nx", ctypes.c_int),
                 ("balance", ctypes.c_float), ("idx", ctypes.c_void_p), ("box", ctypes.c_void_p), ("n", ctypes.c_int),
-                ("iou", ctypes.c_void_p), ("tobj", ctypes.c_void_p), ("cnt", ctypes.c_void_p),
+                ("part", ctypes.c_void_p), ("tobj", ctypes.c_void_p), ("cnt", ctypes.c_void_p),
                 ("grad", ctypes.c_void_p), ("grad_cs", ctypes.c_int)]
 
 
@@ -30,7 +30,8 @@ class LossArgs(ctypes.Structure):                  # adayolo_loss_args
     _fields_ = [("layer", LossLayer * 4), ("nl", ctypes.c_int), ("B", ctypes.c_int), ("na", ctypes.c_int),
                 ("nc", ctypes.c_int), ("no", ctypes.c_int), ("hyp_box", ctypes.c_float), ("hyp_obj", ctypes.c_float),
                 ("hyp_cls", ctypes.c_float), ("cp", ctypes.c_float), ("cn", ctypes.c_float), ("cls_pw", ctypes.c_float),
-                ("obj_pw", ctypes.c_float), ("loss", ctypes.c_void_p), ("grad_loss", ctypes.c_void_p)]
+                ("obj_pw", ctypes.c_float), ("loss", ctypes.c_void_p), ("ticket", ctypes.c_void_p),
+                ("grad_loss", ctypes.c_void_p)]
 
 
 def load():

@@ -147,6 +147,55 @@ def pack_assigned(assigned):
     return packed
 
 
+def assign_labels_packed(loss_fn, shapes, labels, device):
+    """`pack_assigned(assign_labels(...))` computed on the HOST in numpy (the labels are a handful of host rows; as
+    device-side PyTorch the assignment is ~200 launches and several synchronising boolean gathers, 2 ms per training
+    iteration) and moved to `device` in one copy per array. Same float32 arithmetic, same row order as
+    DetectionLoss.assign (build_targets, yolov3/utils/loss.py:320-380); tests/test_yolo_cpu.py checks equality."""
+    import numpy as np
+    f32 = np.float32
+    rows = []
+    for b, lb in enumerate(labels):
+        t = np.array(torch.as_tensor(lb).detach().cpu().numpy(), dtype=f32).reshape(-1, 6)
+        t[:, 0] = b
+        rows.append(t)
+    targets = np.concatenate(rows, 0) if rows else np.zeros((0, 6), f32)
+    anc = getattr(loss_fn, "_anchors_host", None)
+    if anc is None:
+        anc = loss_fn._anchors_host = loss_fn.anchors.detach().float().cpu().numpy()
+    na, nt = loss_fn.na, targets.shape[0]
+    ai = np.repeat(np.arange(na, dtype=f32)[:, None], nt, 1)
+    tgt = np.concatenate((np.repeat(targets[None], na, 0), ai[..., None]), 2)                 # [na, nt, 7]
+    off = np.array([[0, 0], [1, 0], [0, 1], [-1, 0], [0, -1]], f32) * f32(0.5)
+    thr = f32(loss_fn.hyp["anchor_t"])
+    packed = []
+    for i in range(loss_fn.nl):
+        ny, nx = int(shapes[i].shape[2]), int(shapes[i].shape[3])
+        gain = np.array([1, 1, nx, ny, nx, ny, 1], f32)
+        t = tgt * gain
+        if nt:
+            ratio = t[..., 4:6] / anc[i][:, None]
+            t = t[np.maximum(ratio, f32(1) / ratio).max(2) < thr]
+            gxy = t[:, 2:4]
+            gxi = gain[[2, 3]] - gxy
+            j, k = ((gxy % f32(1) < f32(0.5)) & (gxy > f32(1))).T
+            l, m = ((gxi % f32(1) < f32(0.5)) & (gxi > f32(1))).T
+            sel = np.stack((np.ones_like(j), j, k, l, m))
+            t = np.repeat(t[None], 5, 0)[sel]
+            offsets = (np.zeros_like(gxy)[None] + off[:, None])[sel]
+        else:
+            t, offsets = tgt[0], f32(0)
+        gxy, gwh = t[:, 2:4], t[:, 4:6]
+        a = t[:, 6].astype(np.int64)
+        gij = (gxy - offsets).astype(np.int64)
+        idx = np.stack((t[:, 0].astype(np.int64), a, np.clip(gij[:, 1], 0, ny - 1), np.clip(gij[:, 0], 0, nx - 1),
+                        t[:, 1].astype(np.int64)), 1).astype(np.int32)
+        box = np.concatenate((gxy - gij.astype(f32), gwh, anc[i][a]), 1).astype(f32)
+        packed.append((torch.from_numpy(np.ascontiguousarray(idx)).to(device, non_blocking=True),
+                       torch.from_numpy(np.ascontiguousarray(box)).to(device, non_blocking=True)))
+    return packed
+
+
 def batched_per_sample_loss(loss_fn, preds, labels, assigned=None):
     """The same [B,1] per-image losses as `per_sample_loss` in ONE batched pass (the reference loops over the samples
     in Python, train.py:184-196: 2*B loss evaluations of ~150 tiny launches each per iteration). Every reduction the

@@ -176,14 +176,65 @@ class YoloTrainEngine(YoloEngine):
             if rc != 0:
                 _lib.check(rc, f"adayolo {kind}")
 
+    # ---- launch sequences as hipGraphs --------------------------------------------------------------------------
+    # A training iteration is ~450 detector launches (2 forwards of 75 convs + 72 SiLU kernels, one backward of ~150) next
+    # to ~1000 small PyTorch launches, and it is the HOST that is saturated (tools/train_trace.sh: GPU busy 43 % of an
+    # iteration): the two fixed launch sequences are captured once each (static image / image-gradient buffers, the
+    # engine's own activation and gradient buffers) and replayed. ADAYOLO_TRAIN_GRAPH=0 launches them one by one.
+    def _graph(self, which):
+        import os
+        if os.environ.get("ADAYOLO_TRAIN_GRAPH", "1") != "1" or torch.cuda.is_current_stream_capturing():
+            return None
+        sig = tuple(args[16] for kind, _, args in self.tfwd + self.tbwd if kind == "conv")    # re-capture after autotune
+        st = getattr(self, "_graphs", None)
+        if st is None or st["sig"] != sig:
+            st = self._graphs = dict(sig=sig, fwd=None, bwd=None,
+                                     img=torch.empty((self.B, 3, self.H, self.W), dtype=torch.float32, device=self.dev),
+                                     grad_img=torch.empty((self.B, 3, self.H, self.W), dtype=torch.float32, device=self.dev))
+        if st["fwd"] is None:
+            # both sequences at the first forward: the warm-up launches then run on buffers nobody has filled yet
+            with torch.cuda.device(self.dev):
+                torch.cuda.synchronize()
+                side = torch.cuda.Stream()
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):             # warm-up outside the capture (lazy kernel attributes)
+                    self._run(self.tfwd, img=st["img"])
+                    self._run(self.tbwd, grad_img=st["grad_img"])
+                torch.cuda.current_stream().wait_stream(side)
+                for key, plan, kw in (("fwd", self.tfwd, dict(img=st["img"])), ("bwd", self.tbwd, dict(grad_img=st["grad_img"]))):
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g):
+                        self._run(plan, **kw)
+                    st[key] = g
+        return st
+
+    def _forward_raw(self, img):
+        """The forward launch sequence: the raw head maps land in self.raw (bf16, the engine's buffers)."""
+        st = self._graph("fwd")
+        with torch.cuda.device(self.dev):
+            if st is None:
+                self._run(self.tfwd, img=img)
+            else:
+                st["img"].copy_(img)
+                st["fwd"].replay()
+        self._gen += 1
+
+    def _backward_raw(self):
+        """The backward launch sequence from the head-gradient buffers (self._graw) -> d loss / d img."""
+        st = self._graph("bwd")
+        with torch.cuda.device(self.dev):
+            if st is None:
+                grad_img = torch.empty((self.B, 3, self.H, self.W), dtype=torch.float32, device=self.dev)
+                self._run(self.tbwd, grad_img=grad_img)
+                return grad_img
+            st["bwd"].replay()
+            return st["grad_img"].clone()
+
     def forward_train(self, img):
         """img planar fp32 [B,3,H,W] on the device -> the three raw head maps [B,na,ny,nx,no] fp32."""
         if img.shape != (self.B, 3, self.H, self.W) or img.dtype != torch.float32 or img.device != self.dev:
             raise ValueError(f"expected fp32 {(self.B, 3, self.H, self.W)} on {self.dev}")
-        img = img.contiguous()
-        with torch.cuda.device(self.dev):
-            self._run(self.tfwd, img=img)
-        self._gen += 1
+        self._forward_raw(img.contiguous())
         return self.raw_maps()
 
     def backward_image(self, grads):
@@ -193,10 +244,7 @@ class YoloTrainEngine(YoloEngine):
             t.zero_()
             if g is not None:
                 t[..., : self.na * self.no] = g.permute(0, 2, 3, 1, 4).reshape(self.B, v.H, v.W, self.na * self.no).to(torch.bfloat16)
-        grad_img = torch.empty((self.B, 3, self.H, self.W), dtype=torch.float32, device=self.dev)
-        with torch.cuda.device(self.dev):
-            self._run(self.tbwd, grad_img=grad_img)
-        return grad_img
+        return self._backward_raw()
 
     # ---- fused per-image detection loss on the raw maps (csrc/yolo_loss.hip) -----------------------------------
     def head_shapes(self):
@@ -211,20 +259,21 @@ class YoloTrainEngine(YoloEngine):
         if ws is None:
             ws = self._loss_ws = dict(
                 tobj=[torch.empty((self.B, self.na, v.H, v.W), dtype=torch.float32, device=dev) for v in self.raw],
-                cnt=[torch.empty((self.B,), dtype=torch.float32, device=dev) for _ in self.raw], iou=[None] * nl)
+                cnt=[torch.empty((self.B,), dtype=torch.float32, device=dev) for _ in self.raw],
+                part=[torch.empty((self.B, 3), dtype=torch.float32, device=dev) for _ in self.raw],
+                ticket=torch.zeros((self.B,), dtype=torch.int32, device=dev))
         a = _lib.LossArgs()
         keep = []
         for i, (v, gv, (idx, box)) in enumerate(zip(self.raw, self._graw, packed)):
             n = int(idx.shape[0])
-            if ws["iou"][i] is None or ws["iou"][i].numel() < max(n, 1):
-                ws["iou"][i] = torch.empty((max(n, 256),), dtype=torch.float32, device=dev)
             L = a.layer[i]
             L.raw, L.cs, L.ny, L.nx, L.balance = v.ptr, v.cs, v.H, v.W, float(loss_fn.balance[i])
             L.idx, L.box, L.n = idx.data_ptr() if n else None, box.data_ptr() if n else None, n
-            L.iou, L.tobj, L.cnt = ws["iou"][i].data_ptr(), ws["tobj"][i].data_ptr(), ws["cnt"][i].data_ptr()
+            L.part, L.tobj, L.cnt = ws["part"][i].data_ptr(), ws["tobj"][i].data_ptr(), ws["cnt"][i].data_ptr()
             L.grad, L.grad_cs = gv.ptr, gv.cs
             keep += [idx, box]
         a.nl, a.B, a.na, a.nc, a.no = nl, self.B, self.na, loss_fn.nc, self.no
+        a.ticket = ws["ticket"].data_ptr()
         h = loss_fn.hyp
         a.hyp_box, a.hyp_obj, a.hyp_cls = float(h["box"]), float(h["obj"]), float(h["cls"])
         a.cp, a.cn, a.cls_pw, a.obj_pw = float(loss_fn.cp), float(loss_fn.cn), float(h["cls_pw"]), float(h["obj_pw"])
@@ -235,11 +284,9 @@ class YoloTrainEngine(YoloEngine):
             raise ValueError(f"expected fp32 {(self.B, 3, self.H, self.W)} on {self.dev}")
         if loss_fn.nc + 5 != self.no or len(packed) != len(self.raw) or loss_fn.hyp.get("fl_gamma", 0.0) != 0.0:
             raise ValueError("loss / detector mismatch (classes, layers) or focal loss requested: use the PyTorch loss")
-        img = img.contiguous()
         loss = torch.empty((self.B,), dtype=torch.float32, device=self.dev)
+        self._forward_raw(img.contiguous())
         with torch.cuda.device(self.dev):
-            self._run(self.tfwd, img=img)
-            self._gen += 1
             a, keep = self._loss_args(loss_fn, packed)
             a.loss = loss.data_ptr()
             _lib.check(self.L.adayolo_detloss_fwd(ctypes.byref(a), _lib.stream_ptr()), "adayolo_detloss_fwd")
@@ -275,14 +322,12 @@ class _DetectorLossFn(torch.autograd.Function):
             raise RuntimeError("YoloTrainEngine: backward after a newer forward overwrote the saved pre-activations "
                                "(one engine holds one set of buffers; use a second engine for interleaved graphs)")
         g = grad_loss.reshape(eng.B).float().contiguous()
-        grad_img = torch.empty((eng.B, 3, eng.H, eng.W), dtype=torch.float32, device=eng.dev)
         with torch.cuda.device(eng.dev):
             a, keep = eng._loss_args(ctx.loss_fn, ctx.packed)
             scratch = torch.empty((eng.B,), dtype=torch.float32, device=eng.dev)
             a.loss, a.grad_loss = scratch.data_ptr(), g.data_ptr()
             _lib.check(eng.L.adayolo_detloss_bwd(ctypes.byref(a), _lib.stream_ptr()), "adayolo_detloss_bwd")
-            eng._run(eng.tbwd, grad_img=grad_img)
-        return grad_img, None, None, None
+        return eng._backward_raw(), None, None, None
 
 
 class _DetectorFn(torch.autograd.Function):

@@ -178,14 +178,15 @@ int adayolo_nms(const float* boxes_xyxy, int n, float iou_thres, int max_det, vo
  *           + hyp_obj * sum_l balance_l * mean_{anchors x cells of b} BCE(obj, tobj),  tobj = clamp(CIoU, 0) at matched cells
  *   (a cell matched more than once keeps its LAST match's value, the result of a sequential index assignment).
  * raw: the detector's head map, NHWC bf16 [B][ny][nx][cs], channel = anchor * no + (x, y, w, h, obj, classes...).
- * Scratch per layer (device, caller-owned, written by _fwd and read by _bwd): iou fp32 [n], tobj fp32 [B][na][ny][nx],
- * cnt fp32 [B]. adayolo_detloss_bwd writes EVERY element of grad (NHWC bf16 [B][ny][nx][grad_cs], grad_cs % 8 == 0,
+ * Scratch (device, caller-owned, written by _fwd and read by _bwd) per layer: part fp32 [B][3], tobj fp32 [B][na][ny][nx],
+ * cnt fp32 [B]; per call: ticket int32 [B], ZERO before the first call (each call leaves it zero). nc <= 128.
+ * adayolo_detloss_bwd writes EVERY element of grad (NHWC bf16 [B][ny][nx][grad_cs], grad_cs % 8 == 0,
  * >= na*no; channels past na*no are zeroed): d (sum_b grad_loss[b] * loss[b]) / d raw. Both are bit-reproducible.
  */
 typedef struct adayolo_loss_layer {
     const void* raw; int cs; int ny, nx; float balance;
     const int32_t* idx; const float* box; int n;
-    float* iou; float* tobj; float* cnt;
+    float* part; float* tobj; float* cnt;
     void* grad; int grad_cs;
 } adayolo_loss_layer;
 typedef struct adayolo_loss_args {
@@ -193,6 +194,7 @@ typedef struct adayolo_loss_args {
     int nl, B, na, nc, no;
     float hyp_box, hyp_obj, hyp_cls, cp, cn, cls_pw, obj_pw;
     float* loss;                 /* [B] */
+    int32_t* ticket;             /* [B], see above */
     const float* grad_loss;      /* [B], _bwd only */
 } adayolo_loss_args;
 int adayolo_detloss_fwd(const adayolo_loss_args* args, void* stream);

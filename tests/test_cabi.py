@@ -72,17 +72,17 @@ def test_adayolo_argument_checks_without_gpu():
 
 def test_detloss_argument_checks_without_gpu():
     """adayolo_detloss_fwd / _bwd (include/adayolo.h) refuse malformed argument blocks before any launch, and the
-    ctypes mirror of the structs has the header's layout (88 / 416 bytes on LP64)."""
+    ctypes mirror of the structs has the header's layout (88 / 424 bytes on LP64)."""
     from adaptiveisp_amd.yolo import _lib
     L = _lib.load()
-    assert ctypes.sizeof(_lib.LossLayer) == 88 and ctypes.sizeof(_lib.LossArgs) == 416
+    assert ctypes.sizeof(_lib.LossLayer) == 88 and ctypes.sizeof(_lib.LossArgs) == 424
     assert L.adayolo_detloss_fwd(None, None) == -1
     buf = (ctypes.c_float * 64)()
     p = ctypes.cast(buf, ctypes.c_void_p).value
     a = _lib.LossArgs()
-    a.nl, a.B, a.na, a.nc, a.no, a.loss = 1, 1, 3, 80, 85, p
+    a.nl, a.B, a.na, a.nc, a.no, a.loss, a.ticket = 1, 1, 3, 80, 85, p, p
     lay = a.layer[0]
-    lay.raw, lay.cs, lay.ny, lay.nx, lay.tobj, lay.cnt, lay.n = p, 256, 2, 2, p, p, 0
+    lay.raw, lay.cs, lay.ny, lay.nx, lay.tobj, lay.cnt, lay.part, lay.n = p, 256, 2, 2, p, p, p, 0
     lay.cs = 248                                               # narrower than na * no
     assert L.adayolo_detloss_fwd(ctypes.byref(a), None) == -2
     lay.cs = 256
@@ -92,6 +92,9 @@ def test_detloss_argument_checks_without_gpu():
     lay.n = 3                                                  # matches announced, no arrays
     assert L.adayolo_detloss_fwd(ctypes.byref(a), None) == -1
     lay.n = 0
+    a.nc, a.no = 200, 205                                      # more than two classes per lane
+    assert L.adayolo_detloss_fwd(ctypes.byref(a), None) == -2
+    a.nc, a.no = 80, 85
     assert L.adayolo_detloss_bwd(ctypes.byref(a), None) == -1  # no upstream gradient
     a.grad_loss = p
     assert L.adayolo_detloss_bwd(ctypes.byref(a), None) == -2  # no gradient map

@@ -157,5 +157,8 @@ def test_train_iteration_at_the_config4_per_rank_shape():
     after = torch.cat([p.detach().reshape(-1) for p in tr.agent.parameters()])
     assert (after != before).any()
     assert tr.replay.images.shape[1:] == (3, 512, 512) and tr.replay.images.device.type == "cuda"
-    dead = [n for n, p in tr.agent.named_parameters() if p.grad is None]
-    assert dead and all("fc_mask" in n for n in dead)          # as in the reference: heads that never enter the loss
+    # as in the reference: Adam holds state for every parameter that enters the loss and for none of the fc_mask heads
+    # (gradients are released after the step — zero_grad(set_to_none=True) — so the optimizer state is what shows it)
+    dead = [n for n, p in tr.agent.named_parameters() if p not in tr.agent_optimizer.state]
+    assert dead and all("fc_mask" in n for n in dead)
+    assert all(p.grad is None for p in tr.agent.parameters())

@@ -3,6 +3,7 @@ import json
 import os
 
 import numpy as np
+import pytest
 import torch
 
 from _synth import synth_yolo_state_dict
@@ -106,3 +107,32 @@ def test_pack_assigned_layout():
             assert (idx[:, 2] < sh.shape[2]).all() and (idx[:, 3] < sh.shape[3]).all() and (idx[:, 1] < 3).all()
             assert torch.equal(box[:, :4], m["box"]) and torch.equal(box[:, 4:], m["anchors"])
     assert sum(p[0].shape[0] for p in packed) > 0
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2, 3])
+def test_host_target_assignment_equals_the_torch_one(seed):
+    """loss.assign_labels_packed (numpy, host) == pack_assigned(assign_labels(...)) (the torch restatement of
+    build_targets): same rows in the same order, bit for bit, including images without labels and no labels at all."""
+    import types
+    from adaptiveisp_amd.yolo import yolov3
+    from adaptiveisp_amd.yolo.loss import DetectionLoss, assign_labels, assign_labels_packed, default_hyp, pack_assigned
+    det = yolov3()
+    loss_fn = DetectionLoss(det.model[-1].anchors, nc=80, hyp=default_hyp(80, 512))
+    g = torch.Generator().manual_seed(seed)
+    B = 5
+    labels = []
+    for b in range(B):
+        n = 0 if (seed == 3 or b == 2) else int(torch.randint(0, 7, (1,), generator=g))
+        t = torch.zeros(n, 6)
+        t[:, 1] = torch.randint(0, 80, (n,), generator=g).float()
+        t[:, 2:4] = torch.rand(n, 2, generator=g)
+        t[:, 4:6] = torch.rand(n, 2, generator=g) * 0.6 + 0.01
+        labels.append(t)
+    shapes = [types.SimpleNamespace(shape=(B, 3, 512 // s, (512 + 64 * seed) // s, 85), device=torch.device("cpu")) for s in (8, 16, 32)]
+    want = pack_assigned(assign_labels(loss_fn, shapes, labels))
+    got = assign_labels_packed(loss_fn, shapes, labels, "cpu")
+    assert len(got) == len(want) == 3
+    for (gi, gb), (wi, wb) in zip(got, want):
+        assert gi.dtype == torch.int32 and gb.dtype == torch.float32
+        assert gi.shape == wi.shape and torch.equal(gi, wi)
+        assert gb.shape == wb.shape and torch.equal(gb, wb)

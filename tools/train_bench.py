@@ -17,6 +17,8 @@ iters = int(sys.argv[1]) if len(sys.argv) > 1 else 6
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 HW = int(sys.argv[3]) if len(sys.argv) > 3 else 512
 DEV = "cuda:0"
+if os.environ.get("CUDNN_BENCHMARK"):
+    torch.backends.cudnn.benchmark = os.environ["CUDNN_BENCHMARK"] == "1"
 torch.manual_seed(0); np.random.seed(0)
 det = yolov3().to(DEV).train()
 for m in det.modules():
@@ -24,7 +26,7 @@ for m in det.modules():
         m.eval()
 for p in det.parameters():
     p.requires_grad_(False)
-for name in ("hip", "torch"):
+for name in ([os.environ["TRAIN_BENCH_ONLY"]] if os.environ.get("TRAIN_BENCH_ONLY") else ["hip", "torch"]):
     agent = Agent(cfg, shape=(16, 64, 64), device=DEV).to(DEV)
     value = Value(cfg, shape=(19, 64, 64)).to(DEV)
     loss_fn = DetectionLoss(det.model[-1].anchors, nc=80, hyp=default_hyp(80, HW), device=DEV)

@@ -10,7 +10,7 @@ from adaptiveisp_amd.config import cfg
 from adaptiveisp_amd.rl import td_losses
 from adaptiveisp_amd.value import Value
 from adaptiveisp_amd.yolo import YoloTrainEngine, yolov3
-from adaptiveisp_amd.yolo.loss import DetectionLoss, default_hyp, batched_per_sample_loss as per_sample_loss
+from adaptiveisp_amd.yolo.loss import DetectionLoss, default_hyp, assign_labels_packed
 
 B, HW, DEV = 8, 512, "cuda:0"
 torch.manual_seed(0)
@@ -32,21 +32,19 @@ def tic():
 for it in range(4):
     t = tic(); (retouch, new_states, surrogate, penalty), _, _ = agent((imgs, z, states), 0.1); T["agent fwd"] = tic() - t
     t = tic()
-    with torch.no_grad():
-        p_in = eng(imgs)
-    T["detector fwd (input)"] = tic() - t
+    packed = assign_labels_packed(loss_fn, eng.head_shapes(), labels, DEV)
+    T["target assignment (host) + copy"] = tic() - t
     t = tic()
     with torch.no_grad():
-        l_in = per_sample_loss(loss_fn, p_in, labels)
-    T["per-sample loss (input)"] = tic() - t
-    t = tic(); p_re = eng(retouch); T["detector fwd (retouch)"] = tic() - t
-    t = tic(); l_re = per_sample_loss(loss_fn, p_re, labels); T["per-sample loss (retouch)"] = tic() - t
+        l_in = eng.per_sample_loss(loss_fn, imgs, packed)
+    T["detector fwd + fused loss (input)"] = tic() - t
+    t = tic(); l_re = eng.per_sample_loss(loss_fn, retouch, packed); T["detector fwd + fused loss (retouch)"] = tic() - t
     t = tic(); ov = value(imgs, states); nv = value(retouch, new_states); T["value x2"] = tic() - t
     t = tic()
     out = td_losses(cfg, l_in, l_re, penalty, surrogate, new_states, ov, nv, torch.mean(retouch, dim=(1, 2, 3)).unsqueeze(-1))
     T["td math"] = tic() - t
     t = tic(); out["value_loss"].backward(); T["value backward"] = tic() - t
-    t = tic(); out["agent_loss"].backward(); T["agent backward (loss graph + detector bwd + ISP param grads + heads)"] = tic() - t
+    t = tic(); out["agent_loss"].backward(); T["agent backward (loss bwd + detector bwd + ISP param grads + heads)"] = tic() - t
     agent.zero_grad(); value.zero_grad()
 for k, v in T.items():
     print(f"{v * 1e3:8.2f} ms  {k}")
