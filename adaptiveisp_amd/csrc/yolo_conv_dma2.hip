@@ -257,7 +257,7 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void k_conv_igemm_dma32(const C
             }
         }
     };
-    if (a.act == ADAYOLO_ACT_SILU) convert(std::true_type{});   // two copies: the activation is not a per-element select
+    if (a.act == ADAYOLO_ACT_SILU && !a.pre) convert(std::true_type{});   // two copies: the activation is not a per-element select
     else convert(std::false_type{});
     __syncthreads();
     constexpr int CPR = BN / 8;
@@ -268,6 +268,13 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void k_conv_igemm_dma32(const C
         const int m = m0 + ml, n = n0 + ch;
         if (m >= a.M || n >= a.Cout) continue;
         u32x4 v = *reinterpret_cast<const u32x4*>(Cs + ml * CP + ch);
+        if (a.pre) {                                          // training forward: keep the pre-activation, activate its bf16 value
+            *reinterpret_cast<u32x4*>(a.pre + (long)m * a.pre_cs + n) = v;
+            if (a.act == ADAYOLO_ACT_SILU) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = silu_bf16x2(v[j]);
+            }
+        }
         if (a.res) {
             const u32x4 r = *reinterpret_cast<const u32x4*>(a.res + (long)m * a.res_cs + n);
 #pragma unroll

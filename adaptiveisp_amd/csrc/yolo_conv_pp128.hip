@@ -286,8 +286,10 @@ __global__ __launch_bounds__(512) void k_conv_pp128(const ConvArgs a) {
     // ---- epilogue: wave-private LDS transpose (see yolo_conv_pp.hip), 32 px x 64 ch at a time, 128-byte row segments
     unsigned char* my = smem + wave * (64 * kEpiPitch);
     // see yolo_conv_pp.hip: compile-time activation / residual copies, bias and pointers hoisted, batched reads and stores
-    auto epilogue = [&](auto silu_tag, auto res_tag) {
-        constexpr bool kSilu = decltype(silu_tag)::value, kRes = decltype(res_tag)::value;
+    auto epilogue = [&](auto silu_tag, auto res_tag, auto keep_tag) {
+        // kKeep: the tile goes through LDS as the bf16 PRE-activation (kSilu off), is stored to a.pre, then activated
+        constexpr bool kKeep = decltype(keep_tag)::value, kAct = decltype(silu_tag)::value;
+        constexpr bool kSilu = kAct && !kKeep, kRes = decltype(res_tag)::value;
         typedef __attribute__((ext_vector_type(2))) float f32x2v;
         float4 bq[2][4];
 #pragma unroll
@@ -327,6 +329,16 @@ __global__ __launch_bounds__(512) void k_conv_pp128(const ConvArgs a) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // same wave wrote and reads: in-order LDS, no barrier
 #pragma unroll
             for (int it = 0; it < 4; ++it) v[it] = *reinterpret_cast<const u32x4*>(rd + (mi * 32 + it * 8) * kEpiPitch);
+            if (kKeep) {                                         // training forward: store the pre-activation, activate its bf16 value
+#pragma unroll
+                for (int it = 0; it < 4; ++it) {
+                    if (ok[it]) *reinterpret_cast<u32x4*>(a.pre + (long)(mrow + 8 * (4 * mi + it)) * a.pre_cs + n) = v[it];
+                    if (kAct) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) v[it][j] = silu_bf16x2(v[it][j]);
+                    }
+                }
+            }
             if (kRes) {
 #pragma unroll
                 for (int it = 0; it < 4; ++it)
@@ -342,12 +354,15 @@ __global__ __launch_bounds__(512) void k_conv_pp128(const ConvArgs a) {
                 if (ok[it]) __builtin_nontemporal_store(v[it], reinterpret_cast<u32x4*>(op + (4 * mi + it) * ostep));
         }
     };
-    if (a.act == ADAYOLO_ACT_SILU) {
-        if (a.res) epilogue(std::true_type{}, std::true_type{});
-        else epilogue(std::true_type{}, std::false_type{});
+    const std::false_type no{};
+    const std::true_type yes{};
+    if (a.pre) {
+        if (a.act == ADAYOLO_ACT_SILU) { if (a.res) epilogue(yes, yes, yes); else epilogue(yes, no, yes); }
+        else { if (a.res) epilogue(no, yes, yes); else epilogue(no, no, yes); }
+    } else if (a.act == ADAYOLO_ACT_SILU) {
+        if (a.res) epilogue(yes, yes, no); else epilogue(yes, no, no);
     } else {
-        if (a.res) epilogue(std::false_type{}, std::true_type{});
-        else epilogue(std::false_type{}, std::false_type{});
+        if (a.res) epilogue(no, yes, no); else epilogue(no, no, no);
     }
 }
 

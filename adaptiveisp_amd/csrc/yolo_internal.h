@@ -21,11 +21,21 @@ struct ConvArgs {
     // OUTPUT tile while it is in LDS (Bottleneck.cv1 of the next block); null = not fused
     const unsigned short* w2; const float* bias2;
     unsigned short* out2; int out2_cs;
+    // training forward (yolo_conv_dma2.hip / yolo_conv_pp128.hip): when set, the bf16 pre-activation (conv + bias) is stored
+    // here and the activation is applied to that ROUNDED value — bit for bit what adayolo_silu_fwd makes of it
+    unsigned short* pre; int pre_cs;
 };
 
 // Epilogue math on channel pairs: packed fp32 (v_pk_add/mul_f32 do two channels per issue slot; the two transcendentals
 // stay per element) — the conv epilogues are VALU-bound on exactly this (128 SiLUs per lane in the 256x256 kernel).
 typedef float f32x2_pk __attribute__((ext_vector_type(2)));
+// eight bf16 values of an epilogue row: silu of each, rounded back to bf16 (the training forward's second output)
+__device__ __forceinline__ f32x2_pk silu_pk(f32x2_pk x);
+__device__ __forceinline__ unsigned silu_bf16x2(unsigned v) {
+    typedef __bf16 bf16x2_pk __attribute__((ext_vector_type(2)));
+    const f32x2_pk y = silu_pk(f32x2_pk{__uint_as_float(v << 16), __uint_as_float(v & 0xFFFF0000u)});
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(y, bf16x2_pk));
+}
 __device__ __forceinline__ f32x2_pk silu_pk(f32x2_pk x) {
     const f32x2_pk u = x * -1.44269504088896341f;
     f32x2_pk e = {__builtin_amdgcn_exp2f(u.x), __builtin_amdgcn_exp2f(u.y)};

@@ -176,6 +176,39 @@ class YoloTrainEngine(YoloEngine):
             if rc != 0:
                 _lib.check(rc, f"adayolo {kind}")
 
+    KEEP_VARIANTS = (5, 22, 26, 27, 60)            # kernels whose epilogue stores the pre-activation beside the activation
+
+    def _forward_plan(self):
+        """tfwd with every [conv -> pre-activation, SiLU(+residual)] pair whose tuned kernel can do both in one launch
+        (adayolo_conv_keep_fwd, bit-identical to the pair) replaced by that launch; rebuilt when autotune changed a variant."""
+        import os
+        sig = tuple(args[16] for kind, _, args in self.tfwd if kind == "conv")
+        cached = getattr(self, "_tfwd_fused", None)
+        if cached is not None and cached[0] == sig:
+            return cached[1]
+        plan, i = [], 0
+        fuse = os.environ.get("ADAYOLO_TRAIN_KEEP", "1") == "1"
+        while i < len(self.tfwd):
+            e = self.tfwd[i]
+            nxt = self.tfwd[i + 1] if i + 1 < len(self.tfwd) else None
+            if (fuse and e[0] == "conv" and nxt is not None and nxt[0] == "silu" and e[2][16] in self.KEEP_VARIANTS
+                    and e[2][6].value == nxt[2][0].value):        # the conv's output IS the SiLU kernel's pre-activation
+                a, sl = e[2], nxt[2]
+                # conv args: in, in_cs, w, b, res(None), 0, out(=P), out_cs, B, H, W, Cin, Cout, k, s, act(NONE), variant
+                # silu args: pre, pre_cs, res, res_cs, out, out_cs, npix, C
+                args = (a[0], a[1], a[2], a[3], sl[2], sl[3], sl[4], sl[5], a[6], a[7], a[8], a[9], a[10], a[11], a[12], a[13],
+                        a[14], _lib.ACT_SILU, a[16])
+                rc = self.L.adayolo_conv_keep_fwd(*args, _lib.stream_ptr())   # probe once: ESHAPE = this kernel does not serve the shape
+                if rc == 0:
+                    plan.append(("convkeep", self.L.adayolo_conv_keep_fwd, args))
+                    i += 2
+                    continue
+            plan.append(e)
+            i += 1
+        self._tfwd_fused = (sig, plan)
+        self.keep_fused = sum(1 for e in plan if e[0] == "convkeep")
+        return plan
+
     # ---- launch sequences as hipGraphs --------------------------------------------------------------------------
     # A training iteration is ~450 detector launches (2 forwards of 75 convs + 72 SiLU kernels, one backward of ~150) next
     # to ~1000 small PyTorch launches, and it is the HOST that is saturated (tools/train_trace.sh: GPU busy 43 % of an
@@ -198,10 +231,10 @@ class YoloTrainEngine(YoloEngine):
                 side = torch.cuda.Stream()
                 side.wait_stream(torch.cuda.current_stream())
                 with torch.cuda.stream(side):             # warm-up outside the capture (lazy kernel attributes)
-                    self._run(self.tfwd, img=st["img"])
+                    self._run(self._forward_plan(), img=st["img"])
                     self._run(self.tbwd, grad_img=st["grad_img"])
                 torch.cuda.current_stream().wait_stream(side)
-                for key, plan, kw in (("fwd", self.tfwd, dict(img=st["img"])), ("bwd", self.tbwd, dict(grad_img=st["grad_img"]))):
+                for key, plan, kw in (("fwd", self._forward_plan(), dict(img=st["img"])), ("bwd", self.tbwd, dict(grad_img=st["grad_img"]))):
                     g = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(g):
                         self._run(plan, **kw)
@@ -213,7 +246,7 @@ class YoloTrainEngine(YoloEngine):
         st = self._graph("fwd")
         with torch.cuda.device(self.dev):
             if st is None:
-                self._run(self.tfwd, img=img)
+                self._run(self._forward_plan(), img=img)
             else:
                 st["img"].copy_(img)
                 st["fwd"].replay()

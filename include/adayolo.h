@@ -115,6 +115,17 @@ int adayolo_stem_down_fwd(const float* img, const float* w_stem, const float* b_
                           float pad_value, const void* w_next, const float* b_next, void* out_next, int out_next_cstride,
                           void* stream);
 
+/*
+ * Training forward of `Conv` (common.py:45-59) in ONE launch: pre = bf16(conv + bias) is stored (the backward needs
+ * silu'(pre)), out = act(pre) (+ residual) is computed from that ROUNDED value — exactly adayolo_conv_fwd_variant with
+ * ADAYOLO_ACT_NONE into `pre` followed by adayolo_silu_fwd(pre, residual, out), bit for bit. Served by the kernels whose
+ * epilogue has the second output: variants 5 / 22 / 26 / 27 and 60 (EINVAL for any other; ESHAPE when the named kernel
+ * does not take the shape — the caller then keeps the two launches).
+ */
+int adayolo_conv_keep_fwd(const void* in, int in_cstride, const void* weight, const float* bias, const void* residual,
+                          int res_cstride, void* out, int out_cstride, void* pre, int pre_cstride, int B, int H, int W, int Cin,
+                          int Cout, int ksize, int stride, int act, int variant, void* stream);
+
 /* adayolo_stem_fwd with the activation selectable (ADAYOLO_ACT_NONE keeps the pre-activation for training). */
 int adayolo_stem_fwd_act(const float* img, const float* weight, const float* bias, void* out, int out_cstride,
                          int B, int H, int W, int Hp, int pad_top, float pad_value, int Cout, int act, void* stream);

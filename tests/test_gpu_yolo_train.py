@@ -220,3 +220,42 @@ def test_fused_detection_loss_matches_the_pytorch_loss(B, H, W, dup):
     eng.forward_train(x)
     with pytest.raises(RuntimeError):
         stale.sum().backward()
+
+
+@pytest.mark.parametrize("variant", [5, 22, 26, 27, 60])
+def test_conv_keep_fwd_equals_conv_then_silu(variant):
+    """adayolo_conv_keep_fwd (one launch: pre-activation stored, activation applied to its bf16 value, residual added) ==
+    adayolo_conv_fwd_variant(ACT_NONE) into `pre` + adayolo_silu_fwd, bit for bit, on every shape the kernel serves."""
+    from adaptiveisp_amd.yolo import _lib
+    L = _lib.load()
+    st = _lib.stream_ptr()
+    served = 0
+    for (B, H, W, cin, cout, k, s, use_res, act) in [(2, 16, 16, 512, 1024, 3, 1, True, 1), (8, 64, 64, 128, 256, 3, 1, False, 1),
+                                                    (3, 33, 17, 256, 128, 1, 1, True, 1), (2, 32, 32, 256, 512, 3, 2, False, 1),
+                                                    (1, 9, 7, 128, 128, 3, 1, True, 0), (2, 40, 24, 64, 128, 1, 1, False, 1)]:
+        g = torch.Generator().manual_seed(H * 7 + cin)
+        x = torch.randn(B, H, W, cin, generator=g).to(torch.bfloat16).to(DEV)
+        w = (torch.randn(cout, k, k, cin, generator=g) / (k * k * cin) ** 0.5).to(torch.bfloat16).to(DEV)
+        b = torch.randn(cout, generator=g).to(DEV)
+        Ho, Wo = (H - 1) // s + 1, (W - 1) // s + 1
+        res = torch.randn(B, Ho, Wo, cout, generator=g).to(torch.bfloat16).to(DEV) if use_res else None
+        nan = lambda: torch.full((B, Ho, Wo, cout), float("nan"), dtype=torch.bfloat16, device=DEV)  # noqa: E731
+        pre1, out1, pre2, out2 = nan(), nan(), nan(), nan()
+        rc = L.adayolo_conv_keep_fwd(_p(x), cin, _p(w), _p(b), _p(res) if use_res else None, cout if use_res else 0, _p(out1), cout,
+                                     _p(pre1), cout, B, H, W, cin, cout, k, s, act, variant, st)
+        if rc == -2:                                    # this kernel does not take the shape: the engine keeps two launches
+            continue
+        assert rc == 0, (rc, variant)
+        assert L.adayolo_conv_fwd_variant(_p(x), cin, _p(w), _p(b), None, 0, _p(pre2), cout, B, H, W, cin, cout, k, s, 0, variant, st) == 0
+        if act:
+            assert L.adayolo_silu_fwd(_p(pre2), cout, _p(res) if use_res else None, cout if use_res else 0, _p(out2), cout,
+                                      B * Ho * Wo, cout, st) == 0
+        else:
+            out2 = pre2 if not use_res else (pre2.float() + res.float()).to(torch.bfloat16)
+        torch.cuda.synchronize()
+        assert torch.equal(pre1.view(torch.int16), pre2.view(torch.int16)), (variant, B, H, W, cin, cout)
+        assert torch.equal(out1.view(torch.int16), out2.view(torch.int16)), (variant, B, H, W, cin, cout)
+        served += 1
+    assert served >= 3, (variant, served)
+    # not a kernel with the second output
+    assert L.adayolo_conv_keep_fwd(_p(x), cin, _p(w), _p(b), None, 0, _p(out1), cout, _p(pre1), cout, B, H, W, cin, cout, k, s, 1, 50, st) == -1
