@@ -12,6 +12,11 @@
 //      weight registers are loaded once; activation fragments are gathered from the stem patch (stride-2 pixel walk)
 //   D  bias + SiLU + bf16, transposed through LDS, 128 contiguous bytes per pixel
 //   E  (optional) the following 1x1 conv (Bottleneck.cv1, 64 -> 32) + SiLU from the output tile while it is in LDS
+// Per-workgroup timeline (tools/stem_down_stamps.py, four workgroups per CU): loads + image patch 12.7k, stem conv + SiLU 12.4k,
+// second conv 5.0k, its SiLU + tile 2.5k, stores 1.1k, 1x1 stage 2.4k of 39k cycles = 9.75k cycles per tile and CU, which is
+// its VALU issue time (~2000 issue slots per wave and tile: 120 SiLUs per lane are 780 of them, the stem conv's operand
+// assembly ~320, patch index math ~240): a persistent form that requests the next tile's patch under phase B was measured
+// SLOWER (340 vs 282 us; tools/experiments/stem_down_persistent.patch).
 // Numerics: the same roundings as the two separate kernels (image and stem output rounded to bf16, fp32 accumulation).
 #include "yolo_internal.h"
 
@@ -42,6 +47,14 @@ constexpr int kImgBytes = ((3 * IH * IW * 2 + 15) / 16) * 16;   // the image pat
 constexpr int kPatchBytes = NSP * 64;                // 32 ch bf16 per stem pixel; the 128 px x 128 B output tile overlays it
 constexpr int kSmem = kImgBytes + kPatchBytes;
 
+#ifdef ADAYOLO_MEASURE
+__device__ unsigned long long g_sd_stamp[4096 * 12];      // per-workgroup phase stamps (measurement build, tools/stem_down_stamps.py)
+#define SD_STAMP(k) do { if (threadIdx.x == 0) { const int wg_ = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x; \
+        if (wg_ % 3 == 0 && wg_ / 3 < 4096) g_sd_stamp[(wg_ / 3) * 12 + (k)] = __builtin_readcyclecounter(); } } while (0)
+#else
+#define SD_STAMP(k) do { } while (0)
+#endif
+
 __global__ __launch_bounds__(256, 4) void k_stem_down(const float* __restrict__ img, const float* __restrict__ w0,
                                                    const float* __restrict__ b0, const unsigned short* __restrict__ w1,
                                                    const float* __restrict__ b1, unsigned short* __restrict__ out,
@@ -56,6 +69,7 @@ __global__ __launch_bounds__(256, 4) void k_stem_down(const float* __restrict__ 
     const int b = blockIdx.z, ox0 = blockIdx.x * TX, oy0 = blockIdx.y * TY;
     const int Ho = Hp >> 1, Wo = W >> 1;
     const int fy0 = 2 * oy0 - 1, fx0 = 2 * ox0 - 1;              // frame coordinates of stem-patch pixel (0, 0)
+    SD_STAMP(0);
 
     // ---- second-conv weights of this wave's 32 channels: 18 k-steps x 16 B per lane, issued first (L2 hits)
     const int chf = wave & 1, pxh = wave >> 1;
@@ -120,7 +134,9 @@ __global__ __launch_bounds__(256, 4) void k_stem_down(const float* __restrict__ 
     float bv[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) bv[i] = b0[8 * g + i];
+    SD_STAMP(1);
     __syncthreads();
+    SD_STAMP(2);
 
     // ---- B: stem conv on the patch, 16 pixels per step
     for (int grp = wave; grp < (NSP + 15) / 16; grp += 4) {
@@ -147,7 +163,9 @@ __global__ __launch_bounds__(256, 4) void k_stem_down(const float* __restrict__ 
         }
         if (P < NSP) *reinterpret_cast<u32x4*>(patch + P * 64 + ((g ^ ((P >> 1) & 3)) << 4)) = o;
     }
+    SD_STAMP(3);
     __syncthreads();
+    SD_STAMP(4);
 
     // ---- C: second conv from the patch. Wave: channel fragment chf (32 ch), pixel half pxh (4 output rows x 16)
     f32x16 acc[2];
@@ -172,7 +190,9 @@ __global__ __launch_bounds__(256, 4) void k_stem_down(const float* __restrict__ 
             acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wfr[j], af, acc[mi], 0, 0, 0);
         }
     }
+    SD_STAMP(5);
     __syncthreads();                                       // every wave is done with the patch: overlay the output tile
+    SD_STAMP(6);
 
     // ---- D: bias + SiLU + bf16 -> LDS [128 px][64 ch] (16-byte chunks swizzled by the pixel) -> 128-byte rows
 #pragma unroll
@@ -187,7 +207,9 @@ __global__ __launch_bounds__(256, 4) void k_stem_down(const float* __restrict__ 
             *reinterpret_cast<u32x2*>(patch + q * 128 + ((((cl >> 3)) ^ (q & 7)) << 4) + (cl & 4) * 2) = u32x2{lo, hi};
         }
     }
+    SD_STAMP(7);
     __syncthreads();
+    SD_STAMP(8);
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
         const int idx = it * 256 + tid, q = idx >> 3, chunk = idx & 7;
@@ -197,6 +219,7 @@ __global__ __launch_bounds__(256, 4) void k_stem_down(const float* __restrict__ 
             __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(out + (((long)b * Ho + oy) * Wo + ox) * out_cs + chunk * 8));
         }
     }
+    SD_STAMP(9);
     if (!w2) return;
 
     // ---- E (optional): the 1x1 conv that follows in yolov3.yaml (Bottleneck.cv1: 64 -> 32) + SiLU, straight from the
@@ -234,6 +257,7 @@ __global__ __launch_bounds__(256, 4) void k_stem_down(const float* __restrict__ 
             }
         }
     }
+    SD_STAMP(10);
 }
 
 }  // namespace sd
@@ -255,5 +279,11 @@ hipError_t launch_stem_down(const float* img, const float* w0, const float* b0, 
                        static_cast<const unsigned short*>(w2), b2, static_cast<unsigned short*>(out2), out2_cs);
     return hipGetLastError();
 }
+
+#ifdef ADAYOLO_MEASURE
+extern "C" int adayolo_debug_stem_down(unsigned long long* dst, int n) {       // measurement helper, not part of the ABI
+    return hipMemcpyFromSymbol(dst, HIP_SYMBOL(sd::g_sd_stamp), sizeof(unsigned long long) * n) == hipSuccess ? 0 : -1;
+}
+#endif
 
 }  // namespace adayolo
