@@ -19,6 +19,7 @@
 // SLOWER (340 vs 282 us; tools/experiments/stem_down_persistent.patch).
 // Numerics: the same roundings as the two separate kernels (image and stem output rounded to bf16, fp32 accumulation).
 #include "yolo_internal.h"
+#include <cstdlib>
 
 namespace adayolo {
 namespace sd {
@@ -274,7 +275,13 @@ hipError_t launch_stem_down(const float* img, const float* w0, const float* b0, 
     }
     const int Ho = Hp / 2, Wo = W / 2;
     dim3 grid((Wo + sd::TX - 1) / sd::TX, (Ho + sd::TY - 1) / sd::TY, B);
-    hipLaunchKernelGGL(sd::k_stem_down, grid, dim3(256), sd::kSmem, s, img, w0, b0, static_cast<const unsigned short*>(w1), b1,
+    int smem_bytes = sd::kSmem;
+#ifdef ADAYOLO_MEASURE
+    static const int extra = getenv("ADAYOLO_SD_EXTRA_SMEM") ? atoi(getenv("ADAYOLO_SD_EXTRA_SMEM")) : 0;   // > 1 KB: three workgroups per CU
+    smem_bytes += extra;
+    if (extra) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sd::k_stem_down), hipFuncAttributeMaxDynamicSharedMemorySize, smem_bytes);
+#endif
+    hipLaunchKernelGGL(sd::k_stem_down, grid, dim3(256), smem_bytes, s, img, w0, b0, static_cast<const unsigned short*>(w1), b1,
                        static_cast<unsigned short*>(out), out_cs, H, W, Hp, pad_top, pad_value,
                        static_cast<const unsigned short*>(w2), b2, static_cast<unsigned short*>(out2), out2_cs);
     return hipGetLastError();
