@@ -53,20 +53,30 @@ def build(force=False, verbose=True):
     built = []
     for lib, spec in LIBS.items():
         hdrs = [os.path.join(CSRC, h) for h in spec["headers"]]
+        # objects built with other flags (a measurement build: ADAYOLO_EXTRA_FLAGS=-DADAYOLO_MEASURE) are stale whatever their
+        # time stamps say: the flag line of the last build is kept beside them
+        flagfile = os.path.join(CSRC, "." + lib + ".flags")
+        flagline = " ".join([ARCH, *spec["flags"]])
+        if not os.path.exists(flagfile) or open(flagfile).read() != flagline:
+            force_lib = True
+        else:
+            force_lib = force
         jobs = []
         for s in spec["sources"]:
             src, obj = os.path.join(CSRC, s), os.path.join(CSRC, s.rsplit(".", 1)[0] + ".o")
-            if force or _stale(obj, [src, *hdrs]):
+            if force_lib or _stale(obj, [src, *hdrs]):
                 jobs.append((src, obj))
         with ThreadPoolExecutor(max_workers=min(6, max(1, len(jobs)))) as ex:
             list(ex.map(lambda j: _compile(hipcc, j[0], j[1], spec["flags"]), jobs))
         objs = [os.path.join(CSRC, s.rsplit(".", 1)[0] + ".o") for s in spec["sources"]]
         target = os.path.join(CSRC, lib)
-        if force or jobs or _stale(target, objs):
+        if force_lib or jobs or _stale(target, objs):
             r = subprocess.run([hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", target, *objs],
                                cwd=CSRC, capture_output=True, text=True)
             if r.returncode != 0:
                 raise RuntimeError(f"link failed for {lib}:\n{r.stdout}\n{r.stderr}")
+        with open(flagfile, "w") as f:
+            f.write(flagline)
         built.append(target)
         if verbose:
             print(f"[adaptiveisp_amd.build] {target} ({len(jobs)} object(s) rebuilt)")
