@@ -4,19 +4,24 @@
 // it makes the stem (170 us) and the first conv (240 us) HBM-bound at ~3 TB/s. Here it never leaves the CU: a
 // workgroup owns an 8 x 16 tile of the SECOND conv's output, computes the 17 x 33 stem pixels under it into LDS
 // (10 % of them are recomputed by a neighbour) and runs the 3x3 stride-2 conv from there.
-//   A  image patch 19 x 35 x 3 -> LDS as bf16 (letterbox value / zero padding resolved here, like k_stem)
-//   B  stem conv on the patch: K = 27 padded to 32 = one v_mfma_f32_16x16x32_bf16 step per 16 pixels and channel half
-//      (weights in registers, same row permutation as k_stem so that a lane owns 8 consecutive channels), bias + SiLU,
-//      bf16, 16-byte chunks XOR-swizzled by the pixel index; stem pixels outside the frame are the second conv's zero pad
+//   A  image patch 19 x 35 -> LDS as (R, G, B, 0) bf16 per pixel (letterbox value / zero padding resolved here, like k_stem)
+//   B  stem conv on the patch: per kernel row K = 3 columns x 4 = 12 (16 with the zero k-group) = one
+//      v_mfma_f32_16x16x16_bf16 per 16 pixels, channel half and kernel row — the operand is ONE aligned 8-byte LDS read, no
+//      gather / select / pack (weights in registers, same row permutation as k_stem: a lane owns 8 consecutive channels), bias + SiLU,
+//      bf16, 16-byte chunks XOR-swizzled by the pixel's column; stem pixels outside the frame are the second conv's zero pad
 //   C  second conv: K = 9 taps x 32 ch = 18 steps of v_mfma_f32_32x32x16_bf16; a wave owns 64 px x 32 ch, its 72
 //      weight registers are loaded once; activation fragments are gathered from the stem patch (stride-2 pixel walk)
 //   D  bias + SiLU + bf16, transposed through LDS, 128 contiguous bytes per pixel
 //   E  (optional) the following 1x1 conv (Bottleneck.cv1, 64 -> 32) + SiLU from the output tile while it is in LDS
-// Per-workgroup timeline (tools/stem_down_stamps.py, four workgroups per CU): loads + image patch 12.7k, stem conv + SiLU 12.4k,
-// second conv 5.0k, its SiLU + tile 2.5k, stores 1.1k, 1x1 stage 2.4k of 39k cycles = 9.75k cycles per tile and CU, which is
-// its VALU issue time (~2000 issue slots per wave and tile: 120 SiLUs per lane are 780 of them, the stem conv's operand
-// assembly ~320, patch index math ~240): a persistent form that requests the next tile's patch under phase B was measured
-// SLOWER (340 vs 282 us; tools/experiments/stem_down_persistent.patch).
+// The kernel is bound by VALU issue and needs its four workgroups per CU (278 / 300 / 340 us at 4 / 3 / 2). Round 2 took it
+// from 278 to 238 us on issue slots alone (tools/stem_down_stamps.py timeline before: loads + image patch 12.7k, stem conv +
+// SiLU 12.4k, second conv 5.0k, its SiLU + tile 2.5k, stores 1.1k, 1x1 stage 2.4k of 39k cycles per workgroup): the stem
+// conv's operand as one aligned 8-byte read per kernel row instead of eight 2-byte gathers + selects + packs (254 us), the
+// second conv's 36 fragment addresses as base registers + immediates (column-keyed swizzle, 248 us), every prologue load
+// unconditional — 18 stem weights behind a `g < 3 ?` had become six branch regions, each its own memory round trip (238 us).
+// What is left is 120 SiLUs per lane (8 per 16-pixel group of phase B are 36 of its ~76 VALU instructions + 16
+// transcendentals). A persistent form that requests the next tile's patch under phase B was measured SLOWER (340 vs 282 us;
+// tools/experiments/stem_down_persistent.patch).
 // Numerics: the same roundings as the two separate kernels (image and stem output rounded to bf16, fp32 accumulation).
 #include "yolo_internal.h"
 #include <cstdlib>
@@ -25,6 +30,7 @@ namespace adayolo {
 namespace sd {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
@@ -43,10 +49,17 @@ constexpr int TY = 8, TX = 16;                       // output tile of the secon
 constexpr int SH = 2 * TY + 1, SW = 2 * TX + 1;      // stem pixels under it: 17 x 33
 constexpr int IH = SH + 2, IW = SW + 2;              // image pixels under those: 19 x 35
 constexpr int NSP = SH * SW;                         // 561
-constexpr int kImgBytes = ((3 * IH * IW * 2 + 15) / 16) * 16;   // the image patch as bf16 (what the stem's MFMA consumes): with fp32 the
-                                                                  // workgroup is 43.9 KB and only three fit a CU; 39.9 KB: four
-constexpr int kPatchBytes = NSP * 64;                // 32 ch bf16 per stem pixel; the 128 px x 128 B output tile overlays it
-constexpr int kSmem = kImgBytes + kPatchBytes;
+// LDS: the stem patch (32 ch bf16 per stem pixel; the 128 px x 128 B output tile later overlays it) and the image patch as
+// [y][x][4] bf16 (R, G, B, 0: one aligned 8-byte read = the three channels of a pixel = one kernel column of the stem's
+// MFMA operand). The image patch ALIASES the stem pixels 512 .. 560: those are written by the last round of phase B
+// (groups 32 .. 35, behind a barrier), which reads image rows 15 .. 18 only, and their 3136 bytes end inside image row 11,
+// dead since group 24. 37.2 KB per workgroup: four per CU (the kernel needs them: 278 / 300 / 340 us at 4 / 3 / 2).
+constexpr int kPatchBytes = NSP * 64;
+constexpr int kImgOff = 512 * 64;                    // byte offset of the image patch = stem pixel 512
+constexpr int kImgBytes = IH * IW * 8;               // 5320
+constexpr int kSmem = kImgOff + kImgBytes + 8;
+static_assert(kImgOff + kImgBytes >= kPatchBytes, "the image patch must cover the tail of the stem patch it aliases");
+static_assert(kPatchBytes - kImgOff <= 11 * IW * 8 + 7 * 8 && (35 * 16 + 15) / SW >= 15, "aliased bytes must be dead image rows");
 
 #ifdef ADAYOLO_MEASURE
 __device__ unsigned long long g_sd_stamp[4096 * 12];      // per-workgroup phase stamps (measurement build, tools/stem_down_stamps.py)
@@ -63,8 +76,8 @@ __global__ __launch_bounds__(256, 4) void k_stem_down(const float* __restrict__ 
                                                    const unsigned short* __restrict__ w2, const float* __restrict__ b2,
                                                    unsigned short* __restrict__ out2, int out2_cs) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned short* tile = reinterpret_cast<unsigned short*>(smem);
-    unsigned char* patch = smem + kImgBytes;
+    unsigned char* patch = smem;
+    unsigned char* img4 = smem + kImgOff;                  // [IH][IW] x (R, G, B, 0) bf16
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int b = blockIdx.z, ox0 = blockIdx.x * TX, oy0 = blockIdx.y * TY;
@@ -84,53 +97,66 @@ __global__ __launch_bounds__(256, 4) void k_stem_down(const float* __restrict__ 
     // ---- A: image patch (frame rows fy0-1 .. , cols fx0-1 ..)
     const long plane = (long)H * W;
     const float* src = img + (long)b * 3 * plane;
-    // all 8 loads of a thread are issued before the first LDS write: clamped (always legal) addresses, pinned by an
-    // empty asm, then the letterbox value / zero padding by select (a select straight on the load is compiled into a
-    // branch around it and serialises eight memory round trips)
+    // a thread takes whole pixels (index math once per pixel, three plane loads each): all 9 loads of a thread are issued
+    // before the first LDS write — clamped (always legal) addresses, pinned by an empty asm, then the letterbox value /
+    // zero padding by select (a select straight on the load is compiled into a branch around it and serialises the
+    // memory round trips) — and a pixel goes to LDS as one 8-byte (R, G, B, 0) write
     {
-        constexpr int NI = (3 * IH * IW + 255) / 256;
-        float v[NI], m[NI], padc[NI];
+        constexpr int NPX = IH * IW, NI = (NPX + 255) / 256;
+        float v[NI][3], padc[NI];
+        bool inimg[NI];
 #pragma unroll
         for (int it = 0; it < NI; ++it) {
-            const int i = min(tid + 256 * it, 3 * IH * IW - 1);
-            const int c = i / (IH * IW), r = i - c * (IH * IW);
-            const int ly = r / IW, lx = r - ly * IW;
+            const int i = min(tid + 256 * it, NPX - 1);
+            const int ly = i / IW, lx = i - ly * IW;
             const int gy = fy0 - 1 + ly, gx = fx0 - 1 + lx;
             const int sy = gy - pad_top;
             const bool inframe = gy >= 0 && gy < Hp && gx >= 0 && gx < W;
-            const bool inimg = inframe && sy >= 0 && sy < H;
-            v[it] = src[c * plane + (long)min(max(sy, 0), H - 1) * W + min(max(gx, 0), W - 1)];
-            m[it] = inimg ? 1.0f : 0.0f;
-            padc[it] = (inframe && !inimg) ? pad_value : 0.0f;   // zero outside the letterboxed frame (the conv's padding)
-        }
+            inimg[it] = inframe && sy >= 0 && sy < H;
+            padc[it] = (inframe && !inimg[it]) ? pad_value : 0.0f;   // zero outside the letterboxed frame (the conv's padding)
+            const float* q = src + (long)min(max(sy, 0), H - 1) * W + min(max(gx, 0), W - 1);
 #pragma unroll
-        for (int it = 0; it < NI; ++it) asm volatile("" : "+v"(v[it]));      // the loads above stay unconditional
+            for (int c = 0; c < 3; ++c) v[it][c] = q[c * plane];
+        }
 #pragma unroll
         for (int it = 0; it < NI; ++it)
-            if (tid + 256 * it < 3 * IH * IW) tile[tid + 256 * it] = (unsigned short)(pack2(m[it] != 0.0f ? v[it] : padc[it], 0.0f) & 0xFFFFu);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) asm volatile("" : "+v"(v[it][c]));      // the loads above stay unconditional
+#pragma unroll
+        for (int it = 0; it < NI; ++it) {
+            const float r = inimg[it] ? v[it][0] : padc[it], gg = inimg[it] ? v[it][1] : padc[it], bb = inimg[it] ? v[it][2] : padc[it];
+            if (tid + 256 * it < NPX)
+                *reinterpret_cast<u32x2*>(img4 + (tid + 256 * it) * 8) = u32x2{pack2(r, gg), pack2(bb, 0.0f)};
+        }
     }
 
-    // ---- stem weights as two MFMA A fragments (rows permuted: row 4g+i of fragment t = channel 8g + 4t + i)
+    // ---- stem weights: per kernel row kh and channel half t one v_mfma_f32_16x16x16_bf16 operand (rows permuted: row
+    //      4g+i of fragment t = channel 8g + 4t + i); lane (row p, k-group g) holds k = 4g .. 4g+3 = kernel column kw = g,
+    //      channels (R, G, B, pad): zero for g = 3 and for the pad channel
     const int g = lane >> 4, p = lane & 15;
-    bf16x8 wf[2];
-    int off[8];
+    s16x4 wfk[3][2];
+    {
+        float h[3][2][3];                                  // all 18 loads unconditional and in flight together (see phase A)
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        const int k = 8 * g + e;
-        const int tap = k / 3, c = k - tap * 3, kh = tap / 3, kw = tap - kh * 3;
-        off[e] = (k < 27) ? (c * IH + kh) * IW + kw : 0;
-    }
+        for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
-        const int ch = 8 * (p >> 2) + 4 * t + (p & 3);
-        float h[8];
+            for (int t = 0; t < 2; ++t) {
+                const int ch = 8 * (p >> 2) + 4 * t + (p & 3);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const int k = 8 * g + e;
-            h[e] = (k < 27) ? w0[ch * 27 + k] : 0.0f;
-        }
-        const u32x4 pk = {pack2(h[0], h[1]), pack2(h[2], h[3]), pack2(h[4], h[5]), pack2(h[6], h[7])};
-        wf[t] = __builtin_bit_cast(bf16x8, pk);
+                for (int c = 0; c < 3; ++c) h[kh][t][c] = w0[ch * 27 + (kh * 3 + min(g, 2)) * 3 + c];
+            }
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    asm volatile("" : "+v"(h[kh][t][c]));
+                    h[kh][t][c] = g < 3 ? h[kh][t][c] : 0.0f;
+                }
+                const u32x2 pk = {pack2(h[kh][t][0], h[kh][t][1]), pack2(h[kh][t][2], 0.0f)};
+                wfk[kh][t] = __builtin_bit_cast(s16x4, pk);
+            }
     }
     float bv[8];
 #pragma unroll
@@ -139,20 +165,25 @@ __global__ __launch_bounds__(256, 4) void k_stem_down(const float* __restrict__ 
     __syncthreads();
     SD_STAMP(2);
 
-    // ---- B: stem conv on the patch, 16 pixels per step
+    // ---- B: stem conv on the patch, 16 pixels per step: per kernel row one aligned 8-byte read (pixel column kw = g; the
+    //      k-group g = 3 meets zero weights and re-reads column 2 so that it never sees foreign bits) and one MFMA per
+    //      channel half. The last round (groups 32 .. 35) writes the stem pixels the image patch aliases: barrier first.
+    const int gk = min(g, 2);
     for (int grp = wave; grp < (NSP + 15) / 16; grp += 4) {
+        if (grp >= 32) __syncthreads();                      // (uniform: every wave's ninth round)
         const int P = grp * 16 + p;
         const int Pc = P < NSP ? P : NSP - 1;
         const int sy = Pc / SW, sx = Pc - sy * SW;
-        const unsigned short* t0 = tile + sy * IW + sx;
-        unsigned a[8];
+        const unsigned char* t0 = img4 + (sy * IW + sx + gk) * 8;
+        s16x4 af[3];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) a[e] = (8 * g + e < 27) ? (unsigned)t0[off[e]] : 0u;
-        const u32x4 pk = {a[0] | (a[1] << 16), a[2] | (a[3] << 16), a[4] | (a[5] << 16), a[6] | (a[7] << 16)};
-        const bf16x8 af = __builtin_bit_cast(bf16x8, pk);
-        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-        const f32x4 d0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[0], af, z, 0, 0, 0);
-        const f32x4 d1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[1], af, z, 0, 0, 0);
+        for (int kh = 0; kh < 3; ++kh) af[kh] = *reinterpret_cast<const s16x4*>(t0 + kh * IW * 8);
+        f32x4 d0 = {0.f, 0.f, 0.f, 0.f}, d1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+            d0 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(wfk[kh][0], af[kh], d0, 0, 0, 0);
+            d1 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(wfk[kh][1], af[kh], d1, 0, 0, 0);
+        }
         const int fy = fy0 + sy, fx = fx0 + sx;
         const bool inside = fy >= 0 && fy < Hp && fx >= 0 && fx < W;       // else: the second conv's zero padding
         u32x4 o = {0u, 0u, 0u, 0u};
@@ -162,7 +193,7 @@ __global__ __launch_bounds__(256, 4) void k_stem_down(const float* __restrict__ 
             bias_act_pack4<true>(d1[0], d1[1], d1[2], d1[3], float4{bv[4], bv[5], bv[6], bv[7]}, o2, o3);
             o = u32x4{o0, o1, o2, o3};
         }
-        if (P < NSP) *reinterpret_cast<u32x4*>(patch + P * 64 + ((g ^ ((P >> 1) & 3)) << 4)) = o;
+        if (P < NSP) *reinterpret_cast<u32x4*>(patch + P * 64 + ((g ^ ((sx >> 1) & 3)) << 4)) = o;   // chunks keyed by the pixel's COLUMN
     }
     SD_STAMP(3);
     __syncthreads();
@@ -175,19 +206,26 @@ __global__ __launch_bounds__(256, 4) void k_stem_down(const float* __restrict__ 
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[mi][e] = 0.0f;
     const int fr = lane & 31, fq = lane >> 5;
-    int pbase[2];                                          // patch pixel index of tap (0,0) for this lane's two pixels
+    // The 16-byte chunks of a stem pixel are XOR-keyed by (its column >> 1) & 3: a tap's column is 2 ox + kw, so the key is
+    // ox & 3 for kw = 0, 1 and (ox + 1) & 3 for kw = 2 whatever the row — the 36 fragment addresses of a lane are eight
+    // base registers plus immediates (keyed by the linear pixel index they cost ~5 VALU instructions each, in a kernel
+    // that is bound by VALU issue).
+    const unsigned char* fbase[2][2][2];                   // [pixel mi][kw == 2][k half]
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi) {
         const int oyl = 4 * pxh + 2 * mi + (fr >> 4), oxl = fr & 15;
-        pbase[mi] = (2 * oyl) * SW + 2 * oxl;
+        const unsigned char* pb = patch + ((2 * oyl) * SW + 2 * oxl) * 64;
+#pragma unroll
+        for (int k2 = 0; k2 < 2; ++k2)
+#pragma unroll
+            for (int half = 0; half < 2; ++half) fbase[mi][k2][half] = pb + (((2 * half + fq) ^ ((oxl + k2) & 3)) << 4);
     }
 #pragma unroll
     for (int j = 0; j < 18; ++j) {
         const int tap = j >> 1, half = j & 1, kh = tap / 3, kw = tap - kh * 3;
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi) {
-            const int P = pbase[mi] + kh * SW + kw;
-            const bf16x8 af = *reinterpret_cast<const bf16x8*>(patch + P * 64 + (((2 * half + fq) ^ ((P >> 1) & 3)) << 4));
+            const bf16x8 af = *reinterpret_cast<const bf16x8*>(fbase[mi][kw == 2][half] + (kh * SW + kw) * 64);
             acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wfr[j], af, acc[mi], 0, 0, 0);
         }
     }
