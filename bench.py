@@ -10,8 +10,8 @@ N GPUs = N independent replicas (one process per GPU, no data-path collective): 
     python bench.py --gpus 1 --steps 20 --warmup 3
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-Prints ONE JSON line (rank 0). Extra objects: `roofline` (dominant kernel: the 128x128 implicit-GEMM conv,
-timed per launch with HIP events on the launch stream), `isp` (per-step ISP kernel times vs the HBM roof)
+Prints ONE JSON line (rank 0). Extra objects: `roofline` (dominant kernel: the 256x256 ping-pong implicit-GEMM conv,
+timed per launch with HIP events on the launch stream, inside the network), `isp` (per-step ISP kernel times vs the HBM roof)
 and `cpu_baseline` (the reference's op chain restated on torch-CPU + plain torch-CPU detector on a bounded sample,
 host cores of this box; 1 warm-up + 3 repeats, min/median).
 """
