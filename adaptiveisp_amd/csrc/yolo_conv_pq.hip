@@ -44,7 +44,8 @@ constexpr int BN = 128, BK = 32;
 constexpr int kRow = BK * 2;                  // 64 bytes per tile row
 constexpr int kEpiPitch = 144;                // bytes per pixel row of a wave's private epilogue region (64 ch + pad)
 // MI = 32-pixel fragments per wave: 4 -> 256 px tile (24 KB per k-tile, 72 KB ring), 2 -> 128 px tile (16 KB, 48 KB): the
-// small maps (8x23x40: 29 tiles of 256 px) get twice the workgroups
+// small maps (8x23x40: 29 tiles of 256 px) get twice the workgroups. (A 64 px tile — MI = 1, 82 registers, four workgroups
+// per CU — was measured and dropped: slower on every layer, 16 vs 13 us on 1024 -> 512 @ 8x23x40, four MFMAs per barrier.)
 template <int MI> struct Geo {
     static constexpr int BM = 64 * MI;
     static constexpr int kATile = BM * kRow;
