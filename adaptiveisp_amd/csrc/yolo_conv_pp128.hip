@@ -19,6 +19,11 @@
 //     stagger needs): issue -> read = 5 phases. A slot is re-staged at least one phase after its last read.
 //
 // Restrictions (the launcher falls back otherwise): Cin % 64 == 0, Cout % 128 == 0.
+// Measured and dropped (round 2, same outputs bit for bit): ONE phase per k-tile — all 16 fragments in one load section, 16
+// MFMAs per section, two barriers per k-tile instead of four, 190 registers — 71 vs 70 us on 512 -> 1024 @ 8x23x40; the same
+// with the six DMA pieces issued in the LOAD section so that the MFMA section is MFMAs only: 88 us (a piece costs the issuing
+// wave ~150 cycles there, four waves at once). The barriers are not what holds this kernel; the operand stream is
+// (profiles/round2_conv_pp_ablation.txt).
 #include "yolo_internal.h"
 #include <type_traits>
 
