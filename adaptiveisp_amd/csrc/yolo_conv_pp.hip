@@ -21,6 +21,9 @@
 //     load section (with the stagger, only then has every wave passed a barrier behind every other wave's wait).
 //
 // Restrictions (the launcher falls back otherwise): Cin % 64 == 0, Cout % 256 == 0.
+// Measured and dropped (round 2): channel chunk outer / tap inner k order, so that consecutive k-tiles ask for almost the same
+// activation lines (L1 hits instead of L2 fetches): 3-4 % SLOWER on every layer; a non-temporal / system-scope cache policy on
+// the weight DMA (so that weights do not push those lines out): no change.
 #include "yolo_internal.h"
 #include <type_traits>
 #include <cstdlib>
