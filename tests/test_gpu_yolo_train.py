@@ -259,3 +259,48 @@ def test_conv_keep_fwd_equals_conv_then_silu(variant):
     assert served >= 3, (variant, served)
     # not a kernel with the second output
     assert L.adayolo_conv_keep_fwd(_p(x), cin, _p(w), _p(b), None, 0, _p(out1), cout, _p(pre1), cout, B, H, W, cin, cout, k, s, 1, 50, st) == -1
+
+
+def test_graph_replay_and_fused_train_forward_change_nothing():
+    """The training engine at the config-4 per-rank shape with the tuning table: (a) launch sequences replayed from
+    hipGraphs, (b) conv + SiLU pairs of the forward replaced by adayolo_conv_keep_fwd where the tuned kernel has the
+    second output — against the same engine with both switched off: raw head maps and image gradient bit for bit."""
+    import os
+    from _synth import synth_yolo_state_dict, test_image
+    from adaptiveisp_amd.yolo import YoloTrainEngine, yolov3
+    cache = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "adaptiveisp_amd", "yolo", "tuning", "mi355x.json")
+    det = yolov3()
+    det.load_state_dict(synth_yolo_state_dict(det, seed=2))
+    det = det.to(DEV).train()
+    for p in det.parameters():
+        p.requires_grad_(False)
+    B, H, W = 8, 512, 512
+    x = torch.from_numpy(test_image(B, H, W, seed=5, special=False)).to(DEV)
+    g = torch.Generator().manual_seed(9)
+    results = []
+    for graph, keep in (("0", "0"), ("1", "1")):
+        os.environ["ADAYOLO_TRAIN_GRAPH"], os.environ["ADAYOLO_TRAIN_KEEP"] = graph, keep
+        try:
+            eng = YoloTrainEngine(det, B, H, W, device=DEV)
+            eng.autotune(cache=cache, write=False)
+            outs = []
+            for rep in range(2):                                        # second pass = a replay when graphs are on
+                xr = x.clone().requires_grad_(True)
+                raws = eng(xr)
+                if rep == 0:
+                    R = [torch.randn(r.shape, generator=torch.Generator().manual_seed(3 + i)).to(DEV) for i, r in enumerate(raws)]
+                sum((r * w).sum() for r, w in zip(raws, R)).backward()
+                torch.cuda.synchronize()
+                outs.append(([r.detach().clone() for r in raws], xr.grad.clone()))
+            assert all(torch.equal(a, b) for a, b in zip(outs[0][0], outs[1][0])) and torch.equal(outs[0][1], outs[1][1])
+            if keep == "1":
+                assert eng.keep_fused >= 20, eng.keep_fused              # most Conv layers of the forward are single launches
+                assert eng._graphs["fwd"] is not None and eng._graphs["bwd"] is not None
+            results.append(outs[1])
+        finally:
+            os.environ.pop("ADAYOLO_TRAIN_GRAPH", None)
+            os.environ.pop("ADAYOLO_TRAIN_KEEP", None)
+    (raw_a, grad_a), (raw_b, grad_b) = results
+    for a, b in zip(raw_a, raw_b):
+        assert torch.equal(a, b)
+    assert torch.equal(grad_a, grad_b)
