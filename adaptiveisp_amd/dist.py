@@ -19,6 +19,10 @@ def init_from_env(backend=None):
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     use_gpu = torch.cuda.is_available()
+    if use_gpu and os.environ.get("ADAISP_DP_REHEARSAL") == "1":
+        # every rank on device 0 and gloo instead of RCCL (which refuses two ranks on one device): the N-rank code path on a
+        # one-GPU box — a rehearsal of the collectives' placement, not a measurement
+        local, backend = 0, backend or "gloo"
     device = torch.device("cuda", local) if use_gpu else torch.device("cpu")
     if use_gpu:
         torch.cuda.set_device(device)

@@ -400,13 +400,22 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (the product has no CPU path)")
+    # BENCH_REHEARSAL=1: run the N-rank code path on a box with ONE GPU (every rank on device 0, gloo instead of RCCL, which
+    # refuses two ranks on one device) — a rehearsal of the launch / barrier / max-over-ranks / rank-0-only logic, its
+    # throughput means nothing and the JSON line says so
+    rehearsal = os.environ.get("BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if rehearsal:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     step, engine, agent, x0, sched = build_workload(a, dev)
 
@@ -505,6 +514,8 @@ def main():
             line["cpu_baseline"] = cpu_baseline(a, sched)
         except Exception as e:
             line["cpu_baseline"] = {"error": f"{type(e).__name__}: {e}"}
+    if rehearsal:
+        line["data"] = "synthetic (REHEARSAL: all ranks share one device; not a measurement)"
     if rank == 0:
         print(json.dumps(line), flush=True)
     if dist is not None:
