@@ -14,6 +14,11 @@
 //     per wave (Cin = 64), two waves per SIMD; the epilogue goes through one LDS tile (bias + SiLU + bf16 in the
 //     accumulator layout, then 128-byte pixel rows + residual), two barriers per tile.
 // Restrictions (the launcher falls back otherwise): ksize 3, stride 1, Cin in {32, 64}, Cout % 64 == 0, 32-bit offsets.
+// Measured and dropped (round 2, parity-green): the two channel groups skewed by a whole phase across tiles (group 1 one
+// barrier late; in every barrier interval one wave of a SIMD is in its MFMA phase, the other in its SiLU phase; two output
+// tiles; the rows of tile i - 1 leave in the SiLU phase of tile i). Per tile 9.8k cycles against 9.4k here (Cin = 64): side by
+// side the two phases take 3.5k each (alone 3.0k and 2.8k), the patch issue (1.3k) lands in front of a group's MFMAs, and the
+// within-tile skew below already overlaps one SiLU phase of two.
 #include "yolo_internal.h"
 #include <type_traits>
 

@@ -66,7 +66,7 @@ def main():
         totfl += fl * cnt
         dmax = max([(outs[variants[0]].float() - outs[v].float()).abs().max().item() for v in variants[1:]] + [0.0])
         print(f"{H}x{W} {cin:4d}->{cout:4d} k{k} s{s} x{cnt:<2d}          " + "  ".join(row) + f"  maxdiff {dmax:.3g}")
-        if 90 in variants and k == 3 and s == 1 and cin in (32, 64):
+        if (90 in variants or 91 in variants) and k == 3 and s == 1 and cin in (32, 64):
             try:
                 d = (ctypes.c_ulonglong * 16)()
                 torch.cuda.synchronize()
