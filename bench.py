@@ -53,6 +53,8 @@ def parse():
                     "adaptiveisp_amd/yolo/tuning/*.json")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-detail", action="store_true", help="skip the per-kernel roofline passes")
+    ap.add_argument("--raw", action="store_true", help="start every step from a uint16 RGGB Bayer plane in HBM (adaisp_demosaic, "
+                    "an extension: the reference's pipeline starts from RGB) instead of the fp32 RGB batch")
     return ap.parse_args()
 
 
@@ -78,6 +80,16 @@ def build_workload(a, dev):
         engine.autotune(cache=TUNE_CACHE, retune=a.retune)
     g = torch.Generator(device="cpu").manual_seed(1234 + 1)
     x0 = (torch.rand(a.batch, 3, a.height, a.width, generator=g) ** 2.2 * 0.5).to(dev)
+    raw = None
+    if getattr(a, "raw", False):
+        # the same scene as a 16-bit RGGB colour-filter-array plane: R at (even, even), G at (even, odd) / (odd, even), B at (odd, odd)
+        from adaptiveisp_amd import _lib as isp_lib
+        q = (x0 * 65535.0).round().clamp(0, 65535).to(torch.int32)
+        plane = q[:, 1].clone()
+        plane[:, 0::2, 0::2] = q[:, 0, 0::2, 0::2]
+        plane[:, 1::2, 1::2] = q[:, 2, 1::2, 1::2]
+        raw = plane.to(torch.uint16).contiguous()
+        isp_lib.demosaic(raw, out=x0)                      # x0 is from now on what the demosaic writes at the top of every step
     z = torch.rand(a.batch, cfg.z_dim, generator=g).to(dev)
     s0 = torch.zeros(a.batch, cfg.num_state_dim, device=dev)
     sched = SCHEDULES[a.schedule]
@@ -88,6 +100,8 @@ def build_workload(a, dev):
         pending plan) continues a slice. `out`: where the slice's last filter writes (the pipeline's hand-over /
         mid-episode buffer). Half-steps [0, 2*len(sched)) in order are exactly Agent.forward step by step."""
         stop = 2 * len(sched) if stop is None else stop
+        if raw is not None and start == 0 and carry is None:
+            isp_lib.demosaic(raw, out=x0)                  # --raw: the episode starts from the Bayer plane
         x, st, plan = carry if carry is not None else (x0, s0, None)
         last_apply = max((h for h in range(start, stop) if h & 1), default=-1)
         with torch.no_grad():
@@ -474,7 +488,8 @@ def main():
         "metric": f"ISP+YOLO forward images/sec @{a.width}x{a.height} bs{a.batch}", "value": round(value, 2), "unit": "images/sec",
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-        "config": {"workload": f"batch {a.batch} x {a.width}x{a.height} fp32 RGB, 5-step ISP schedule "
+        "config": {"workload": f"batch {a.batch} x {a.width}x{a.height} " + ("uint16 RGGB Bayer plane -> demosaic -> " if a.raw else "") +
+                               f"fp32 RGB, {len(sched)}-step ISP schedule "
                                f"{[NAMES[k] for k in sched]} (teacher-forced, policy/heads evaluated every step) + YOLOv3 "
                                f"forward @{a.width}x{engine.Hp} bf16 (random-init weights)",
                    "per_gpu_batch": a.batch, "global_batch": a.batch * world, "parallelism": f"replicas x{world}",

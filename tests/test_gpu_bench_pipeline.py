@@ -51,3 +51,26 @@ def test_full_size_chain_is_bit_reproducible_beside_the_detector():
         torch.cuda.synchronize()
         assert torch.equal(x, xref), f"ISP episode differs in run {i}"
         assert torch.equal(pred, pref), f"detector output differs in run {i}"
+
+
+def test_raw_bayer_start_pipelined_equals_sequential():
+    """bench.py --raw: every step starts from a uint16 RGGB plane (adaisp_demosaic at the top of the episode). The pipelined
+    replay must equal the sequential step, and the demosaiced batch must be what the ISP chain starts from."""
+    sys.path.insert(0, ROOT)
+    import bench
+    from adaptiveisp_amd import _lib
+    a = argparse.Namespace(batch=2, height=96, width=128, schedule="mixed", retune=False, raw=True)
+    bench.TUNE_CACHE = None
+    step, engine, agent, x0, sched = bench.build_workload(a, torch.device("cuda:0"))
+    ref = step().clone()
+    first = x0.clone()                                         # what the demosaic wrote
+    assert torch.isfinite(first).all() and 0.0 <= float(first.min()) and float(first.max()) <= 1.0
+    x0.fill_(float("nan"))                                     # the next step must rebuild it from the Bayer plane
+    assert torch.equal(step(), ref) and torch.equal(x0, first)
+    prime, run = bench.build_pipeline(step, engine, x0)
+    prime()
+    for _ in range(4):
+        x0.fill_(float("nan"))
+        run()
+        torch.cuda.synchronize()
+        assert torch.equal(engine.pred, ref)
