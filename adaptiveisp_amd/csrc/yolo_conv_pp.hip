@@ -105,7 +105,8 @@ struct KPos {
 };
 
 // ABL: 0 real kernel, 1 no DMA in the loop, 2 no LDS reads / MFMA, 3 no epilogue stores, 4 no k-loop, 5 no DMA
-// instructions in the loop, 6 no epilogue (measurement builds)
+// instructions in the loop, 6 no epilogue, 8 / 9 activation lines for one kernel column in three / one tap in nine
+// (measurement builds)
 // FUSE: the tile holds ALL 256 output channels of its 256 pixels, so the 1x1 conv that consumes this layer's output
 // (Bottleneck.cv1 of the next block, 256 -> 128, HBM-bound on its own: it re-reads 60 MB that were just written) is
 // applied to the output tile while it sits in LDS: the epilogue puts the post-residual bf16 rows back into the waves'
@@ -202,6 +203,10 @@ __global__ __launch_bounds__(512) void k_conv_pp(const ConvArgs a) {
     // instructions per piece that otherwise sit between two MFMAs of the issuing wave and overrun the 32-cycle slot)
     auto addr_a1 = [&](int h, int j, const KPos& p, bool live) {
         const int i = 2 * h + j;
+        // ABL 8 / 9 (measurement): the activation pieces of one kernel column in three / one tap in nine fetch real lines, the
+        // others the zero page — the distinct-line traffic a per-kernel-row activation strip / a whole patch in LDS would leave
+        if (ABL == 8 && p.kw != 0) live = false;
+        if (ABL == 9 && p.tap != 0) live = false;
         return sel(live && ((amask[i] >> p.tap) & 1u), arow[i] + p.aoff, zaddr);
     };
     auto addr_w1 = [&](int h, int j, const KPos& p, bool live) { return sel(live, wrow[2 * h + j] + p.woff, zaddr); };
@@ -538,6 +543,8 @@ hipError_t launch_conv_pp(ConvArgs a, hipStream_t s, int variant) {
     if (variant == 55) return pp::launch<5>(a, s);
     if (variant == 56) return pp::launch<6>(a, s);
     if (variant == 57) return pp::launch<7>(a, s);
+    if (variant == 58) return pp::launch<8>(a, s);
+    if (variant == 59) return pp::launch<9>(a, s);
 #endif
     (void)variant;
     if (a.w2) {                                          // fused 1x1 second layer: the tile must hold all channels
