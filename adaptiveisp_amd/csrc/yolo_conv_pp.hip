@@ -24,6 +24,9 @@
 // Measured and dropped (round 2): channel chunk outer / tap inner k order, so that consecutive k-tiles ask for almost the same
 // activation lines (L1 hits instead of L2 fetches): 3-4 % SLOWER on every layer; a non-temporal / system-scope cache policy on
 // the weight DMA (so that weights do not push those lines out): no change.
+// And: the four waves of a group issuing their two pieces behind DIFFERENT MFMAs of a section (wave w behind the w-th and
+// (w+4)-th, a scalar compare + branch per slot) instead of all behind the 1st and the 4th: 78 vs 70 us — the extra states between
+// MFMAs cost more than the texture-address queue they were meant to spare.
 #include "yolo_internal.h"
 #include <type_traits>
 #include <cstdlib>
