@@ -4,8 +4,8 @@ over xGMI on the MI355X node, "gloo" on CPU for tests).
 The reference trains on one GPU (train.py:45 WORLD_SIZE = 1). Sharding is by replay records: every rank draws its own
 batch, runs the whole hot path locally, and the ONLY collective per iteration is an all-reduce (mean) of the agent
 and value gradients — issued after backward() and BEFORE the 1e-5 grad-norm clip so the clip sees the global
-gradient (train.py:341-349). Gradients are flattened into one bucket per model (28.7 MB + 4.9 MB fp32): a few large
-transfers suit the point-to-point xGMI links better than hundreds of small ones.
+gradient (train.py:341-349). Both models' gradients are flattened into ONE bucket (28.7 MB + 4.9 MB fp32, SURVEY
+8(e)): one large transfer suits the point-to-point xGMI links better than hundreds of small ones.
 """
 import os
 
@@ -51,10 +51,16 @@ def broadcast_parameters(modules, src=0):
 
 
 class GradBucket:
-    """Flat fp32 view of a module's gradients; `all_reduce_mean()` averages them across ranks in one collective."""
+    """Flat fp32 view of the gradients of one or MORE modules; `all_reduce_mean()` averages them across ranks in ONE
+    collective (agent 28.7 MB + value 4.9 MB as a single flattened bucket). The last `len(params)` floats of
+    the buffer are a presence mask (1 where this rank's backward produced a gradient): after the sum every rank knows
+    which parameters received a gradient ANYWHERE, so a parameter whose local .grad is None on one rank only still gets
+    the averaged gradient (and its Adam update) on every rank — the replicas cannot drift apart over a data-dependent
+    branch. Parameters that never enter the loss on any rank (the filters' fc_mask heads: masking is hard-wired off,
+    isp/filters.py:161-162) keep .grad = None as in the reference, so Adam creates no state for them."""
 
-    def __init__(self, module):
-        self.params = [p for p in module.parameters() if p.requires_grad]
+    def __init__(self, *modules):
+        self.params = [p for m in modules for p in m.parameters() if p.requires_grad]
         self.numel = sum(p.numel() for p in self.params)
         self.flat = None
 
@@ -67,7 +73,9 @@ class GradBucket:
             return None                       # single process: the gradients stay where autograd put them
         dev = self.params[0].device
         if self.flat is None or self.flat.device != dev:
-            self.flat = torch.zeros(self.numel, dtype=torch.float32, device=dev)
+            self.flat = torch.zeros(self.numel + len(self.params), dtype=torch.float32, device=dev)
+        present = torch.tensor([0.0 if p.grad is None else 1.0 for p in self.params], dtype=torch.float32)
+        self.flat[self.numel:].copy_(present)
         off = 0
         for p in self.params:
             n = p.numel()
@@ -76,35 +84,36 @@ class GradBucket:
             else:
                 self.flat[off:off + n].copy_(p.grad.reshape(-1))
             off += n
-        work = None
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-            work = dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, async_op=async_op)
-            if not async_op:
-                self.flat.div_(dist.get_world_size())
+        work = dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, async_op=async_op)
+        if not async_op:
+            self.flat[:self.numel].div_(dist.get_world_size())
         return work
 
     def finish(self, work=None):
-        """Complete an async all-reduce (if any) and scatter the averaged bucket back into .grad. Parameters that
-        never enter the loss (the filters' fc_mask heads: masking is hard-wired off, isp/filters.py:161-162) keep
-        .grad = None as in the reference, so Adam creates no state for them and saved optimizer state matches."""
+        """Complete an async all-reduce (if any) and scatter the averaged bucket back into .grad (materialising .grad
+        where another rank had a gradient and this one did not)."""
         if not self._active():
             return
         if work is not None:
             work.wait()
-            self.flat.div_(dist.get_world_size())
+            self.flat[:self.numel].div_(dist.get_world_size())
+        anywhere = self.flat[self.numel:].cpu() > 0      # one small D2H per iteration: which parameters have a gradient on ANY rank
         off = 0
-        for p in self.params:
+        for p, have in zip(self.params, anywhere.tolist()):
             n = p.numel()
-            if p.grad is not None:
-                p.grad.copy_(self.flat[off:off + n].view_as(p))
+            if have:
+                g = self.flat[off:off + n].view_as(p)
+                if p.grad is None:
+                    p.grad = g.clone()
+                else:
+                    p.grad.copy_(g)
             off += n
 
 
 def synced_step(models, optimizers, buckets, max_grad_norm=1e-5):
-    """After loss.backward(): all-reduce(mean) the gradients of every model (overlapped), clip, step.
+    """After loss.backward(): all-reduce(mean) the gradients (one bucket = one collective), clip, step.
     Mirrors train.py:341-351 with the collective inserted before the clip."""
-    works = [b.all_reduce_mean(async_op=dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1)
-             for b in buckets]
+    works = [b.all_reduce_mean(async_op=GradBucket._active()) for b in buckets]
     for b, w in zip(buckets, works):
         b.finish(w)
     for m in models:
@@ -112,3 +121,23 @@ def synced_step(models, optimizers, buckets, max_grad_norm=1e-5):
     for o in optimizers:
         o.step()
         o.zero_grad(set_to_none=True)       # (the reference's default too: the next backward writes the gradients instead of adding to zeros)
+
+
+def launch_ranks(n, target, argv, module=False):
+    """`--gpus N` without torchrun: start N ranks of `target` (a script path, or a module name with module=True) under
+    `python -m torch.distributed.run` on 127.0.0.1 as a CHILD process and return its exit code. The caller must not have
+    touched the GPU (importing torch does not): the parent only waits, the children own the devices. stdout/stderr are
+    inherited, so rank 0's JSON line is the parent's output."""
+    import socket
+    import subprocess
+    import sys
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={int(n)}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port)]
+    cmd += (["-m", target] if module else [target]) + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: what RCCL needs on this driver
+    env.setdefault("OMP_NUM_THREADS", "8")
+    return subprocess.call(cmd, env=env)

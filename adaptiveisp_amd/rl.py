@@ -75,7 +75,7 @@ def train_iteration(cfg, agent, value, detector, loss_fn, imgs, z, states, label
     out["agent_loss"].backward(retain_graph=False)
     models = [agent, value]
     if buckets is None:
-        buckets = [adist.GradBucket(m) for m in models]
+        buckets = [adist.GradBucket(*models)]
     adist.synced_step(models, optimizers, buckets, max_grad_norm=1e-5)
     out["retouch"] = retouch.detach()
     out["new_states"] = new_states.detach()

@@ -39,7 +39,7 @@ class Trainer:
         lf = lr_lambda(self.max_iter_step)
         self.agent_scheduler = torch.optim.lr_scheduler.LambdaLR(self.agent_optimizer, lr_lambda=lf)
         self.value_scheduler = torch.optim.lr_scheduler.LambdaLR(self.value_optimizer, lr_lambda=lf)
-        self.buckets = [adist.GradBucket(agent), adist.GradBucket(value)]
+        self.buckets = [adist.GradBucket(agent, value)]          # ONE flattened bucket = one collective per iteration
         self.iter = 0
         adist.broadcast_parameters([agent, value], src=0)
         self.history = []
@@ -146,20 +146,50 @@ def main(argv=None):
     ap.add_argument("--detector-ckpt", default=None, help="yolov3.pt (pickled reference module)")
     ap.add_argument("--isp-ckpt", default=None, help="ckpt-*.pth to resume from")
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--gpus", type=int, default=None, help="start this many ranks (one per GPU) under torch.distributed.run "
+                    "as a child process; without it the process is one rank of whatever torchrun set up")
     a = ap.parse_args(argv)
-    rank, world, device = adist.init_from_env()
-    if device.type != "cuda":
-        raise SystemExit("adaptiveisp_amd.train needs a HIP device (the ISP and detector kernels have no CPU path)")
-    cache = os.path.join(os.path.dirname(os.path.abspath(__file__)), "yolo", "tuning", "mi355x.json")
-    tr = build_trainer(cfg, rank, world, device, a.batch, a.size, lr=a.lr, epochs=a.epochs, save_dir=a.save_dir,
-                       sync_bn=a.sync_bn, detector_ckpt=a.detector_ckpt, isp_ckpt=a.isp_ckpt, seed=a.seed, tune_cache=cache)
+    if a.gpus and a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        import sys
+        # the parent never touches the GPU: it starts the ranks as a child and exits with their code
+        raise SystemExit(adist.launch_ranks(a.gpus, "adaptiveisp_amd.train", sys.argv[1:] if argv is None else argv, module=True))
+    # ADAISP_DP_REHEARSAL=dry: the launch / barrier / max-over-ranks / one-JSON-line harness with no device (an iteration is
+    # a host sleep + one real bucketed all-reduce over gloo) — what the CPU test of `--gpus N` runs
+    dry = os.environ.get("ADAISP_DP_REHEARSAL") == "dry"
+    rank, world, device = adist.init_from_env("gloo" if dry else None)
+    if a.gpus and world != a.gpus:
+        raise SystemExit(f"adaptiveisp_amd.train: --gpus {a.gpus} but WORLD_SIZE={world}")
+    if dry:
+        class _Dry:
+            max_iter_step, history = 10, []
+
+            def __init__(self):
+                self.net = torch.nn.Linear(8, 8)
+                self.bucket = adist.GradBucket(self.net)
+
+            def train(self, iters):
+                for _ in range(iters):
+                    time.sleep(0.002)
+                    for p in self.net.parameters():
+                        p.grad = torch.ones_like(p)
+                    self.bucket.finish(self.bucket.all_reduce_mean())
+        tr = _Dry()
+    else:
+        if device.type != "cuda":
+            raise SystemExit("adaptiveisp_amd.train needs a HIP device (the ISP and detector kernels have no CPU path)")
+        if os.environ.get("ADAISP_DP_REHEARSAL") != "1" and torch.cuda.device_count() < world:
+            raise SystemExit(f"adaptiveisp_amd.train: {world} ranks but only {torch.cuda.device_count()} device(s) visible")
+        cache = os.path.join(os.path.dirname(os.path.abspath(__file__)), "yolo", "tuning", "mi355x.json")
+        tr = build_trainer(cfg, rank, world, device, a.batch, a.size, lr=a.lr, epochs=a.epochs, save_dir=a.save_dir,
+                           sync_bn=a.sync_bn, detector_ckpt=a.detector_ckpt, isp_ckpt=a.isp_ckpt, seed=a.seed, tune_cache=cache)
     n = tr.max_iter_step + 1 if a.iters is None else a.iters
     tr.train(min(a.warmup, n))
 
     def fence():
         if world > 1:
             torch.distributed.barrier()
-        torch.cuda.synchronize()
+        if not dry:
+            torch.cuda.synchronize()
 
     fence()
     t0 = time.perf_counter()
@@ -176,6 +206,11 @@ def main(argv=None):
         print(json.dumps({"metric": "RL training images/sec", "value": round(world * a.batch * timed / dt, 2) if timed else None,
                           "n_gpus": world, "iters": timed, "ms_per_iter": round(dt / max(timed, 1) * 1e3, 2),
                           "per_gpu_batch": a.batch, "global_batch": a.batch * world, "image": f"{a.size}x{a.size}",
+                          # what the N > 1 semantics are: BatchNorm statistics of the agent / value CNNs per rank (False) or
+                          # over the global batch (True = the reference's single-GPU batch-64 behaviour); gradients of both
+                          # models travel in ONE flattened all-reduce per iteration
+                          "sync_bn": bool(a.sync_bn), "grad_buckets": 1,
+                          "parallelism": f"dp{world}" + (" (DRY REHEARSAL: no device)" if dry else ""),
                           "last": last}), flush=True)
     if world > 1:
         torch.distributed.barrier()

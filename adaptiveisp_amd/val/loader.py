@@ -14,6 +14,7 @@ PARITY UNPINNED against cv2 itself (absent: no fixture can be generated); the ge
 properties in tests/test_loader.py. Decoding is PIL's (libjpeg / libpng, as cv2.imread's).
 """
 import glob
+import functools
 import math
 import os
 
@@ -66,8 +67,9 @@ def resize_linear_u8(img, size):
     return np.clip(out, 0, 255).astype(np.uint8)
 
 
+@functools.lru_cache(maxsize=64)
 def _area_weights(src, dst):
-    """Dense [dst, src] matrix of footprint overlaps, rows normalised to 1 (fp32)."""
+    """Dense [dst, src] matrix of footprint overlaps, rows normalised to 1 (fp32); cached per (src, dst)."""
     scale = src / dst
     m = np.zeros((dst, src), np.float32)
     for d in range(dst):
@@ -88,6 +90,14 @@ def resize_area_u8(img, size):
         return img.copy()
     if w > W or h > H:
         return resize_linear_u8(img, size)
+    if W % w == 0 and H % h == 0:
+        # integer shrink factors: OpenCV's ResizeAreaFast path — an INTEGER block sum, then (sum + 2) >> 2 for 2 x 2 blocks
+        # (ties round half UP there) and cvRound(sum * (1.f / area)) otherwise
+        fx, fy = W // w, H // h
+        blk = img.astype(np.int32).reshape(h, fy, w, fx, -1).sum(axis=(1, 3))
+        if fx == 2 and fy == 2:
+            return ((blk + 2) >> 2).astype(np.uint8)
+        return np.clip(np.rint(blk.astype(np.float32) * np.float32(1.0 / (fx * fy))), 0, 255).astype(np.uint8)
     mx, my = _area_weights(W, w), _area_weights(H, h)
     acc = np.einsum("yi,ijc->yjc", my, np.einsum("xj,ijc->ixc", mx, img.astype(np.float32)))
     return np.clip(np.rint(acc), 0, 255).astype(np.uint8)

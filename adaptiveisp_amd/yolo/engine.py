@@ -245,6 +245,8 @@ class YoloEngine:
                 table = {tuple(int(x) for x in k.split(",")): int(v) for k, v in json.load(open(cache)).items()}
             except Exception:
                 table = {}
+            # a table written by an older build may name variants this library no longer has: treat them as missing
+            table = {k: v for k, v in table.items() if v in self.TUNE_CANDIDATES}
             if keys <= set(table):
                 for kind, fn, args in entries:
                     if kind == "conv":

@@ -188,8 +188,11 @@ def assign_labels_packed(loss_fn, shapes, labels, device):
         gxy, gwh = t[:, 2:4], t[:, 4:6]
         a = t[:, 6].astype(np.int64)
         gij = (gxy - offsets).astype(np.int64)
-        idx = np.stack((t[:, 0].astype(np.int64), a, np.clip(gij[:, 1], 0, ny - 1), np.clip(gij[:, 0], 0, nx - 1),
-                        t[:, 1].astype(np.int64)), 1).astype(np.int32)
+        # the reference clamps gi / gj IN PLACE (views of gij) before tbox = gxy - gij (loss.py:372-376): a label centred on the
+        # map's far edge (x or y == 1.0) gets its offset against the CLAMPED cell
+        gij[:, 0] = np.clip(gij[:, 0], 0, nx - 1)
+        gij[:, 1] = np.clip(gij[:, 1], 0, ny - 1)
+        idx = np.stack((t[:, 0].astype(np.int64), a, gij[:, 1], gij[:, 0], t[:, 1].astype(np.int64)), 1).astype(np.int32)
         box = np.concatenate((gxy - gij.astype(f32), gwh, anc[i][a]), 1).astype(f32)
         packed.append((torch.from_numpy(np.ascontiguousarray(idx)).to(device, non_blocking=True),
                        torch.from_numpy(np.ascontiguousarray(box)).to(device, non_blocking=True)))

@@ -407,36 +407,9 @@ def cpu_baseline(a, sched):
             "detector_s": {"min": r3(d_min), "median": r3(d_med)}}
 
 
-def main():
-    a = parse()
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a HIP device (the product has no CPU path)")
-    # BENCH_REHEARSAL=1: run the N-rank code path on a box with ONE GPU (every rank on device 0, gloo instead of RCCL, which
-    # refuses two ranks on one device) — a rehearsal of the launch / barrier / max-over-ranks / rank-0-only logic, its
-    # throughput means nothing and the JSON line says so
-    rehearsal = os.environ.get("BENCH_REHEARSAL") == "1"
-    if rehearsal:
-        local = 0
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if rehearsal:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
-        else:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-
+def prepare_gpu_run(a, dev):
+    """Workload, eager warm-up, hipGraph capture and the two-stream pipeline -> (run, single_run, graphed, pipelined, engine, x0, sched)."""
     step, engine, agent, x0, sched = build_workload(a, dev)
-
-    def barrier():
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
 
     run = step
     single_run = None
@@ -470,6 +443,63 @@ def main():
             print(f"[bench] hipGraph capture unavailable ({type(e).__name__}: {e}); launching eagerly", file=sys.stderr)
             torch.cuda.synchronize()
             run = step
+    return run, single_run, graphed, pipelined, engine, x0, sched
+
+
+def main():
+    a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` (how the driver calls it): this process has not touched the GPU and never will — it
+        # starts one rank per GPU under torch.distributed.run as a CHILD, relays rank 0's JSON line (inherited stdout) and
+        # exits with the child's code. (Replacing a GPU-initialised process by exec is what this pool forbids; we do neither.)
+        from adaptiveisp_amd.dist import launch_ranks
+        raise SystemExit(launch_ranks(a.gpus, os.path.abspath(__file__), sys.argv[1:]))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        raise SystemExit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}: launch one rank per GPU (or let --gpus N do it)")
+    # BENCH_REHEARSAL=1: run the N-rank code path on a box with ONE GPU (every rank on device 0, gloo instead of RCCL, which
+    # refuses two ranks on one device) — a rehearsal of the launch / barrier / max-over-ranks / rank-0-only logic, its
+    # throughput means nothing and the JSON line says so. BENCH_REHEARSAL=dry: the same harness with NO device at all (the
+    # step is a host sleep) — what tests/test_dist_gloo.py runs on the CPU box to pin `--gpus N` -> N ranks -> one line.
+    rehearsal = os.environ.get("BENCH_REHEARSAL", "")
+    dry = rehearsal == "dry"
+    rehearsal = rehearsal in ("1", "dry")
+    if dry:
+        dev = torch.device("cpu")
+    else:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a HIP device (the product has no CPU path)")
+        if not rehearsal and torch.cuda.device_count() < world:
+            raise SystemExit(f"bench.py: --gpus {world} but only {torch.cuda.device_count()} device(s) visible")
+        if rehearsal:
+            local = 0
+        torch.cuda.set_device(local)
+        dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if rehearsal:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        if not dry:
+            torch.cuda.synchronize()
+
+    if dry:
+        run, sched, Hp = (lambda: time.sleep(0.002)), SCHEDULES[a.schedule], (a.height + 31) // 32 * 32
+        graphed = pipelined = False
+        single_run = engine = x0 = None
+        a.no_detail = a.no_cpu_baseline = True
+    else:
+        run, single_run, graphed, pipelined, engine, x0, sched = prepare_gpu_run(a, dev)
+        Hp = engine.Hp
     for _ in range(a.warmup):
         run()
     barrier()
@@ -491,7 +521,7 @@ def main():
         "config": {"workload": f"batch {a.batch} x {a.width}x{a.height} " + ("uint16 RGGB Bayer plane -> demosaic -> " if a.raw else "") +
                                f"fp32 RGB, {len(sched)}-step ISP schedule "
                                f"{[NAMES[k] for k in sched]} (teacher-forced, policy/heads evaluated every step) + YOLOv3 "
-                               f"forward @{a.width}x{engine.Hp} bf16 (random-init weights)",
+                               f"forward @{a.width}x{Hp} bf16 (random-init weights)",
                    "per_gpu_batch": a.batch, "global_batch": a.batch * world, "parallelism": f"replicas x{world}",
                    "launch": ("hipGraph replay, 2-stage pipeline: one ISP episode's worth of steps (batch i+1 from its NLM "
                               "step on, then the first steps of batch i+2) beside the detector of batch i "
@@ -530,7 +560,8 @@ def main():
         except Exception as e:
             line["cpu_baseline"] = {"error": f"{type(e).__name__}: {e}"}
     if rehearsal:
-        line["data"] = "synthetic (REHEARSAL: all ranks share one device; not a measurement)"
+        line["data"] = ("synthetic (DRY REHEARSAL: no device, the step is a host sleep; not a measurement)" if dry else
+                        "synthetic (REHEARSAL: all ranks share one device; not a measurement)")
     if rank == 0:
         print(json.dumps(line), flush=True)
     if dist is not None:

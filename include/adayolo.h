@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define ADAYOLO_ABI_VERSION 1
+#define ADAYOLO_ABI_VERSION 2
 
 #define ADAYOLO_ACT_NONE 0
 #define ADAYOLO_ACT_SILU 1

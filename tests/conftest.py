@@ -33,3 +33,12 @@ def oracle_mod():
     import oracle
     oracle.build()
     return oracle
+
+
+def pytest_sessionfinish(session, exitstatus):
+    """GPU sessions leave the measured parity errors behind (tests/_margins.py)."""
+    import _margins
+    if _margins.RECORDS:
+        out = os.path.join(ROOT, "gpurun_out")
+        os.makedirs(out, exist_ok=True)
+        _margins.dump(os.path.join(out, "parity_margins.txt"))

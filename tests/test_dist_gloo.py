@@ -47,6 +47,29 @@ def _worker(rank, world, port, out):
     for i, p in enumerate(v.parameters()):
         p.grad = torch.full_like(p, float(rank + 1))
     adist.synced_step([v], [torch.optim.SGD(v.parameters(), lr=0.0)], [bucket], max_grad_norm=1e-5)
+    # a gradient that exists on ONE rank only (a data-dependent branch): the presence mask travels in the same collective,
+    # every rank materialises the averaged gradient and applies the same update; a parameter with no gradient anywhere
+    # keeps .grad = None on every rank
+    lin = torch.nn.Linear(3, 2)
+    with torch.no_grad():
+        lin.weight.fill_(1.0); lin.bias.fill_(1.0)
+    b2 = adist.GradBucket(lin)
+    lin.weight.grad = torch.full_like(lin.weight, 4.0) if rank == 0 else None
+    seen = {}
+    real_clip = torch.nn.utils.clip_grad_norm_
+
+    def spy(params, max_norm, *a, **k):
+        seen["grads"] = [None if p.grad is None else p.grad.clone() for p in params]
+        return real_clip([p for p in lin.parameters()], max_norm, *a, **k)
+
+    torch.nn.utils.clip_grad_norm_ = spy
+    try:
+        adist.synced_step([lin], [torch.optim.SGD(lin.parameters(), lr=1.0)], [b2], max_grad_norm=1e9)
+    finally:
+        torch.nn.utils.clip_grad_norm_ = real_clip
+    assert torch.equal(seen["grads"][0], torch.full_like(lin.weight, 4.0 / world)) and seen["grads"][1] is None
+    assert torch.equal(lin.weight.detach(), torch.full_like(lin.weight, 1.0 - 4.0 / world))
+    assert torch.equal(lin.bias.detach(), torch.ones_like(lin.bias))
     out.put((rank, bucket.numel))
     dist.barrier()
     dist.destroy_process_group()
@@ -131,7 +154,7 @@ def _rl_worker(rank, world, port, out):
     anchors = torch.tensor([[[1.2, 1.6], [2.0, 3.7], [4.1, 2.9]]] * 3)
     loss_fn = DetectionLoss(anchors, nc=4, hyp=default_hyp(4, 64), device="cpu")
     opts = [torch.optim.Adam(agent.parameters(), lr=3e-5), torch.optim.Adam(value.parameters(), lr=3e-5)]
-    buckets = [adist.GradBucket(agent), adist.GradBucket(value)]
+    buckets = [adist.GradBucket(agent, value)]
     g = torch.Generator().manual_seed(100 + rank)
     B = 2
     norms = []
@@ -164,8 +187,12 @@ def _rl_worker(rank, world, port, out):
     allnorms = [torch.zeros_like(nt) for _ in range(world)]
     dist.all_gather(allnorms, nt)
     assert all(torch.equal(allnorms[0], t) for t in allnorms), "the clip must see the same (global) gradient norm"
-    dead = [n for n, p in agent.named_parameters() if p.grad is None]
-    out.put((rank, float(nt.sum()), len(dead)))
+    # synced_step ends with zero_grad(set_to_none=True), so .grad says nothing here: the optimizer state does. Adam holds
+    # state for exactly the parameters that ever had a gradient: all but the filters' fc_mask heads (masking is off).
+    no_state = sorted(n for n, p in agent.named_parameters() if p not in opts[0].state)
+    assert no_state and all(".fc_mask." in n for n in no_state), no_state
+    assert all(p in opts[1].state for p in value.parameters())
+    out.put((rank, float(nt.sum()), len(no_state)))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -184,4 +211,49 @@ def test_two_ranks_train_iteration_lock_step():
         assert p.exitcode == 0
     got = sorted(out.get(timeout=5) for _ in range(2))
     assert got[0][1] == got[1][1] and got[0][1] > 0
-    assert got[0][2] == got[1][2] and got[0][2] > 0        # fc_mask heads: no gradient, .grad stays None (as the reference)
+    assert got[0][2] == got[1][2] == 20                    # 10 filters x (fc_mask.weight, fc_mask.bias): no gradient, no Adam state
+
+
+# ---- `bench.py --gpus N` / `python -m adaptiveisp_amd.train --gpus N` start N ranks themselves -------------------------
+
+def _run_launcher(cmd, env_extra):
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, **env_extra)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, *cmd], cwd=root, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout                      # ONE line, from rank 0
+    return json.loads(lines[0])
+
+
+def test_bench_gpus_n_launches_n_ranks():
+    """The driver calls `python3 bench.py --gpus N ...` WITHOUT torchrun: the parent must start N ranks as a child process
+    and relay rank 0's line. BENCH_REHEARSAL=dry: same harness (barrier, max over ranks, one line), no device."""
+    line = _run_launcher(["bench.py", "--gpus", "2", "--steps", "3", "--warmup", "1"], {"BENCH_REHEARSAL": "dry"})
+    assert line["n_gpus"] == 2 and line["steps"] == 3 and line["warmup"] == 1 and line["scaling"] == "weak"
+    assert line["config"]["global_batch"] == 16 and line["config"]["per_gpu_batch"] == 8
+    assert line["config"]["parallelism"] == "replicas x2"
+    assert line["metric"].startswith("ISP+YOLO forward images/sec @1280x720 bs8") and "REHEARSAL" in line["data"]
+    one = _run_launcher(["bench.py", "--steps", "2", "--warmup", "0"], {"BENCH_REHEARSAL": "dry"})
+    assert one["n_gpus"] == 1 and one["config"]["global_batch"] == 8
+
+
+def test_bench_rejects_a_world_that_is_not_gpus():
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, BENCH_REHEARSAL="dry", WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "1"], cwd=root, env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "WORLD_SIZE" in r.stderr
+
+
+def test_train_gpus_n_launches_n_ranks():
+    line = _run_launcher(["-m", "adaptiveisp_amd.train", "--gpus", "2", "--iters", "2", "--warmup", "0", "--batch", "4"],
+                         {"ADAISP_DP_REHEARSAL": "dry"})
+    assert line["n_gpus"] == 2 and line["global_batch"] == 8 and line["per_gpu_batch"] == 4
+    assert line["sync_bn"] is False and line["grad_buckets"] == 1 and line["iters"] == 2

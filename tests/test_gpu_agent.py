@@ -3,6 +3,8 @@ import numpy as np
 import pytest
 import torch
 
+from _margins import close
+
 pytestmark = pytest.mark.gpu
 T = torch.from_numpy
 
@@ -33,12 +35,11 @@ def test_teacher_forced_step(golden, k):
         (x, ns, sur, pen), dbg, _ = ag((T(g["x"]).to(dev), T(g["z"]).to(dev), T(g["s0"]).to(dev)), 1.0,
                                        selected_filter_id=k)
     assert np.array_equal(ns.cpu().numpy(), g[f"forced{k}.new_states"])
-    np.testing.assert_allclose(pen.cpu().numpy(), g[f"forced{k}.penalty"], rtol=1e-4, atol=1e-5)
-    np.testing.assert_allclose(dbg["filter_debug_info"][k]["filter_parameters"].reshape(-1).cpu().numpy(),
-                               g[f"forced{k}.param0"], rtol=1e-4, atol=1e-5)
+    close("teacher_forced_step#1", pen.cpu().numpy(), g[f"forced{k}.penalty"], rtol=1e-4, atol=1e-5)
+    close(f"teacher_forced_step:param:f{k}", dbg["filter_debug_info"][k]["filter_parameters"].reshape(-1).cpu().numpy(), g[f"forced{k}.param0"], rtol=1e-4, atol=1e-5)
     # the heads run on MIOpen/rocBLAS (different summation order than the CPU reference): parameters agree to
     # ~1e-5, which the filters amplify slightly
-    np.testing.assert_allclose(x.cpu().numpy(), g[f"forced{k}.x"], rtol=2e-4, atol=2e-5)
+    close(f"teacher_forced_step:x:f{k}", x.cpu().numpy(), g[f"forced{k}.x"], rtol=2e-4, atol=2e-5)
 
 
 @pytest.mark.parametrize("tag", ["s0", "s1"])
@@ -48,10 +49,10 @@ def test_policy_selection(golden, tag):
     with torch.no_grad():
         (x, ns, sur, pen), dbg, _ = ag((T(g["x"]).to(dev), T(g["z"]).to(dev), T(g[tag]).to(dev)),
                                        float(g[f"{tag}.progress"]))
-    np.testing.assert_allclose(dbg["pdf"].cpu().numpy(), g[f"{tag}.pdf0"], rtol=1e-3, atol=1e-5)
+    close("policy_selection#1", dbg["pdf"].cpu().numpy(), g[f"{tag}.pdf0"], rtol=1e-3, atol=1e-5)
     assert np.array_equal(dbg["selected_filter"].cpu().numpy(), g[f"{tag}.selected"])
     assert np.array_equal(ns.cpu().numpy(), g[f"{tag}.new_states"])
-    np.testing.assert_allclose(x.cpu().numpy(), g[f"{tag}.x"], rtol=2e-4, atol=2e-5)
+    close("policy_selection#2", x.cpu().numpy(), g[f"{tag}.x"], rtol=2e-4, atol=2e-5)
 
 
 def test_value(golden):
@@ -64,8 +65,7 @@ def test_value(golden):
     va.load_state_dict(synth_state_dict(va, seed=1))
     va = va.to(dev).eval()
     with torch.no_grad():
-        np.testing.assert_allclose(va(T(g["x"]).to(dev), T(g["s0"]).to(dev)).cpu().numpy(), g["value.s0"], rtol=1e-3,
-                                   atol=1e-4)
+        close("value#1", va(T(g["x"]).to(dev), T(g["s0"]).to(dev)).cpu().numpy(), g["value.s0"], rtol=1e-3, atol=1e-4)
 
 
 def test_filter_module_api(golden):
@@ -78,9 +78,9 @@ def test_filter_module_api(golden):
     for name, cls in (("T", F.ToneFilter), ("CCM", F.CCMFilter), ("NLM", F.DenoiseFilter), ("Shr", F.SharpenFilter)):
         f = cls(cfg, predict=False)
         p = f.filter_param_regressor(T(g[f"{name}.feat"]).to(dev))
-        np.testing.assert_allclose(f.process(img, p).cpu().numpy(), g[f"{name}.process"], rtol=1e-5, atol=2e-6)
+        close("filter_module_api#1", f.process(img, p).cpu().numpy(), g[f"{name}.process"], rtol=1e-5, atol=2e-6)
         low, high, dbg = f.forward(img, specified_parameter=p, high_res=img)
-        np.testing.assert_allclose(low.cpu().numpy(), g[f"{name}.forward"], rtol=1e-5, atol=2e-6)
+        close("filter_module_api#2", low.cpu().numpy(), g[f"{name}.forward"], rtol=1e-5, atol=2e-6)
         assert torch.equal(low, high) and set(dbg) == {"filter_parameters", "mask"}
 
 
@@ -100,15 +100,15 @@ def test_fused_eval_path_matches_torch_path(golden, tag):
     assert torch.equal(dbgf["selected_filter"], dbgt["selected_filter"]) and dbgf["selected_filter"].dtype == torch.int64
     assert np.array_equal(dbgf["selected_filter"].cpu().numpy(), g[f"{tag}.selected"])
     assert torch.equal(nsf, nst) and np.array_equal(nsf.cpu().numpy(), g[f"{tag}.new_states"])
-    torch.testing.assert_close(dbgf["pdf"], dbgt["pdf"], rtol=1e-4, atol=1e-6)
-    np.testing.assert_allclose(dbgf["pdf"].cpu().numpy(), g[f"{tag}.pdf0"], rtol=1e-3, atol=1e-5)
-    torch.testing.assert_close(surf, surt, rtol=1e-4, atol=1e-5)
-    torch.testing.assert_close(penf, pent, rtol=1e-4, atol=1e-5)
-    np.testing.assert_allclose(penf.cpu().numpy(), g[f"{tag}.penalty"], rtol=1e-4, atol=1e-5)
+    close("fused_eval_path_matches_torch_path#1", dbgf["pdf"], dbgt["pdf"], rtol=1e-4, atol=1e-6)
+    close("fused_eval_path_matches_torch_path#2", dbgf["pdf"].cpu().numpy(), g[f"{tag}.pdf0"], rtol=1e-3, atol=1e-5)
+    close("fused_eval_path_matches_torch_path#3", surf, surt, rtol=1e-4, atol=1e-5)
+    close("fused_eval_path_matches_torch_path#4", penf, pent, rtol=1e-4, atol=1e-5)
+    close("fused_eval_path_matches_torch_path#5", penf.cpu().numpy(), g[f"{tag}.penalty"], rtol=1e-4, atol=1e-5)
     for a, b in zip(dbgf["filter_debug_info"], dbgt["filter_debug_info"]):
         assert a["filter_parameters"].shape == b["filter_parameters"].shape
-        torch.testing.assert_close(a["filter_parameters"], b["filter_parameters"], rtol=1e-4, atol=1e-5)
-    np.testing.assert_allclose(xf.cpu().numpy(), g[f"{tag}.x"], rtol=2e-4, atol=2e-5)
+        close("fused_eval_path_matches_torch_path#6", a["filter_parameters"], b["filter_parameters"], rtol=1e-4, atol=1e-5)
+    close("fused_eval_path_matches_torch_path#7", xf.cpu().numpy(), g[f"{tag}.x"], rtol=2e-4, atol=2e-5)
 
 
 def test_fused_eval_forced_and_highres(golden):
@@ -119,10 +119,10 @@ def test_fused_eval_forced_and_highres(golden):
         for k in range(10):
             (x, ns, sur, pen), dbg, _ = ag(inp, 1.0, selected_filter_id=k)
             assert np.array_equal(ns.cpu().numpy(), g[f"forced{k}.new_states"])
-            np.testing.assert_allclose(pen.cpu().numpy(), g[f"forced{k}.penalty"], rtol=1e-4, atol=1e-5)
-            np.testing.assert_allclose(x.cpu().numpy(), g[f"forced{k}.x"], rtol=2e-4, atol=2e-5)
+            close("fused_eval_forced_and_highres#1", pen.cpu().numpy(), g[f"forced{k}.penalty"], rtol=1e-4, atol=1e-5)
+            close(f"fused_eval_forced:x:f{k}", x.cpu().numpy(), g[f"forced{k}.x"], rtol=2e-4, atol=2e-5)
         (x, ns, hr), _, _ = ag(inp, 1.0, high_res=T(g["hr.in"]).to(dev), selected_filter_id=5)
-        np.testing.assert_allclose(hr.cpu().numpy(), g["hr.out"], rtol=2e-4, atol=2e-5)
+        close("fused_eval_forced_and_highres#3", hr.cpu().numpy(), g["hr.out"], rtol=2e-4, atol=2e-5)
         # `out=`: the retouched batch lands in the caller's buffer (the bench's double-buffered hand-over), same values
         buf = torch.full_like(inp[0], float("nan"))
         (x2, _, _, _), _, _ = ag(inp, 1.0, selected_filter_id=3, out=buf)
@@ -181,7 +181,7 @@ def test_training_iteration_end_to_end():
     opts = [torch.optim.Adam(agent.parameters(), lr=3e-5), torch.optim.Adam(value.parameters(), lr=3e-5)]
     before = torch.cat([p.detach().reshape(-1) for p in agent.parameters()]).clone()
     out = train_iteration(cfg, agent, value, det, loss_fn, imgs, z, states, labels, 0.1, opts,
-                          buckets=[adist.GradBucket(agent), adist.GradBucket(value)])
+                          buckets=[adist.GradBucket(agent, value)])
     torch.cuda.synchronize()
     for k in ("reward", "q_value", "value_loss", "agent_loss"):
         assert torch.isfinite(out[k]).all(), k
@@ -223,7 +223,7 @@ def test_device_side_sampling_train_mode(golden):
     assert torch.equal(ns[:, 3:], torch.maximum(states[:, 3:].cpu(), hot))
     assert torch.equal(ns[:, 2], states[:, 2].cpu() + 1)
     sur = torch.sum(hot * torch.log(pdf + 1e-10), dim=1, keepdim=True)
-    torch.testing.assert_close(o["surrogate"].cpu(), sur, rtol=1e-5, atol=1e-6)
+    close("device_side_sampling_train_mode#1", o["surrogate"].cpu(), sur, rtol=1e-5, atol=1e-6)
     y = _lib.forward(x, o["op_ids"], o["packed"], clip=True)
     assert not y[0].any() and y[1].any()
     # the same launch in eval mode is the arg-max
@@ -246,7 +246,7 @@ def test_pool64_backward_matches_aten(shape):
     y.backward(go)
     xr = x.detach().cpu().requires_grad_(True)
     torch.nn.AdaptiveAvgPool2d((64, 64))(xr).backward(go.cpu())
-    torch.testing.assert_close(x.grad.cpu(), xr.grad, rtol=2e-6, atol=1e-9)
+    close("pool64_backward_matches_aten#1", x.grad.cpu(), xr.grad, rtol=2e-6, atol=1e-9)
     assert torch.equal(y.detach(), _lib.pool64(x.detach()))
 
 
@@ -267,13 +267,13 @@ def test_critic_to_actor_gradient_matches_reference(golden, k):
     (xo, ns, sur, pen), dbg, _ = ag((T(g["x"]).to(dev), T(g["z"]).to(dev), T(g["s0"]).to(dev)), 1.0, selected_filter_id=k)
     assert xo.requires_grad
     v = va(xo, ns)
-    np.testing.assert_allclose(v.detach().cpu().numpy(), g[f"f{k}.value"], rtol=1e-3, atol=1e-4)
+    close(f"critic_to_actor_value:f{k}", v.detach().cpu().numpy(), g[f"f{k}.value"], rtol=1e-3, atol=1e-4)
     (-v.mean()).backward()
     flt = ag.filters[k]
     for got, key in ((flt.fc_filter.weight.grad, "gw"), (flt.fc_filter.bias.grad, "gb")):
         ref = g[f"f{k}.{key}"]
         assert got is not None and np.abs(ref).max() > 0
-        np.testing.assert_allclose(got.cpu().numpy(), ref, rtol=2e-3, atol=2e-3 * np.abs(ref).max())
+        close(f"critic_to_actor_gradient:f{k}", got.cpu().numpy(), ref, rtol=2e-3, atol=2e-3 * np.abs(ref).max())
     for j, other in enumerate(ag.filters):                 # only the selected filter's heads see this gradient
         if j != k and other.fc_filter.bias.grad is not None:
             assert not other.fc_filter.bias.grad.any()
@@ -295,6 +295,6 @@ def test_config1_single_640_three_steps_on_the_hip_path(oracle_mod):
             assert ag._fast is not None
             p = dbg["filter_debug_info"][k]["filter_parameters"].reshape(1, -1).cpu().numpy()
             ref = oracle_mod.forward(x.cpu().numpy(), ops[k], p, clip=True)
-            np.testing.assert_allclose(y.cpu().numpy(), ref, rtol=1e-5, atol=2e-6)
+            close("config1_single_640_three_steps_on_the_hip_path#1", y.cpu().numpy(), ref, rtol=1e-5, atol=2e-6)
             assert float(st2[0, 2]) == step + 1 and float(st2[0, 3 + k]) == 1.0 and int(dbg["selected_filter"][0]) == k
             x, st = y, st2

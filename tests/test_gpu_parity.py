@@ -5,6 +5,8 @@ import numpy as np
 import pytest
 import torch
 
+from _margins import close
+
 pytestmark = pytest.mark.gpu
 
 OPS = {"E": 0, "G": 1, "CCM": 2, "Shr": 3, "NLM": 4, "T": 5, "Ct": 6, "Sp": 7, "BW": 8, "W": 9, "USM": 10,
@@ -57,14 +59,14 @@ def test_golden_vectors(golden, name, mode):
     if name in BIT_EXACT:
         np.testing.assert_array_equal(out, g[f"{name}.{mode}"])
     else:
-        np.testing.assert_allclose(out, g[f"{name}.{mode}"], rtol=RTOL, atol=ATOL)
+        close(f"golden_vectors:{name}", out, g[f"{name}.{mode}"], rtol=RTOL, atol=ATOL)
 
 
 @pytest.mark.parametrize("tag", ["a", "tiny", "odd"])
 def test_golden_nlm_wrap(golden, tag):
     g = golden("nlm")
     out = gpu_process(OPS["NLM"], g[f"{tag}.img"], g[f"{tag}.h"], clip=True)
-    np.testing.assert_allclose(out, g[f"{tag}.out"], rtol=RTOL, atol=ATOL)
+    close("golden_nlm_wrap#1", out, g[f"{tag}.out"], rtol=RTOL, atol=ATOL)
 
 
 @pytest.mark.parametrize("tag", ["a", "tiny", "odd"])
@@ -76,8 +78,8 @@ def test_nlm_reference_order_kernel(golden, oracle_mod, tag):
     img, h = torch.from_numpy(g[f"{tag}.img"]).to(dev()), torch.from_numpy(g[f"{tag}.h"]).to(dev())
     exact = _lib.process(OPS["NLM"], img, h, clip=True, nlm_exact=True).cpu().numpy()
     fast = _lib.process(OPS["NLM"], img, h, clip=True).cpu().numpy()
-    np.testing.assert_allclose(exact, g[f"{tag}.out"], rtol=RTOL, atol=ATOL)
-    np.testing.assert_allclose(fast, g[f"{tag}.out"], rtol=RTOL, atol=ATOL)
+    close("nlm_reference_order_kernel#1", exact, g[f"{tag}.out"], rtol=RTOL, atol=ATOL)
+    close("nlm_reference_order_kernel#2", fast, g[f"{tag}.out"], rtol=RTOL, atol=ATOL)
     assert np.abs(fast - exact).max() < 2e-6
 
 
@@ -98,7 +100,7 @@ def test_nlm_hand_scheduled_kernel_matches_compiled_form(oracle_mod, shape):
         assert torch.equal(_lib.process(OPS["NLM"], img, h, clip=True), fast)
         assert torch.equal(_lib.process(OPS["NLM"], img, h, clip=True, nlm_tile32=True), t32)
     ref = oracle_mod.forward(img.cpu().numpy(), OPS["NLM"], h.cpu().numpy(), clip=True)
-    np.testing.assert_allclose(fast.cpu().numpy(), ref, rtol=RTOL, atol=ATOL)
+    close("nlm_hand_scheduled_kernel_matches_compiled_form#1", fast.cpu().numpy(), ref, rtol=RTOL, atol=ATOL)
     assert (fast - v1).abs().max().item() < 2e-6
     # the 24-row (3 workgroups per CU, default) and the 32-row tile run the same per-pixel instruction sequence
     assert torch.equal(fast, t32)
@@ -110,7 +112,7 @@ def test_golden_pool64(golden, tag):
     g = golden("pool64")
     out = _lib.pool64(torch.from_numpy(g[f"{tag}.img"]).to(dev())).cpu().numpy()
     # window sums in a fixed (but not ATen's) order, then one division: a few ulp, never more
-    np.testing.assert_allclose(out, g[f"{tag}.out"], rtol=2e-6, atol=0)
+    close("golden_pool64#1", out, g[f"{tag}.out"], rtol=2e-6, atol=0)
 
 
 SHAPES = [(2, 64, 128), (1, 37, 53), (3, 5, 7), (1, 3, 3), (1, 33, 260), (2, 96, 64)]
@@ -134,7 +136,7 @@ def test_vs_oracle_shapes(oracle_mod, name, shape):
         if name in BIT_EXACT:
             np.testing.assert_array_equal(out, ref, err_msg=f"{name} {shape} clip={clip}")
         else:
-            np.testing.assert_allclose(out, ref, rtol=RTOL, atol=ATOL, err_msg=f"{name} {shape} clip={clip}")
+            close(f"vs_oracle_shapes:{name}", out, ref, rtol=RTOL, atol=ATOL, err_msg=f"{name} {shape} clip={clip}")
 
 
 def test_mixed_ids_one_call(oracle_mod):
@@ -155,9 +157,9 @@ def test_mixed_ids_one_call(oracle_mod):
                        torch.from_numpy(params).to(dev()), clip=True, pooled=pooled)
     torch.cuda.synchronize()
     ref = oracle_mod.forward(img, ids, params, clip=True)
-    np.testing.assert_allclose(out.cpu().numpy(), ref, rtol=RTOL, atol=ATOL)
+    close("mixed_ids_one_call#1", out.cpu().numpy(), ref, rtol=RTOL, atol=ATOL)
     assert not out[0].any()
-    np.testing.assert_allclose(pooled.cpu().numpy(), oracle_mod.pool64(ref), rtol=RTOL, atol=1e-6)
+    close("mixed_ids_one_call#2", pooled.cpu().numpy(), oracle_mod.pool64(ref), rtol=RTOL, atol=1e-6)
     # the per-op entry point runs the same kernels: bit-identical to the mixed call
     for b, op in enumerate(ids):
         one = _lib.process(int(op), torch.from_numpy(img[b:b + 1]).to(dev()), torch.from_numpy(params[b:b + 1]).to(dev()),
@@ -204,17 +206,17 @@ def test_fullsize_identities():
     eye = torch.eye(3, device=dev()).reshape(1, 9).repeat(B, 1)
     assert torch.equal(_lib.process(OPS["CCM"], x, eye * 2.0), x)              # rows are re-normalised
     assert torch.equal(_lib.process(OPS["E"], x, one * 0.0), x)
-    torch.testing.assert_close(_lib.process(OPS["G"], x, one), x.clamp_min(0.001), rtol=1e-6, atol=0)   # gamma 1
+    close("fullsize_identities#1", _lib.process(OPS["G"], x, one), x.clamp_min(0.001), rtol=1e-6, atol=0)   # gamma 1
     assert torch.equal(_lib.process(OPS["BW"], x, one * 0.0), x)
     assert torch.equal(_lib.process(OPS["Sp"], x, one * 0.0), x)
     assert torch.equal(_lib.process(OPS["Shr"], x, one), x)                      # factor 1 keeps the image
     assert torch.equal(_lib.process(OPS["ShrV2"], x, one * 0.0), x)
     # exposure: +1 EV then -1 EV is the identity up to two roundings of exp()
     y = _lib.process(OPS["E"], _lib.process(OPS["E"], x, one), x.new_full((B, 1), -1.0))
-    torch.testing.assert_close(y, x, rtol=1e-6, atol=0)
+    close("fullsize_identities#2", y, x, rtol=1e-6, atol=0)
     # a flat tone curve is the identity on [0,1] up to rounding
     t = _lib.process(OPS["T"], x, torch.full((B, 8), 1.3, device=dev()))
-    torch.testing.assert_close(t, x, rtol=2e-6, atol=1e-7)
+    close("fullsize_identities#3", t, x, rtol=2e-6, atol=1e-7)
     # clip is idempotent and bounds the output
     c = _lib.process(OPS["E"], x, one * 3.0, clip=True)
     assert float(c.max()) <= 1.0 and float(c.min()) >= 0.0
@@ -229,8 +231,7 @@ def test_fullsize_nlm_properties():
     assert torch.equal(y, x)
     # a constant image is a fixed point for any h, and the output is a convex combination of inputs
     c = torch.full_like(x, 0.375)
-    torch.testing.assert_close(_lib.process(OPS["NLM"], c, torch.full((2, 1), 0.5, device=dev())), c, rtol=1e-6,
-                               atol=0)
+    close("fullsize_nlm_properties#1", _lib.process(OPS["NLM"], c, torch.full((2, 1), 0.5, device=dev())), c, rtol=1e-6, atol=0)
     z = _lib.process(OPS["NLM"], x, torch.full((2, 1), 0.3, device=dev()))
     assert float(z.max()) <= float(x.max()) + 1e-6 and float(z.min()) >= float(x.min()) - 1e-6
     # circular boundary: rolling the input rolls the output (torch.roll semantics of the reference)
@@ -245,7 +246,7 @@ def test_fullsize_pool_checksum():
     p = _lib.pool64(x)
     # 1280 = 64*20 columns tile exactly; rows overlap (720/64 = 11.25) -> compare against torch's own pooling
     ref = torch.nn.functional.adaptive_avg_pool2d(x, (64, 64))
-    torch.testing.assert_close(p, ref, rtol=1e-5, atol=1e-7)
+    close("fullsize_pool_checksum#1", p, ref, rtol=1e-5, atol=1e-7)
 
 
 # ---- parameter gradients (adaisp_backward_params) vs the reference's autograd ----------------------------
@@ -261,7 +262,7 @@ def test_param_gradients_match_reference_autograd(golden, name, mode):
     grad = _lib.backward_params(img, torch.from_numpy(gg["grad_out"]).to(dev()), ids, p, clip=(mode == "forward"))
     ref = gg[f"{name}.{mode}"]
     # sums of ~3k signed terms in a different order than autograd's reductions: compare to the gradient scale
-    np.testing.assert_allclose(grad.cpu().numpy()[:, :ref.shape[1]], ref, rtol=2e-4, atol=2e-4 * max(1.0, np.abs(ref).max()))
+    close(f"param_gradients:{name}", grad.cpu().numpy()[:, :ref.shape[1]], ref, rtol=2e-4, atol=2e-4 * max(1.0, np.abs(ref).max()))
 
 
 def test_autograd_through_filter_modules(golden):
@@ -291,19 +292,19 @@ def test_fullsize_4k_properties(oracle_mod):
     x = (torch.rand(B, 3, H, W, device=dev()) ** 2.2 * 0.5)
     one = torch.ones(B, 1, device=dev())
     # sharpen with factor 1 is the identity (adjust_sharpness: img*1 + blur*0), NLM of a constant image is that constant
-    torch.testing.assert_close(_lib.process(OPS["Shr"], x, one), x, rtol=0, atol=0)
+    close("fullsize_4k_properties#1", _lib.process(OPS["Shr"], x, one), x, rtol=0, atol=0)
     c = torch.full((1, 3, H, W), 0.25, device=dev())
-    torch.testing.assert_close(_lib.process(OPS["NLM"], c, torch.full((1, 1), 0.4, device=dev())), c, rtol=1e-6, atol=1e-7)
+    close("fullsize_4k_properties#2", _lib.process(OPS["NLM"], c, torch.full((1, 1), 0.4, device=dev())), c, rtol=1e-6, atol=1e-7)
     # sharpen(f) on the whole frame vs the oracle on a crop whose stencil footprint lies inside the crop
     f = torch.tensor([[2.5], [0.3]], device=dev())
     y = _lib.process(OPS["Shr"], x, f)
     y0, x0, ch, cw = 1000, 2000, 96, 160
     crop = x[:, :, y0 - 1:y0 + ch + 1, x0 - 1:x0 + cw + 1].contiguous().cpu().numpy()
     ref = oracle_mod.forward(crop, oracle_mod.OPS["SHARPEN"], f.cpu().numpy(), clip=True)[:, :, 1:-1, 1:-1]
-    np.testing.assert_allclose(y[:, :, y0:y0 + ch, x0:x0 + cw].cpu().numpy(), ref, rtol=1e-5, atol=2e-6)
+    close("fullsize_4k_properties#3", y[:, :, y0:y0 + ch, x0:x0 + cw].cpu().numpy(), ref, rtol=1e-5, atol=2e-6)
     assert float(y.min()) >= 0.0 and float(y.max()) <= 1.0
     p = _lib.pool64(x)
-    torch.testing.assert_close(p, torch.nn.functional.adaptive_avg_pool2d(x, 64), rtol=1e-5, atol=1e-6)
+    close("fullsize_4k_properties#4", p, torch.nn.functional.adaptive_avg_pool2d(x, 64), rtol=1e-5, atol=1e-6)
 
 
 # ---- BASELINE.json sizes against the oracle itself ---------------------------------------------------------
@@ -344,8 +345,8 @@ def test_fullsize_episode_vs_oracle(oracle_mod, sched):
             if n in BIT_EXACT:
                 np.testing.assert_array_equal(out[b], ref[b], err_msg=f"step {k} image {b} {n}")
             else:
-                np.testing.assert_allclose(out[b], ref[b], rtol=RTOL, atol=ATOL, err_msg=f"step {k} image {b} {n}")
-        np.testing.assert_allclose(pooled.cpu().numpy(), oracle_mod.pool64(out), rtol=2e-6, atol=0)
+                close(f"fullsize_episode_vs_oracle:{n}", out[b], ref[b], rtol=RTOL, atol=ATOL, err_msg=f"step {k} image {b} {n}")
+        close("fullsize_episode_vs_oracle#2", pooled.cpu().numpy(), oracle_mod.pool64(out), rtol=2e-6, atol=0)
         chain = oracle_mod.forward(chain, ids, params, clip=True)
         x = y
     # end to end: five chained steps on each side. Differences of 1e-5 relative per step pass through sharpen's
@@ -365,6 +366,6 @@ def test_4k_denoise_sharpen_vs_oracle(oracle_mod):
     z = _lib.process(OPS["Shr"], y, f, clip=True)
     torch.cuda.synchronize()
     ref_y = oracle_mod.forward(x.cpu().numpy(), OPS["NLM"], h.cpu().numpy(), clip=True)
-    np.testing.assert_allclose(y.cpu().numpy(), ref_y, rtol=RTOL, atol=ATOL)
+    close("4k_denoise_sharpen_vs_oracle#1", y.cpu().numpy(), ref_y, rtol=RTOL, atol=ATOL)
     ref_z = oracle_mod.forward(y.cpu().numpy(), OPS["Shr"], f.cpu().numpy(), clip=True)
     np.testing.assert_array_equal(z.cpu().numpy(), ref_z)

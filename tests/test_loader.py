@@ -91,3 +91,20 @@ def test_lod_batches(tmp_path):
     assert abs(float(imgs[0, 0, 64 + 5, 5]) * 255 - src[:, :, 2].astype(np.float32)[3:5, 3:5].mean()) < 60
     big = batches[1][0]
     assert big.shape == (1, 3, 512, 512) and not big[0, :, :96].any()                 # 640x1024 -> 320x512, 96 black rows above
+
+
+def test_area_resize_integer_factors_round_like_resizeareafast():
+    """Exact 2x shrink: OpenCV's uint8 INTER_AREA takes the integer ResizeAreaFast path, (sum + 2) >> 2 — ties round half
+    UP, not to even; other integer factors cvRound(sum / area)."""
+    from adaptiveisp_amd.val.loader import resize_area_u8
+    im = np.zeros((4, 4, 1), np.uint8)
+    im[0:2, 0:2, 0] = [[1, 1], [0, 0]]            # sum 2 -> 0.5 -> 1 (half-to-even would give 0)
+    im[0:2, 2:4, 0] = [[3, 3], [2, 2]]            # sum 10 -> 2.5 -> 3 (half-to-even would give 2)
+    im[2:4, 0:2, 0] = [[255, 255], [255, 254]]    # sum 1019 -> 254.75 -> 255
+    out = resize_area_u8(im, (2, 2))[..., 0]
+    assert out.tolist() == [[1, 3], [255, 0]]
+    rng = np.random.default_rng(0)
+    big = rng.integers(0, 256, (9, 12, 3), dtype=np.uint8)
+    got = resize_area_u8(big, (4, 3))
+    want = np.rint(big.astype(np.float32).reshape(3, 3, 4, 3, 3).sum(axis=(1, 3)) * np.float32(1 / 9)).astype(np.uint8)
+    assert np.array_equal(got, want)

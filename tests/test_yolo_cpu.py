@@ -127,6 +127,10 @@ def test_host_target_assignment_equals_the_torch_one(seed):
         t[:, 1] = torch.randint(0, 80, (n,), generator=g).float()
         t[:, 2:4] = torch.rand(n, 2, generator=g)
         t[:, 4:6] = torch.rand(n, 2, generator=g) * 0.6 + 0.01
+        if n and b == 0:
+            t[0, 2] = 1.0                              # centre ON the far edge: gxy == nx, cell index clamped to nx - 1 and
+        if n > 1 and b == 1:                           # the box offset taken against the CLAMPED cell (loss.py:372-376)
+            t[1, 3] = 1.0
         labels.append(t)
     shapes = [types.SimpleNamespace(shape=(B, 3, 512 // s, (512 + 64 * seed) // s, 85), device=torch.device("cpu")) for s in (8, 16, 32)]
     want = pack_assigned(assign_labels(loss_fn, shapes, labels))
