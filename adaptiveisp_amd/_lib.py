@@ -19,9 +19,9 @@ NLM_EXACT = 2      # NLM patch sums in the reference's running-sum order (slower
 NLM_SEP_V1 = 4     # the compiler-scheduled form of the separable kernel (cross-check / measurement)
 NO_USM = 8         # adaisp_forward: no image selects the unsharp mask (its empty launch is skipped)
 NLM_TILE32 = 16    # the 32-row tile of the default NLM kernel (cross-check / measurement)
-ABI_VERSION = 3
+ABI_VERSION = 4
 
-EXPORTS = ("adaisp_forward", "adaisp_process", "adaisp_backward_params", "adaisp_pool64", "adaisp_pool64_backward", "adaisp_demosaic", "adaisp_num_params",
+EXPORTS = ("adaisp_forward", "adaisp_forward_uniform", "adaisp_process", "adaisp_backward_params", "adaisp_pool64", "adaisp_pool64_backward", "adaisp_demosaic", "adaisp_num_params",
            "adaisp_policy_conv", "adaisp_policy_fc1", "adaisp_policy_finish",
            "adaisp_strerror", "adaisp_abi_version")
 
@@ -43,6 +43,8 @@ def load():
     L = ctypes.CDLL(LIB_PATH)
     vp, ci, cu = ctypes.c_void_p, ctypes.c_int, ctypes.c_uint
     L.adaisp_forward.argtypes = [vp, vp, vp, vp, vp, ci, ci, ci, ci, cu, vp]
+    L.adaisp_forward_uniform.argtypes = [ci, vp, vp, vp, vp, ci, ci, ci, ci, cu, vp]
+    L.adaisp_forward_uniform.restype = ci
     L.adaisp_process.argtypes = [ci, vp, vp, vp, ci, ci, ci, ci, cu, vp]
     L.adaisp_backward_params.argtypes = [vp, vp, vp, vp, ci, vp, ci, ci, ci, cu, vp]
     L.adaisp_pool64.argtypes = [vp, vp, ci, ci, ci, vp]
@@ -77,6 +79,13 @@ def _dev_f32(t, name):
     return t.contiguous()
 
 
+def _wrote(t):
+    """A kernel wrote `t` through its raw pointer: tell torch (version counter), so that anything keyed on the tensor's
+    version — autograd's saved-tensor checks, Agent's cached pooling of its last output — sees the change."""
+    if t is not None:
+        torch.autograd.graph.increment_version(t)
+
+
 def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
@@ -101,29 +110,42 @@ def process(op, img, params, clip=False, out=None, nlm_exact=False, nlm_v1=False
                               (NLM_TILE32 if nlm_tile32 else 0),
                               _stream())
     _check(rc, "adaisp_process")
+    _wrote(out)
     return out
 
 
-def forward(img, op_ids, params, clip=True, pooled=None, out=None, nlm_exact=False, no_usm=False):
-    """adaisp_forward: image b is filtered by op_ids[b] (int32, device). params [B,stride]."""
+def forward(img, op_ids, params, clip=True, pooled=None, out=None, nlm_exact=False, no_usm=False, host_op=None):
+    """adaisp_forward: image b is filtered by op_ids[b] (int32, device). params [B,stride]. `pooled` ([B,3,64,64]) receives
+    the 64x64 pooling of the result (fused into the filter launch where the geometry allows). `host_op`: the caller KNOWS
+    that every op_ids[b] == host_op (a teacher-forced step) -> adaisp_forward_uniform, one launch instead of one per family."""
     L = load()
     img = _dev_f32(img, "img")
     B, H, W = _img_shape(img)
     params = _dev_f32(params.reshape(B, -1), "params")
-    if op_ids.dtype != torch.int32 or not op_ids.is_cuda:
-        raise TypeError("op_ids must be an int32 device tensor")
-    op_ids = op_ids.contiguous()
+    if host_op is None:
+        if op_ids.dtype != torch.int32 or not op_ids.is_cuda:
+            raise TypeError("op_ids must be an int32 device tensor")
+        op_ids = op_ids.contiguous()
+    if pooled is not None and (tuple(pooled.shape) != (B, 3, 64, 64) or pooled.dtype != torch.float32 or
+                               pooled.device != img.device or not pooled.is_contiguous()):
+        raise ValueError(f"pooled must be a contiguous float32 [{B},3,64,64] tensor on {img.device}")
     if out is None:
         out = torch.empty_like(img)
     elif (out.shape != img.shape or out.dtype != torch.float32 or out.device != img.device or not out.is_contiguous()):
         raise ValueError(f"out must be a contiguous float32 {tuple(img.shape)} tensor on {img.device}, got {out.dtype} "
                          f"{tuple(out.shape)} on {out.device}")
+    flags = (CLIP01 if clip else 0) | (NLM_EXACT if nlm_exact else 0) | (NO_USM if no_usm else 0)
     with torch.cuda.device(img.device):
-        rc = L.adaisp_forward(img.data_ptr(), out.data_ptr(), pooled.data_ptr() if pooled is not None else None,
-                              op_ids.data_ptr(), params.data_ptr(), params.shape[1], B, H, W,
-                              (CLIP01 if clip else 0) | (NLM_EXACT if nlm_exact else 0) | (NO_USM if no_usm else 0),
-                              _stream())
+        if host_op is not None:
+            rc = L.adaisp_forward_uniform(int(host_op), img.data_ptr(), out.data_ptr(),
+                                          pooled.data_ptr() if pooled is not None else None, params.data_ptr(),
+                                          params.shape[1], B, H, W, flags, _stream())
+        else:
+            rc = L.adaisp_forward(img.data_ptr(), out.data_ptr(), pooled.data_ptr() if pooled is not None else None,
+                                  op_ids.data_ptr(), params.data_ptr(), params.shape[1], B, H, W, flags, _stream())
     _check(rc, "adaisp_forward")
+    _wrote(out)
+    _wrote(pooled)
     return out
 
 
@@ -187,6 +209,7 @@ def demosaic(raw, pattern="RGGB", black_level=0.0, white_level=65535.0, out=None
         rc = L.adaisp_demosaic(raw.data_ptr(), out.data_ptr(), B, H, W, pat, float(black_level), float(white_level),
                                _stream())
     _check(rc, "adaisp_demosaic")
+    _wrote(out)
     return out
 
 

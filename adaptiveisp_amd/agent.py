@@ -9,6 +9,7 @@ caller can observe is unchanged: argument/return tuples, debug_info keys, state-
 state update, the penalty terms and the selection arithmetic (int64, bit-exact).
 """
 import math
+import weakref
 
 import torch
 import torch.nn as nn
@@ -66,6 +67,7 @@ class Agent(nn.Module):
         self._param_width = max(f.get_num_filter_parameters() for f in self.filters)
         self._fast = None            # fused eval path (policy_fast.FastPolicy), built on first use
         self._ones_mask = None
+        self._pool_cache = None      # (weakref to the image the last eval step returned, its version, its 64x64 pooling)
         self.use_fast_eval = True
 
     # ------------------------------------------------------------------------------------------
@@ -87,27 +89,48 @@ class Agent(nn.Module):
         return isp_apply_selected(img, packed, op_ids, clip=True)
 
     # ------------------------------------------------------------------------------------------
-    def plan_step(self, inp, progress, selected_filter_id=None):
+    def plan_step(self, inp, progress, selected_filter_id=None, pooled=None):
         """First half of an eval step on the fused kernels: 64x64 pooling + the policy (trunks, heads, selection, state
         update, penalties). Returns the step's decision — a dict of device tensors (`op_ids`, `packed` parameter rows,
-        `new_states`, `selected`, `pdf`, `params_all`, `surrogate`, `penalty`) — without touching the full-resolution
-        image. `apply_step` is the other half; `forward` in eval mode is the two in sequence (agent.py:88-285)."""
+        `new_states`, `selected`, `pdf`, `params_all`, `surrogate`, `penalty`) plus `host_op` (the kernel op code when
+        `selected_filter_id` forces it, else None) — without touching the full-resolution image. `pooled`: the
+        [B,3,64,64] pooling of x if the caller already has it (the previous step's `apply_step(..., pooled_next=)`
+        produced it in the filter launch); otherwise x is pooled here (adaisp_pool64, agent.py:97). `apply_step` is the
+        other half; `forward` in eval mode is the two in sequence (agent.py:88-285)."""
         x, z, states = inp
         if self._fast is None:
             from .policy_fast import FastPolicy
             self._fast = FastPolicy(self)
-        return self._fast.run(self.down_sample(x), z, states, progress, selected_filter_id)
+        if pooled is None:
+            pooled = self.down_sample(x)
+        plan = self._fast.run(pooled, z, states, progress, selected_filter_id)
+        plan["host_op"] = None if selected_filter_id is None else self._op_table_host[int(selected_filter_id) + 1]
+        return plan
 
-    def apply_step(self, x, plan, out=None):
+    def apply_step(self, x, plan, out=None, pooled_next=None):
         """Second half: the selected filter of every image on the full-resolution batch (one adaisp_forward call; `plan`
-        needs `op_ids` and `packed` only, so a caller may carry just those two between the halves)."""
+        needs `op_ids` and `packed` only — and `host_op` when the step was teacher-forced — so a caller may carry just
+        those between the halves). `pooled_next` ([B,3,64,64]) receives the 64x64 pooling of the result: the next step's
+        policy input, written by the same launch (agent.py:97 of the NEXT step)."""
         no_usm = _lib.OP_USM not in self._op_table_host
-        return _lib.forward(x, plan["op_ids"], plan["packed"], clip=True, no_usm=no_usm, out=out)
+        return _lib.forward(x, plan["op_ids"], plan["packed"], clip=True, no_usm=no_usm, out=out, pooled=pooled_next,
+                            host_op=plan.get("host_op"))
+
+    def _cached_pool(self, x):
+        """The pooling of x if x IS the tensor the previous eval step returned, unmodified since."""
+        c = self._pool_cache
+        if c is not None and c[0]() is x and x._version == c[1]:
+            return c[2]
+        return None
 
     def _forward_fast(self, x, z, states, progress, high_res, selected_filter_id, out=None):
         """Eval-mode step on the fused kernels: 7 launches instead of ~250 (see policy_fast.py)."""
-        o = self.plan_step((x, z, states), progress, selected_filter_id)
-        x_out = self.apply_step(x, o, out=out)
+        o = self.plan_step((x, z, states), progress, selected_filter_id, pooled=self._cached_pool(x))
+        # the filter launch also pools its result: an eval loop that feeds the returned image back in (val_adaptiveisp.py
+        # :293-304, the bench) never runs a separate pooling pass after the first step
+        pooled_next = torch.empty((x.shape[0], 3, 64, 64), dtype=torch.float32, device=x.device)
+        x_out = self.apply_step(x, o, out=out, pooled_next=pooled_next)
+        self._pool_cache = (weakref.ref(x_out), x_out._version, pooled_next)      # (_lib bumps the version of every tensor a kernel writes)
         hr_out = self.apply_step(high_res, o) if high_res is not None else None
         mask = self._ones_mask                      # Filter.get_mask with masking off (isp/filters.py:161-173): ones(1,1,1,1)
         if mask is None or mask.device != x.device:

@@ -97,23 +97,57 @@ int adaisp_process(int op, const float* img, float* out, const float* params, in
     return e == hipSuccess ? ADAISP_OK : ADAISP_ELAUNCH;
 }
 
+namespace {
+
+// One RL step for a batch: ids on the device (`filter_id`) or one host-known op (`filter_id` == NULL). With `pooled` the
+// next step's 64x64 planes come out of the SAME launches for the pointwise and stencil ops (window-aligned cut, PoolGeom);
+// NLM images (its 60 x 24 tiles cannot follow the 11.25-row pool windows without 7 % more tiles) are pooled by a launch
+// of their own, which returns at once for every other image — and is not enqueued at all when the host knows the op.
+int step_impl(const float* img, float* out, float* pooled, const int32_t* filter_id, int uniform_op, const float* params,
+              int param_stride, int B, int H, int W, unsigned flags, hipStream_t s) {
+    if (ranges_overlap(img, out, (long)B * 3 * H * W)) return ADAISP_EALIAS;
+    if (pooled && W > 16384) return ADAISP_ESHAPE;
+    if (H < 3 || W < 3) return ADAISP_ESHAPE;     // as adaisp_process: an image whose op is a stencil could not be served
+    Batch a{img, out, filter_id, uniform_op, params, param_stride, B, H, W, flags};
+    const bool host_op = filter_id == nullptr;
+    const bool pw = !host_op || op_is_pointwise(uniform_op), cv = !host_op || op_is_conv(uniform_op),
+               nl = !host_op || uniform_op == ADAISP_OP_NLM;
+    const PoolGeom g = pooled ? pool_geom(H, W, img, out) : PoolGeom{0, 0, false};
+    // The ids live on the device, so each kernel family is enqueued for the whole batch and its workgroups return at
+    // once for images whose op belongs to another family.
+    if (pw && (g.ok ? launch_pointwise_pool(a, pooled, g, s) : launch_pointwise(a, s)) != hipSuccess) return ADAISP_ELAUNCH;
+    if (cv && (g.ok ? launch_conv_pool(a, pooled, g, s) : launch_conv(a, s)) != hipSuccess) return ADAISP_ELAUNCH;
+    if (nl && launch_nlm(a, s) != hipSuccess) return ADAISP_ELAUNCH;
+    if (pooled) {
+        if (!g.ok) {
+            if (launch_pool64(out, pooled, B, H, W, s) != hipSuccess) return ADAISP_ELAUNCH;
+        } else if (nl && launch_pool64_sel(out, pooled, filter_id, uniform_op, true, flags, B, H, W, s) != hipSuccess) {
+            return ADAISP_ELAUNCH;
+        }
+    }
+    return ADAISP_OK;
+}
+
+}  // namespace
+
 int adaisp_forward(const float* img, float* out, float* pooled64_next, const int32_t* filter_id, const float* params,
                    int param_stride, int B, int H, int W, unsigned flags, void* stream) {
     int rc = check_common(img, out, params, param_stride, B, H, W);
     if (rc) return rc;
     if (!filter_id) return ADAISP_EINVAL;
-    if (ranges_overlap(img, out, (long)B * 3 * H * W)) return ADAISP_EALIAS;
-    if (pooled64_next && W > 16384) return ADAISP_ESHAPE;
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    Batch a{img, out, filter_id, 0, params, param_stride, B, H, W, flags};
-    // The ids live on the device, so each kernel family is enqueued for the whole batch and its
-    // workgroups return at once for images whose op belongs to another family.
-    if (H < 3 || W < 3) return ADAISP_ESHAPE;     // as adaisp_process: an image whose op is a stencil could not be served
-    if (launch_pointwise(a, s) != hipSuccess) return ADAISP_ELAUNCH;
-    if (launch_conv(a, s) != hipSuccess) return ADAISP_ELAUNCH;
-    if (launch_nlm(a, s) != hipSuccess) return ADAISP_ELAUNCH;
-    if (pooled64_next && launch_pool64(out, pooled64_next, B, H, W, s) != hipSuccess) return ADAISP_ELAUNCH;
-    return ADAISP_OK;
+    return step_impl(img, out, pooled64_next, filter_id, 0, params, param_stride, B, H, W, flags,
+                     static_cast<hipStream_t>(stream));
+}
+
+int adaisp_forward_uniform(int op, const float* img, float* out, float* pooled64_next, const float* params,
+                           int param_stride, int B, int H, int W, unsigned flags, void* stream) {
+    int rc = check_common(img, out, params, param_stride, B, H, W);
+    if (rc) return rc;
+    const int np = adaisp_num_params(op);
+    if (np < 0) return ADAISP_EOP;
+    if (np > param_stride) return ADAISP_EINVAL;
+    return step_impl(img, out, pooled64_next, nullptr, op, params, param_stride, B, H, W, flags,
+                     static_cast<hipStream_t>(stream));
 }
 
 int adaisp_backward_params(const float* img, const float* grad_out, const int32_t* filter_id, const float* params,

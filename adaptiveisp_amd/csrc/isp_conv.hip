@@ -210,19 +210,21 @@ __device__ __forceinline__ void finish_row(const RawRow& r, bool active, bool ed
     else { v[0] = l2; v[1] = l1; v[6] = r1; v[7] = r2; }
 }
 
+// The walk itself. The wave's lanes cover pixels gx = x_first + 4 * lane < x_read_end of plane `src`; output rows
+// [y_begin, y_end) are computed, rows < y_store_end and pixels < x_store_end are stored (the fused-pooling cut computes
+// the row / quad it shares with the next pool window without storing it). `colsum` accumulates the lane's four output
+// columns over the computed rows, ascending y from its initial value (the pooled planes' column sums).
 template <int R, int MODE, int NG>
-__device__ void conv_rows(const float* __restrict__ in, float* __restrict__ out, const float* __restrict__ p, int H,
-                          int W, int c, int strip, int band, int rs) {
+__device__ void conv_rows_core(const float* __restrict__ src, float* __restrict__ dst, const float* __restrict__ p, int H,
+                               int W, int x_first, int x_read_end, int x_store_end, int y_begin, int y_end,
+                               int y_store_end, float (&colsum)[4]) {
     constexpr int G = 2 * R + 1, GS = G * NG;        // ring period, rows per pipeline group
     const int lane = threadIdx.x & 63;
-    const long plane = (long)H * W;
-    const float* src = in + c * plane;
-    float* dst = out + c * plane;
-    const int gx = strip * 256 + 4 * lane;
-    const bool active = gx < W;                      // W % 4 == 0 on this path
+    const int gx = x_first + 4 * lane;
+    const bool active = gx < x_read_end;             // W % 4 == 0 on this path
     const bool last_col = active && gx + 4 >= W;
-    const bool edge_l = lane == 0, edge_r = lane == 63 && active && !last_col;
-    const int y_begin = band * rs, y_end = min(H, y_begin + rs);
+    const bool edge_l = lane == 0, edge_r = active && gx + 4 >= x_read_end && !last_col;
+    const bool store_x = active && gx < x_store_end;
 
     float w[G][G];
     float amount;
@@ -292,11 +294,25 @@ __device__ void conv_rows(const float* __restrict__ in, float* __restrict__ out,
                 const float r = (MODE == kAdjust) ? ctr * amount + blur * (1.0f - amount) : ctr + (ctr - blur) * amount;
                 o[k] = clamp01(r);
             }
-            if (active && y < y_end) *reinterpret_cast<float4*>(dst + (long)y * W + gx) = make_float4(o[0], o[1], o[2], o[3]);
+            if (y < y_end) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) colsum[k] += o[k];
+                if (store_x && y < y_store_end) *reinterpret_cast<float4*>(dst + (long)y * W + gx) = make_float4(o[0], o[1], o[2], o[3]);
+            }
         }
 #pragma unroll
         for (int u = 0; u < GS; ++u) cur[u] = nxt[u];
     }
+}
+
+template <int R, int MODE, int NG>
+__device__ __forceinline__ void conv_rows(const float* __restrict__ in, float* __restrict__ out, const float* __restrict__ p,
+                                          int H, int W, int c, int strip, int band, int rs) {
+    const long plane = (long)H * W;
+    const int x_end = min(W, strip * 256 + 256), y_begin = band * rs, y_end = min(H, y_begin + rs);
+    float unused[4] = {0.f, 0.f, 0.f, 0.f};
+    conv_rows_core<R, MODE, NG>(in + c * plane, out + c * plane, p, H, W, strip * 256, x_end, x_end, y_begin, y_end, y_end,
+                                unused);
 }
 
 // R = 1: the two 3x3 sharpeners; R = 2: the 5x5 unsharp mask (its own kernel: the 5-row pipeline needs 134 VGPRs, which
@@ -321,6 +337,43 @@ __global__ __launch_bounds__(kThreads) void k_conv_rows(const float* __restrict_
     else conv_rows<1, kSharpness, NG>(img + off, out + off, p, H, W, c, strip, band, rs);
 }
 
+// The same walk cut along the pool windows, with the next step's 64x64 pooling fused (isp_internal.h: PoolGeom): a wave =
+// one strip of pool columns x one pool row x one plane; workgroup = the strips of (pool row, plane).
+template <int R>
+__global__ __launch_bounds__(1024) void k_conv_rows_pool(const float* __restrict__ img, float* __restrict__ out,
+                                                         float* __restrict__ pooled, const int32_t* __restrict__ ids,
+                                                         int uniform_op, const float* __restrict__ params, int pstride,
+                                                         int H, int W, int cps) {
+    extern __shared__ __attribute__((aligned(16))) float colsum_lds[];   // [waves][256]
+    const int b = blockIdx.z;
+    const int op = ids ? ids[b] : uniform_op;
+    if (R == 1 && op != ADAISP_OP_SHARPEN && op != ADAISP_OP_SHARPEN_V2) return;
+    if (R == 2 && op != ADAISP_OP_USM) return;
+    const int oy = blockIdx.x, c = blockIdx.y;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const long plane = (long)H * W;
+    const float* src = img + ((long)b * 3 + c) * plane;
+    float* dst = out + ((long)b * 3 + c) * plane;
+    const float* p = params + (long)b * pstride;
+    const int ys = win_lo(oy, H), ye = win_hi(oy, H), y_own_end = oy == 63 ? H : win_lo(oy + 1, H);
+    const int x_lo = strip_x_lo(wave, cps, W), x_end = strip_x_end(wave, cps, W), x_own_end = strip_x_lo(wave + 1, cps, W);
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    if (R == 2) conv_rows_core<2, kUSM, 1>(src, dst, p, H, W, x_lo, x_end, x_own_end, ys, ye, y_own_end, acc);
+    else if (op == ADAISP_OP_SHARPEN) conv_rows_core<1, kAdjust, 1>(src, dst, p, H, W, x_lo, x_end, x_own_end, ys, ye, y_own_end, acc);
+    else conv_rows_core<1, kSharpness, 1>(src, dst, p, H, W, x_lo, x_end, x_own_end, ys, ye, y_own_end, acc);
+    float* cs = colsum_lds + wave * 256;
+    *reinterpret_cast<float4*>(cs + 4 * lane) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    __syncthreads();
+    const int c0 = strip_cell0(wave, cps), ncell = strip_cell0(wave + 1, cps) - c0;
+    if (lane < ncell) {
+        const int ox = c0 + lane;
+        const int xs = win_lo(ox, W), xe = win_hi(ox, W);
+        float a = 0.f;
+        for (int xx = xs; xx < xe; ++xx) a += cs[xx - x_lo];
+        pooled[(((long)b * 3 + c) * 64 + oy) * 64 + ox] = a / (float)(ye - ys) / (float)(xe - xs);
+    }
+}
+
 template <bool VEC>
 __global__ __launch_bounds__(kThreads) void k_conv(const float* __restrict__ img, float* __restrict__ out,
                                                    const int32_t* __restrict__ ids, int uniform_op,
@@ -339,6 +392,20 @@ __global__ __launch_bounds__(kThreads) void k_conv(const float* __restrict__ img
 }
 
 }  // namespace
+
+hipError_t launch_conv_pool(const Batch& a, float* pooled, const PoolGeom& g, hipStream_t s) {
+    const bool want3 = a.ids ? true : (a.uniform_op == ADAISP_OP_SHARPEN || a.uniform_op == ADAISP_OP_SHARPEN_V2);
+    const bool want5 = a.ids ? !(a.flags & ADAISP_NO_USM) : (a.uniform_op == ADAISP_OP_USM);
+    const dim3 grid(64, 3, a.B), block(64 * g.strips);
+    const size_t smem = (size_t)g.strips * 256 * sizeof(float);
+    if (want3)
+        hipLaunchKernelGGL(k_conv_rows_pool<1>, grid, block, smem, s, a.img, a.out, pooled, a.ids, a.uniform_op, a.params,
+                           a.pstride, a.H, a.W, g.cps);
+    if (want5)
+        hipLaunchKernelGGL(k_conv_rows_pool<2>, grid, block, smem, s, a.img, a.out, pooled, a.ids, a.uniform_op, a.params,
+                           a.pstride, a.H, a.W, g.cps);
+    return hipGetLastError();
+}
 
 hipError_t launch_conv(const Batch& a, hipStream_t s) {
     const bool vec = (a.W % 4 == 0) && (a.W >= 8) && ((reinterpret_cast<uintptr_t>(a.img) & 15) == 0) &&

@@ -30,7 +30,48 @@ __host__ __device__ inline bool op_is_conv(int op) {
     return op == ADAISP_OP_SHARPEN || op == ADAISP_OP_SHARPEN_V2 || op == ADAISP_OP_USM;
 }
 
+// ---- AdaptiveAvgPool2d((64,64)) window rule (PyTorch): cell o covers [floor(o*n/64), ceil((o+1)*n/64)) -----------
+__host__ __device__ inline int win_lo(int o, int n) { return (int)(((long)o * n) / 64); }
+__host__ __device__ inline int win_hi(int o, int n) { return (int)((((long)(o + 1)) * n + 63) / 64); }
+
+// Fused pooling geometry: the pixel kernels that also produce the next step's 64x64 pooled planes are cut along the
+// pool windows. A WAVE owns a "strip" = `cps` consecutive pool columns (its quad-aligned pixel span <= 256 = 64 lanes x
+// 4 px), a WORKGROUP the `strips` strips of one pool row `oy` (rows win_lo(oy,H) .. win_hi(oy,H)). Rows / quads that
+// belong to two windows are READ (and computed) by both owners and WRITTEN by the first. Column sums run down the
+// window's rows in a lane's registers (ascending y from 0.0f), the x-window sums ascending x from 0.0f through LDS —
+// exactly k_pool64's order, so fused and stand-alone pooling are bit-identical.
+struct PoolGeom {
+    int cps, strips;
+    bool ok;
+};
+__host__ __device__ inline int strip_cell0(int s, int cps) { return s * cps < 64 ? s * cps : 64; }
+__host__ __device__ inline int strip_x_lo(int s, int cps, int W) {               // first pixel a strip reads AND owns
+    return strip_cell0(s, cps) >= 64 ? W : (win_lo(strip_cell0(s, cps), W) & ~3);
+}
+__host__ __device__ inline int strip_x_end(int s, int cps, int W) {              // one past the last pixel it reads
+    return (win_hi(strip_cell0(s + 1, cps) - 1, W) + 3) & ~3;
+}
+inline PoolGeom pool_geom(int H, int W, const void* img, const void* out) {
+    PoolGeom g{0, 0, false};
+    if (H < 64 || W < 64 || (W & 3) || (reinterpret_cast<uintptr_t>(img) & 15) || (reinterpret_cast<uintptr_t>(out) & 15))
+        return g;
+    for (int strips = 1; strips <= 16; ++strips) {
+        const int cps = (64 + strips - 1) / strips;
+        if ((64 + cps - 1) / cps != strips) continue;
+        bool fits = true;
+        for (int s = 0; s < strips && fits; ++s) fits = strip_x_end(s, cps, W) - strip_x_lo(s, cps, W) <= 256;
+        if (fits) { g.cps = cps; g.strips = strips; g.ok = true; return g; }
+    }
+    return g;
+}
+
 hipError_t launch_pointwise(const Batch& a, hipStream_t s);
+hipError_t launch_pointwise_pool(const Batch& a, float* pooled, const PoolGeom& g, hipStream_t s);
+hipError_t launch_conv_pool(const Batch& a, float* pooled, const PoolGeom& g, hipStream_t s);
+// pooling of `img` for the images the fused kernels did not serve: with `only_unfused` an image is skipped unless its op
+// is NLM (ids on the device, or `uniform_op`)
+hipError_t launch_pool64_sel(const float* img, float* pooled, const int32_t* ids, int uniform_op, bool only_unfused,
+                             unsigned flags, int B, int H, int W, hipStream_t s);
 hipError_t launch_conv(const Batch& a, hipStream_t s);     // 3x3 sharpen, 3x3 sharpness, 5x5 USM
 hipError_t launch_nlm(const Batch& a, hipStream_t s);
 hipError_t launch_pool64(const float* img, float* pooled, int B, int H, int W, hipStream_t s);

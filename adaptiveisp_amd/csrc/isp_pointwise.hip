@@ -280,7 +280,106 @@ __global__ __launch_bounds__(kThreads) void k_pointwise(const float* __restrict_
     }
 }
 
+// ---- the same ops with the next step's 64x64 pooling fused (agent.py:97 applied to this step's output) ---------
+// One wave = one strip of pool columns x one pool row (isp_internal.h: PoolGeom); the lane owns a pixel quad and walks
+// the window's rows, four rows (12 x 16-B loads) in flight; the three planes' column sums stay in registers.
+template <class OP>
+__device__ __forceinline__ void stream_pool(const float* __restrict__ in, float* __restrict__ out,
+                                            const float* __restrict__ p, int H, int W, int ys, int ye, int y_own_end,
+                                            int x, bool active, bool own_x, const Clip clip, float4 (&acc)[3]) {
+    OP op;
+    op.init(p);
+    const long plane = (long)H * W;
+    const int xs = active ? x : 0;                      // inactive lanes read a valid quad and drop it
+    for (int y0 = ys; y0 < ye; y0 += 4) {
+        float4 r[4], g[4], b[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const long o = (long)min(y0 + u, ye - 1) * W + xs;
+            r[u] = *reinterpret_cast<const float4*>(in + o);
+            g[u] = *reinterpret_cast<const float4*>(in + plane + o);
+            b[u] = *reinterpret_cast<const float4*>(in + 2 * plane + o);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int y = y0 + u;
+            if (y < ye) {
+                apply4(op, r[u], g[u], b[u], clip);
+                if (active) {
+                    acc[0].x += r[u].x; acc[0].y += r[u].y; acc[0].z += r[u].z; acc[0].w += r[u].w;
+                    acc[1].x += g[u].x; acc[1].y += g[u].y; acc[1].z += g[u].z; acc[1].w += g[u].w;
+                    acc[2].x += b[u].x; acc[2].y += b[u].y; acc[2].z += b[u].z; acc[2].w += b[u].w;
+                    if (own_x && y < y_own_end) {
+                        const long o = (long)y * W + x;
+                        *reinterpret_cast<float4*>(out + o) = r[u];
+                        *reinterpret_cast<float4*>(out + plane + o) = g[u];
+                        *reinterpret_cast<float4*>(out + 2 * plane + o) = b[u];
+                    }
+                }
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(1024) void k_pointwise_pool(const float* __restrict__ img, float* __restrict__ out,
+                                                         float* __restrict__ pooled, const int32_t* __restrict__ ids,
+                                                         int uniform_op, const float* __restrict__ params, int pstride,
+                                                         int H, int W, int cps, unsigned flags) {
+    extern __shared__ __attribute__((aligned(16))) float colsum[];      // [waves][3][256]
+    const int oy = blockIdx.x, b = blockIdx.y;
+    int op = ids ? ids[b] : uniform_op;
+    if (op_is_conv(op) || op == ADAISP_OP_NLM) return;                   // block-uniform: the whole workgroup leaves
+    if (!op_is_pointwise(op)) op = ADAISP_OP_ZERO;                       // unknown id (device data): the zero image, like -1
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const long plane = (long)H * W;
+    const float* in = img + (long)b * 3 * plane;
+    float* o = out + (long)b * 3 * plane;
+    const float* p = params + (long)b * pstride;
+    const Clip clip((flags & ADAISP_CLIP01) != 0);
+    const int ys = win_lo(oy, H), ye = win_hi(oy, H);
+    const int y_own_end = oy == 63 ? H : win_lo(oy + 1, H);
+    const int x_lo = strip_x_lo(wave, cps, W), x_end = strip_x_end(wave, cps, W);
+    const int x = x_lo + 4 * lane;
+    const bool active = x < x_end, own_x = x < strip_x_lo(wave + 1, cps, W);
+    float4 acc[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) acc[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+    switch (op) {
+        case ADAISP_OP_ZERO:     stream_pool<OpZero>(in, o, p, H, W, ys, ye, y_own_end, x, active, own_x, clip, acc); break;
+        case ADAISP_OP_EXPOSURE: stream_pool<OpExposure>(in, o, p, H, W, ys, ye, y_own_end, x, active, own_x, clip, acc); break;
+        case ADAISP_OP_GAMMA:    stream_pool<OpGamma>(in, o, p, H, W, ys, ye, y_own_end, x, active, own_x, clip, acc); break;
+        case ADAISP_OP_WB:       stream_pool<OpWB>(in, o, p, H, W, ys, ye, y_own_end, x, active, own_x, clip, acc); break;
+        case ADAISP_OP_CCM:      stream_pool<OpCCM>(in, o, p, H, W, ys, ye, y_own_end, x, active, own_x, clip, acc); break;
+        case ADAISP_OP_TONE:     stream_pool<OpTone>(in, o, p, H, W, ys, ye, y_own_end, x, active, own_x, clip, acc); break;
+        case ADAISP_OP_COLOR:    stream_pool<OpColor>(in, o, p, H, W, ys, ye, y_own_end, x, active, own_x, clip, acc); break;
+        case ADAISP_OP_CONTRAST: stream_pool<OpContrast>(in, o, p, H, W, ys, ye, y_own_end, x, active, own_x, clip, acc); break;
+        case ADAISP_OP_WNB:      stream_pool<OpWNB>(in, o, p, H, W, ys, ye, y_own_end, x, active, own_x, clip, acc); break;
+        case ADAISP_OP_SATPLUS:  stream_pool<OpSatPlus>(in, o, p, H, W, ys, ye, y_own_end, x, active, own_x, clip, acc); break;
+        default: break;
+    }
+    float* cs = colsum + wave * 3 * 256;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) *reinterpret_cast<float4*>(cs + c * 256 + 4 * lane) = acc[c];
+    __syncthreads();
+    const int c0 = strip_cell0(wave, cps), ncell = strip_cell0(wave + 1, cps) - c0;
+    const float kh = (float)(ye - ys);
+    for (int i = lane; i < 3 * ncell; i += 64) {
+        const int c = i / ncell, ox = c0 + (i - c * ncell);
+        const int xs = win_lo(ox, W), xe = win_hi(ox, W);
+        const float* col = cs + c * 256 - x_lo;
+        float a = 0.f;
+        for (int xx = xs; xx < xe; ++xx) a += col[xx];
+        pooled[(((long)b * 3 + c) * 64 + oy) * 64 + ox] = a / kh / (float)(xe - xs);
+    }
+}
+
 }  // namespace
+
+hipError_t launch_pointwise_pool(const Batch& a, float* pooled, const PoolGeom& g, hipStream_t s) {
+    hipLaunchKernelGGL(k_pointwise_pool, dim3(64, (unsigned)a.B), dim3(64 * g.strips), (size_t)g.strips * 3 * 256 * sizeof(float),
+                       s, a.img, a.out, pooled, a.ids, a.uniform_op, a.params, a.pstride, a.H, a.W, g.cps, a.flags);
+    return hipGetLastError();
+}
 
 hipError_t launch_pointwise(const Batch& a, hipStream_t s) {
     const long plane = (long)a.H * a.W;

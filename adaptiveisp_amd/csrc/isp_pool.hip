@@ -13,18 +13,19 @@ namespace {
 
 constexpr int kThreads = 256;
 
-__device__ __forceinline__ int win_lo(int o, int n) { return (int)(((long)o * n) / 64); }
-__device__ __forceinline__ int win_hi(int o, int n) { return (int)((((long)(o + 1)) * n + 63) / 64); }
-
 // grid: (64 output rows, B, XCH column chunks of 64/XCH output cells); rows of the window are unrolled 4-deep so
 // several 16-B loads per lane are in flight.
 constexpr int XCH = 4;
 
+// `only_nlm`: pool only the images whose op is NLM (the pointwise and stencil kernels of the same RL step have already
+// written the pooled planes of theirs, fused: isp_internal.h PoolGeom); ids on the device or one host-known op.
 template <bool VEC>
 __global__ __launch_bounds__(kThreads) void k_pool64(const float* __restrict__ img, float* __restrict__ pooled,
-                                                     int H, int W) {
+                                                     int H, int W, const int32_t* __restrict__ ids, int uniform_op,
+                                                     int only_nlm) {
     extern __shared__ __attribute__((aligned(16))) float colsum[];   // [3][span] column sums of this chunk
     const int oy = blockIdx.x, b = blockIdx.y, ch = blockIdx.z;
+    if (only_nlm && (ids ? ids[b] : uniform_op) != ADAISP_OP_NLM) return;
     const int ox0 = ch * (64 / XCH), ox1 = ox0 + 64 / XCH;
     const int ys = win_lo(oy, H), ye = win_hi(oy, H);
     const int x_lo = win_lo(ox0, W) & ~3, x_hi = win_hi(ox1 - 1, W);  // quad-aligned start of the chunk's columns
@@ -100,13 +101,19 @@ hipError_t launch_pool64_bwd(const float* grad_pooled, float* grad_img, int B, i
     return hipGetLastError();
 }
 
-hipError_t launch_pool64(const float* img, float* pooled, int B, int H, int W, hipStream_t s) {
+hipError_t launch_pool64_sel(const float* img, float* pooled, const int32_t* ids, int uniform_op, bool only_unfused,
+                             unsigned flags, int B, int H, int W, hipStream_t s) {
+    (void)flags;
     const bool vec = (W % 4 == 0) && ((reinterpret_cast<uintptr_t>(img) & 15) == 0);
     dim3 grid(64, B, XCH);
     const size_t smem = 3 * ((size_t)(W + XCH - 1) / XCH + 16 + W / 64) * sizeof(float);   // >= 3 x padded chunk span
-    if (vec) hipLaunchKernelGGL(k_pool64<true>, grid, dim3(kThreads), smem, s, img, pooled, H, W);
-    else hipLaunchKernelGGL(k_pool64<false>, grid, dim3(kThreads), smem, s, img, pooled, H, W);
+    if (vec) hipLaunchKernelGGL(k_pool64<true>, grid, dim3(kThreads), smem, s, img, pooled, H, W, ids, uniform_op, only_unfused ? 1 : 0);
+    else hipLaunchKernelGGL(k_pool64<false>, grid, dim3(kThreads), smem, s, img, pooled, H, W, ids, uniform_op, only_unfused ? 1 : 0);
     return hipGetLastError();
+}
+
+hipError_t launch_pool64(const float* img, float* pooled, int B, int H, int W, hipStream_t s) {
+    return launch_pool64_sel(img, pooled, nullptr, 0, false, 0u, B, H, W, s);
 }
 
 }  // namespace adaisp

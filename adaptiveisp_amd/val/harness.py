@@ -15,11 +15,12 @@ from .nms import non_max_suppression
 
 
 def run_eval(agent, detector, batches, cfg, steps=5, conf_thres=0.001, iou_thres=0.6, max_det=300, single_cls=False,
-             pipeline=None, records_path=None, nc=80, nms_fn=None, param_dir=None):
+             pipeline=None, records_path=None, nc=80, nms_fn=None, param_dir=None, details=None):
     """Returns dict(mp, mr, map50, map75, map, seen, nt, ap_class, ap, records). `detector(x)` -> [B, N, 5+nc]
     decoded predictions (YoloEngine or the module tree in eval mode). `pipeline`: optional list of forced filter ids
     per step (val_adaptiveisp.py:292, --pipeline). `param_dir`: write one JSON per batch (named after its first image) with
-    the chosen filter ids and image 0's regressed parameters per step, as `--save_param` does (:296-301,324-327)."""
+    the chosen filter ids and image 0's regressed parameters per step, as `--save_param` does (:296-301,324-327).
+    `details`: a list that receives one dict per image (path, retouched image, detections after NMS, `correct` matrix)."""
     import collections
     import json
     from ..util import get_initial_states, get_noise
@@ -67,6 +68,9 @@ def run_eval(agent, detector, batches, cfg, steps=5, conf_thres=0.001, iou_thres
             shape = shapes[si][0]
             correct = torch.zeros(npr, niou, dtype=torch.bool, device=dev)
             seen += 1
+            if details is not None:
+                details.append(dict(path=str(paths[si]), retouch=retouch[si].detach().cpu(), pred=pred.detach().cpu().clone(),
+                                    correct=None))
             if npr == 0:
                 if nl:
                     stats.append((correct, *torch.zeros((2, 0), device=dev), labels[:, 0]))
@@ -80,6 +84,8 @@ def run_eval(agent, detector, batches, cfg, steps=5, conf_thres=0.001, iou_thres
                 scale_boxes(im[si].shape[1:], tbox, shape, shapes[si][1])
                 labelsn = torch.cat((labels[:, 0:1], tbox), 1)
                 correct = process_batch(predn, labelsn, iouv)
+            if details is not None:
+                details[-1]["correct"] = correct.detach().cpu()
             stats.append((correct, pred[:, 4], pred[:, 5], labels[:, 0]))
     res = dict(mp=0.0, mr=0.0, map50=0.0, map75=0.0, map=0.0, seen=seen, ap_class=np.zeros(0, int), ap=np.zeros((0, niou)),
                records=records, filter_names=filter_names)

@@ -107,7 +107,9 @@ def non_max_suppression(prediction, conf_thres=0.25, iou_thres=0.45, classes=Non
         if n == 0:
             output.append(torch.zeros((0, 6 + nm), device=prediction.device))
             continue
-        seg = seg[seg[:, 4].argsort(descending=True)[:MAX_NMS]]
+        # stable: equal scores keep candidate order, so the CPU and the GPU run of the loop see the same list (the
+        # reference's argsort leaves the order of ties to the backend)
+        seg = seg[seg[:, 4].argsort(descending=True, stable=True)[:MAX_NMS]]
         offset = seg[:, 5:6] * (0 if agnostic else MAX_WH)         # classes never suppress each other
         kept = nms_fn(seg[:, :4] + offset, seg[:, 4], iou_thres)[:max_det]
         output.append(seg[kept])

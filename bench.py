@@ -94,25 +94,32 @@ def build_workload(a, dev):
     s0 = torch.zeros(a.batch, cfg.num_state_dim, device=dev)
     sched = SCHEDULES[a.schedule]
 
-    def isp_chain(out=None, start=0, stop=None, carry=None, with_carry=False):
-        """The 5-step episode, or a slice of it in HALF-steps: half-step 2i is step i's pooling + policy
-        (Agent.plan_step), 2i+1 its filter on the full-resolution batch (Agent.apply_step); `carry` = (image, states,
-        pending plan) continues a slice. `out`: where the slice's last filter writes (the pipeline's hand-over /
-        mid-episode buffer). Half-steps [0, 2*len(sched)) in order are exactly Agent.forward step by step."""
+    def isp_chain(out=None, start=0, stop=None, carry=None, with_carry=False, pooled_out=None):
+        """The 5-step episode, or a slice of it in HALF-steps: half-step 2i is step i's policy on the 64x64 pooling of
+        its input (Agent.plan_step), 2i+1 its filter on the full-resolution batch (Agent.apply_step), which ALSO writes
+        the pooling of its result — the next step's policy input — in the same launch; only the episode's first image is
+        pooled by a launch of its own. `carry` = (image, states, pending plan, pooled planes of the image) continues a
+        slice. `out` / `pooled_out`: where the slice's last filter writes (the pipeline's hand-over / mid-episode
+        buffers). Half-steps [0, 2*len(sched)) in order are exactly Agent.forward step by step."""
         stop = 2 * len(sched) if stop is None else stop
         if raw is not None and start == 0 and carry is None:
             isp_lib.demosaic(raw, out=x0)                  # --raw: the episode starts from the Bayer plane
-        x, st, plan = carry if carry is not None else (x0, s0, None)
+        x, st, plan, pooled = carry if carry is not None else (x0, s0, None, None)
         last_apply = max((h for h in range(start, stop) if h & 1), default=-1)
         with torch.no_grad():
             for h in range(start, stop):
                 if h & 1:
-                    x = agent.apply_step(x, plan, out=out if h == last_apply else None)
+                    last = h == last_apply
+                    if (h >> 1) + 1 < len(sched):          # a next step exists: its policy input comes out of this launch
+                        pooled = pooled_out if (last and pooled_out is not None) else x0.new_empty((a.batch, 3, 64, 64))
+                    else:
+                        pooled = None
+                    x = agent.apply_step(x, plan, out=out if last else None, pooled_next=pooled)
                     plan = None
                 else:
-                    plan = agent.plan_step((x, z, st), 1.0, selected_filter_id=sched[h >> 1])
-                    st = plan["new_states"]
-        return (x, st, plan) if with_carry else x
+                    plan = agent.plan_step((x, z, st), 1.0, selected_filter_id=sched[h >> 1], pooled=pooled)
+                    st, pooled = plan["new_states"], None
+        return (x, st, plan, pooled) if with_carry else x
 
     def step():
         x = isp_chain()
@@ -148,7 +155,7 @@ def build_pipeline(step, engine, x0, cut=None, gate=None):
     if not 0 <= cut < nh:
         raise ValueError(f"cut={cut} outside the {nh} half-steps of the episode")
     xbuf = [torch.empty_like(x0), torch.empty_like(x0)]
-    mid = [None, None]                                    # per slot: (image, states, op ids, packed parameter rows)
+    mid = [None, None]                                    # per slot: image, states, op ids, packed parameter rows, host-known op, pooled planes
     side = torch.cuda.Stream()
     # both stages on ordinary-priority streams: a high-priority stream for the ISP chain was measured 26 % SLOWER
     # (1039 vs 1407 images/s) — its NLM workgroups then pre-empt the detector's at every CU hand-over
@@ -156,18 +163,20 @@ def build_pipeline(step, engine, x0, cut=None, gate=None):
 
     def head(p):                                          # half-steps 0 .. cut-1 of a fresh batch -> mid-episode slot p
         if mid[p] is None:
-            x, st, plan = step.isp_chain(stop=cut, with_carry=True)
+            x, st, plan, pooled = step.isp_chain(stop=cut, with_carry=True)
             mid[p] = [torch.empty_like(x0) if cut > 1 else None, torch.empty_like(st),
-                      torch.empty_like(plan["op_ids"]) if plan else None, torch.empty_like(plan["packed"]) if plan else None]
-        x, st, plan = step.isp_chain(out=mid[p][0], stop=cut, with_carry=True)
+                      torch.empty_like(plan["op_ids"]) if plan else None, torch.empty_like(plan["packed"]) if plan else None,
+                      plan["host_op"] if plan else None, torch.empty_like(pooled) if pooled is not None else None]
+        x, st, plan, pooled = step.isp_chain(out=mid[p][0], stop=cut, with_carry=True, pooled_out=mid[p][5])
         mid[p][1].copy_(st)
         if plan:
             mid[p][2].copy_(plan["op_ids"])
             mid[p][3].copy_(plan["packed"])
 
     def carry(p):
-        img, st, ids, packed = mid[p]
-        return (img if img is not None else x0, st, {"op_ids": ids, "packed": packed} if ids is not None else None)
+        img, st, ids, packed, host_op, pooled = mid[p]
+        return (img if img is not None else x0, st,
+                {"op_ids": ids, "packed": packed, "host_op": host_op} if ids is not None else None, pooled)
 
     if cut:                                               # slots exist before capture (their addresses are baked in)
         head(0); head(1)

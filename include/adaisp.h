@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define ADAISP_ABI_VERSION 3
+#define ADAISP_ABI_VERSION 4
 
 /* Kernel op codes. 0..9 follow the reference's default filter order (config.py:19-22). */
 enum adaisp_op {
@@ -71,12 +71,24 @@ enum adaisp_op {
  * `filter_id` lives on the device (no host sync is needed to pick the work); -1 — and any id outside enum adaisp_op —
  * writes zeros (the reference's all-zero one-hot row).
  * If `pooled64_next` != NULL it receives AdaptiveAvgPool2d((64,64)) of `out`
- * ([B,3,64,64]; agent.py:97 / value.py:63) for the next step's policy input.
+ * ([B,3,64,64]; agent.py:97 / value.py:63) for the next step's policy input — from the SAME launch for the pointwise
+ * and 3x3 / 5x5 stencil ops (the kernels are cut along the pool windows; rows 16-byte aligned, H, W >= 64, pool columns
+ * <= 64 px wide), bit-identical to adaisp_pool64(out); NLM images and other geometries take a pooling launch.
  * `out` must not alias `img`.
  */
 int adaisp_forward(const float* img, float* out, float* pooled64_next,
                    const int32_t* filter_id, const float* params, int param_stride,
                    int B, int H, int W, unsigned flags, void* stream);
+
+/*
+ * adaisp_forward when the HOST knows the op of the step (teacher-forced schedules, `selected_filter_id` of
+ * Agent.forward, agent.py:88,150-153): one op for the whole batch, per-image params, optional fused pooling. Exactly one
+ * kernel is enqueued (two for NLM with pooling) instead of one per kernel family. Same results as adaisp_forward with
+ * filter_id[b] == op.
+ */
+int adaisp_forward_uniform(int op, const float* img, float* out, float* pooled64_next,
+                           const float* params, int param_stride,
+                           int B, int H, int W, unsigned flags, void* stream);
 
 /*
  * Same arithmetic with ONE host-known op for the whole batch: Filter.process(img, param)

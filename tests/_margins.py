@@ -1,13 +1,27 @@
-"""Float assertions of the GPU parity tests, with the measured error kept.
+"""Float assertions of the GPU parity tests, with the measured error kept and the tolerance taken from it.
 
-`close(label, got, ref, rtol, atol)` asserts |got - ref| <= atol + rtol * |ref| element-wise (numpy's allclose rule) and
-records, per label, the largest absolute error, the largest relative error on elements with |ref| >= 1e-3, and the
-largest share of the allowed error any element used. At the end of a GPU session `tests/conftest.py` writes the table
-to `gpurun_out/parity_margins.txt`; the copy under `profiles/` is what the tolerances in the tests were set from
-(each <= 4x the measured value). Test infrastructure only."""
+`close(label, got, ref, rtol, atol)` asserts |got - ref| <= atol + rtol * |ref| element-wise (numpy's allclose rule).
+The (rtol, atol) at the call site are CAPS (north_star's 1e-5 for the fp32 filters, the gradient-scale bounds for the
+gradient checks); the tolerance actually asserted comes from `tests/parity_tolerances.json` when the label is listed
+there — written by `tools/set_tolerances.py` from the errors MEASURED on the MI355X (`profiles/round3_parity_margins.txt`),
+each entry <= 4x the measured value and never looser than the cap.
+
+Per label a GPU session records: the largest absolute error, the largest relative error on elements with
+|ref| >= 1e-3, `r4` = min(cap, 4 x that relative error) and `need_atol` = the largest |d| - r4 * |ref| (what the absolute
+term has to cover once the relative term is r4 — the dark pixels and the cancellation-limited stencil outputs), and the
+share of the ASSERTED tolerance the worst element used. `tests/conftest.py` writes the table to
+`gpurun_out/parity_margins.txt` at the end of the session. Test infrastructure only."""
+import json
+import os
+
 import numpy as np
 
 RECORDS = {}
+_TABLE_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "parity_tolerances.json")
+try:          # PARITY_MEASURE=1: assert the call-site caps only (the run that (re)measures the margins the table is made from)
+    TABLE = {} if os.environ.get("PARITY_MEASURE") == "1" else json.load(open(_TABLE_PATH))
+except Exception:
+    TABLE = {}
 
 
 def _np(a):
@@ -21,23 +35,33 @@ def close(label, got, ref, rtol, atol=0.0, err_msg=""):
     assert g.shape == r.shape, f"{label}: shape {g.shape} vs {r.shape}"
     if g.size == 0:
         return
-    assert np.isfinite(g).all() or not np.isfinite(r).all(), f"{label}: non-finite output"
+    cap_r, cap_a = float(rtol), float(atol)
+    if label in TABLE:
+        rtol, atol = min(cap_r, float(TABLE[label]["rtol"])), min(cap_a, float(TABLE[label]["atol"]))
     fin = np.isfinite(r)
     assert np.array_equal(g[~fin], r[~fin], equal_nan=True), f"{label}: non-finite pattern differs"
+    assert np.isfinite(g[fin]).all(), f"{label}: non-finite output"
     d = np.abs(g[fin] - r[fin])
     a = np.abs(r[fin])
     allowed = atol + rtol * a
     with np.errstate(divide="ignore", invalid="ignore"):
         used = np.where(d == 0, 0.0, d / allowed)
     big = a >= 1e-3
-    rec = RECORDS.setdefault(label, {"n": 0, "max_abs": 0.0, "max_rel": 0.0, "used": 0.0, "rtol": rtol, "atol": atol})
+    rec = RECORDS.setdefault(label, {"n": 0, "max_abs": 0.0, "max_rel": 0.0, "r4": 0.0, "need_atol": 0.0, "used": 0.0,
+                                     "rtol": 0.0, "atol": 0.0, "cap_r": cap_r, "cap_a": cap_a})
     rec["n"] += 1
+    rel = 0.0
     if d.size:
         rec["max_abs"] = max(rec["max_abs"], float(d.max()))
         if big.any():
-            rec["max_rel"] = max(rec["max_rel"], float((d[big] / a[big]).max()))
+            rel = float((d[big] / a[big]).max())
+            rec["max_rel"] = max(rec["max_rel"], rel)
+        r4 = min(cap_r, max(4.0 * rel, 2.4e-7)) if cap_r > 0 else 0.0
+        rec["r4"] = max(rec["r4"], r4)
+        rec["need_atol"] = max(rec["need_atol"], float(np.maximum(d - r4 * a, 0.0).max()))
         rec["used"] = max(rec["used"], float(used.max()))
     rec["rtol"], rec["atol"] = max(rec["rtol"], rtol), max(rec["atol"], atol)
+    rec["cap_r"], rec["cap_a"] = max(rec["cap_r"], cap_r), max(rec["cap_a"], cap_a)
     worst = float(used.max()) if d.size else 0.0
     assert worst <= 1.0, (f"{label}: error uses {worst:.3g}x the tolerance (rtol {rtol:g}, atol {atol:g}); "
                           f"max abs {float(d.max()):.3g} {err_msg}")
@@ -46,9 +70,11 @@ def close(label, got, ref, rtol, atol=0.0, err_msg=""):
 def dump(path):
     if not RECORDS:
         return
-    lines = ["# label | assertions | max abs err | max rel err (|ref| >= 1e-3) | share of tolerance used | rtol | atol"]
+    lines = ["# label | assertions | max abs err | max rel err (|ref| >= 1e-3) | r4 | need_atol | share of asserted tolerance used "
+             "| asserted rtol | asserted atol | cap rtol | cap atol"]
     for k in sorted(RECORDS):
         r = RECORDS[k]
-        lines.append(f"{k} | {r['n']} | {r['max_abs']:.3e} | {r['max_rel']:.3e} | {r['used']:.3f} | {r['rtol']:g} | {r['atol']:g}")
+        lines.append(f"{k} | {r['n']} | {r['max_abs']:.3e} | {r['max_rel']:.3e} | {r['r4']:.3e} | {r['need_atol']:.3e} | "
+                     f"{r['used']:.3f} | {r['rtol']:g} | {r['atol']:g} | {r['cap_r']:g} | {r['cap_a']:g}")
     with open(path, "w") as f:
         f.write("\n".join(lines) + "\n")

@@ -272,6 +272,7 @@ def main():
     gen_replay()
     gen_mosaic()
     gen_value_path()
+    gen_midsize()
     tot = sum(os.path.getsize(os.path.join(HERE, f)) for f in os.listdir(HERE) if f.endswith(".npz"))
     print("fixtures written, total bytes:", tot)
 
@@ -309,7 +310,7 @@ if __name__ == "__main__" and "--value-path-only" in sys.argv:
     gen_value_path()
     sys.exit(0)
 
-if __name__ == "__main__" and "--eval-only" not in sys.argv and "--ckpt-only" not in sys.argv and "--replay-only" not in sys.argv and "--mosaic-only" not in sys.argv:
+if __name__ == "__main__" and not any(f in sys.argv for f in ("--eval-only", "--ckpt-only", "--replay-only", "--mosaic-only", "--midsize-only")):
     main()
 
 
@@ -523,5 +524,35 @@ def gen_mosaic():
     print("mosaic.npz written")
 
 
-if __name__ == "__main__" and "--mosaic-only" in sys.argv:
+def gen_midsize():
+    """One MID-SIZE fixture per stencil stage: 1 x 3 x 96 x 160 — an interior larger than one NLM
+    tile (60 x 24) and one conv strip, 1.5 x 2.5 px pool windows — through the reference's NLM, USM, Sharpen, SharpenV2 and
+    AdaptiveAvgPool2d((64, 64)) of each result; plus a 180 x 160 image for the pooling alone (2.8-row overlapping windows)."""
+    filters, cfg, _, _ = import_reference()
+    T = torch.from_numpy
+    out = {}
+    img = test_image(1, 96, 160, seed=47)
+    img += np.random.default_rng(47).normal(0, 0.01, img.shape).astype(np.float32)
+    out["img"] = img
+    pool = torch.nn.AdaptiveAvgPool2d((64, 64))
+    cases = (("NLM", filters.DenoiseFilter, [[0.15]]), ("USM", filters.SharpenUSMFilter, [[1.1, 1.4]]),
+             ("Shr", filters.SharpenFilter, [[3.5]]), ("ShrV2", filters.SharpenFilterV2, [[1.7]]))
+    with torch.no_grad():
+        for name, cls, p in cases:
+            f = cls(cfg, predict=False)
+            param = torch.tensor(p, dtype=torch.float32)
+            fwd, _, _ = f.forward(T(img), specified_parameter=param)
+            out[f"{name}.param"] = np.asarray(p, np.float32)
+            out[f"{name}.forward"] = fwd.numpy()
+            out[f"{name}.pooled"] = pool(fwd).numpy()
+        x = test_image(1, 180, 160, seed=48, special=False)
+        out["pool.img"] = x
+        out["pool.out"] = pool(T(x)).numpy()
+    np.savez_compressed(os.path.join(HERE, "midsize.npz"), **out)
+    print("wrote midsize.npz")
+
+
+if __name__ == "__main__" and "--midsize-only" in sys.argv:
+    gen_midsize()
+elif __name__ == "__main__" and "--mosaic-only" in sys.argv:
     gen_mosaic()

@@ -298,3 +298,40 @@ def test_config1_single_640_three_steps_on_the_hip_path(oracle_mod):
             close("config1_single_640_three_steps_on_the_hip_path#1", y.cpu().numpy(), ref, rtol=1e-5, atol=2e-6)
             assert float(st2[0, 2]) == step + 1 and float(st2[0, 3 + k]) == 1.0 and int(dbg["selected_filter"][0]) == k
             x, st = y, st2
+
+
+def test_eval_loop_reuses_the_pooling_of_the_filter_launch(golden):
+    """Agent.forward in an eval loop (val_adaptiveisp.py:293-304 feeds the returned image back in): from the second step on
+    the policy reads the 64x64 planes the previous filter launch wrote. Same selections, states, pdf and pixels as the
+    loop that pools every input with a launch of its own — and an image modified in between is pooled again."""
+    g = golden("agent")
+    ag, cfg, dev = _agent()
+    z = T(g["z"]).to(dev)
+
+    def loop(use_cache, forced):
+        x, st = T(g["x"]).to(dev), T(g["s0"]).to(dev)
+        trace = []
+        with torch.no_grad():
+            for k in range(4):
+                if not use_cache:
+                    ag._pool_cache = None
+                hit = ag._cached_pool(x) is not None
+                (x, st, sur, pen), dbg, _ = ag((x, z, st), 0.5, selected_filter_id=forced[k] if forced else None)
+                trace.append((x.clone(), st.clone(), dbg["selected_filter"].clone(), dbg["pdf"].clone(), pen.clone(), hit))
+        return trace
+
+    for forced in (None, [4, 3, 0, 5]):
+        a, b = loop(True, forced), loop(False, forced)
+        assert [t[5] for t in a] == [False, True, True, True] and not any(t[5] for t in b)
+        for ta, tb in zip(a, b):
+            assert all(torch.equal(u, v) for u, v in zip(ta[:5], tb[:5]))
+    # a caller that edits the returned image in place gets a fresh pooling, not the cached one
+    with torch.no_grad():
+        (x, st, _, _), _, _ = ag((T(g["x"]).to(dev), z, T(g["s0"]).to(dev)), 0.5)
+        assert ag._cached_pool(x) is not None
+        x.mul_(0.5)
+        assert ag._cached_pool(x) is None
+        from adaptiveisp_amd import _lib
+        (y, _, _, _), _, _ = ag((T(g["x"]).to(dev), z, T(g["s0"]).to(dev)), 0.5)
+        _lib.process(_lib.OP_EXPOSURE, T(g["x"]).to(dev), torch.ones(y.shape[0], 1, device=dev), out=y)   # raw-pointer write
+        assert ag._cached_pool(y) is None

@@ -75,3 +75,115 @@ def test_run_eval_hip_path(tmp_path):
     assert r1["seen"] == 2 and r1["nt"].sum() == 3
     assert r1["records"] == r2["records"] and r1["map50"] == r2["map50"]
     assert len(r1["records"][0][1]) == 5
+
+
+def _write_lod_folder(root):
+    """A synthetic LOD-style folder: images/ + labels/ (YOLO txt), four PNGs of different native sizes and aspect ratios."""
+    import os
+    from PIL import Image
+    os.makedirs(root / "images"); os.makedirs(root / "labels")
+    rng = np.random.default_rng(11)
+    paths = []
+    for i, (h, w) in enumerate([(600, 800), (512, 384), (333, 500), (720, 1280)]):
+        base = rng.random((h // 8 + 1, w // 8 + 1, 3))
+        im = np.kron(base, np.ones((8, 8, 1)))[:h, :w] * 0.35 + rng.random((h, w, 3)) * 0.1       # dark, blocky, noisy
+        Image.fromarray((im * 255).astype(np.uint8)).save(root / "images" / f"img{i}.png")
+        n = 2 + i
+        lb = np.concatenate([rng.integers(0, 7, (n, 1)).astype(np.float64), rng.uniform(0.25, 0.75, (n, 2)),
+                             rng.uniform(0.1, 0.4, (n, 2))], 1)
+        np.savetxt(root / "labels" / f"img{i}.txt", lb, fmt="%.6f")
+        paths.append(str(root / "images" / f"img{i}.png"))
+    return paths
+
+
+def test_config3_eval_loop_at_its_shape(tmp_path, oracle_mod):
+    """BASELINE config 3 at its own shape (val_adaptiveisp.py:287-310,337,466-467): the LOD loader at img_size 512, batch 1
+    (512 x 512 square letterbox, images of different native sizes), a detector imported from a reference-pickled
+    checkpoint, five ISP steps with the per-step early-exit check, NMS at conf 0.001, box rescaling, matching, mAP.
+    The GPU run (fused policy + HIP filters with fused pooling, YoloEngine bf16, HIP NMS) against a CPU run of the SAME
+    loop with the oracle standing in for every kernel (tests/_engine.py: C oracle ISP + pooling, torch-CPU heads, oracle
+    greedy NMS): filter ids per step (records.txt) equal, retouched images within the episode tolerance, and — the CPU
+    loop being fed the engine's predictions, so that bf16-vs-fp32 logits do not enter — the detections after NMS, every
+    per-image `correct` matrix and the mAP figures EQUAL. The engine's predictions themselves are held to the fp32
+    module tree on the same retouched image (bf16 tolerance)."""
+    import os
+    from _engine import cpu_agent
+    from _synth import synth_state_dict
+    from adaptiveisp_amd.agent import Agent
+    from adaptiveisp_amd.config import cfg
+    from adaptiveisp_amd.val import run_eval
+    from adaptiveisp_amd.val.loader import LODImages
+    from adaptiveisp_amd.yolo import YoloEngine
+    from adaptiveisp_amd.yolo.checkpoint import load_detector_checkpoint
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    paths = _write_lod_folder(tmp_path)
+    data = LODImages(str(tmp_path / "images"), img_size=512, batch_size=1)
+    batches = list(data)
+    assert len(batches) == 4 and all(tuple(b[0].shape) == (1, 3, 512, 512) for b in batches)
+    assert sorted(os.path.basename(b[2][0]) for b in batches) == [f"img{i}.png" for i in range(4)]
+    det = load_detector_checkpoint(os.path.join(gold, "yolov3_w0625_refpickle.pt")).eval()
+    nc = det.model[-1].nc
+    agent = Agent(cfg, shape=(6 + len(cfg.filters), 64, 64), device=DEV)
+    agent.load_state_dict(synth_state_dict(agent, seed=0))
+    agent = agent.to(DEV).eval()
+    eng = YoloEngine(det, 1, 512, 512, device=DEV)
+
+    # ---- the GPU loop -------------------------------------------------------------------------------------------
+    cache = {}
+
+    def gpu_detector(x):
+        p = eng(x).clone()
+        cache[len(cache)] = (x.detach().cpu().clone(), p.detach().cpu().clone())
+        return p
+
+    np.random.seed(0)
+    dg = []
+    rg = run_eval(agent, gpu_detector, batches, cfg, steps=5, conf_thres=0.001, iou_thres=0.6, nc=nc,
+                  records_path=str(tmp_path / "records.txt"), details=dg)
+    assert agent._fast is not None and rg["seen"] == 4
+    rows = open(tmp_path / "records.txt").read().strip().splitlines()
+    assert rows[0] == ",".join(f.get_short_name() for f in agent.filters) and len(rows) == 5
+    for (name, ids), line in zip(rg["records"], rows[1:]):
+        assert line == name + "," + ",".join(ids) and len(ids) == 5
+        # test_steps = 5: `stopped` is raised by the fifth step, never earlier (agent.py:234-259) — all five ids are real
+        assert all(0 <= int(k) < len(agent.filters) for k in ids)
+
+    # ---- the same loop on the CPU, the oracle standing in for the kernels ------------------------------------------
+    cag = cpu_agent(cfg, seed=0)
+    feed = iter(range(len(cache)))
+    cpu_retouch = []
+
+    def cpu_detector(x):
+        i = next(feed)
+        cpu_retouch.append(x.detach().clone())
+        return cache[i][1].clone()                          # the engine's predictions: bf16 logits stay out of the comparison
+
+    def oracle_nms_fn(boxes, scores, thr):                  # (boxes arrive sorted by descending score)
+        b = boxes.detach().cpu().numpy().astype(np.float32)
+        return torch.from_numpy(oracle_mod.nms(b, float(thr), max_det=max(len(b), 1)))
+
+    np.random.seed(0)
+    dc = []
+    rc = run_eval(cag, cpu_detector, batches, cfg, steps=5, conf_thres=0.001, iou_thres=0.6, nc=nc, nms_fn=oracle_nms_fn,
+                  details=dc)
+    assert rc["records"] == rg["records"], (rc["records"], rg["records"])
+    for i, (a, b) in enumerate(zip(dg, dc)):
+        assert a["path"] == b["path"]
+        d = (cache[i][0] - cpu_retouch[i]).abs()
+        assert float(d.max()) < 2e-4, (i, float(d.max()))                 # five chained steps (see test_fullsize_episode_vs_oracle)
+        assert float((d > 1e-5 * cpu_retouch[i].abs() + 2e-6).float().mean()) < 1e-3
+        assert a["pred"].shape == b["pred"].shape and a["pred"].shape[0] > 0, (i, a["pred"].shape, b["pred"].shape)
+        np.testing.assert_allclose(a["pred"].numpy(), b["pred"].numpy(), rtol=1e-6, atol=1e-6)    # same boxes, same order
+        assert (a["correct"] is None) == (b["correct"] is None)
+        if a["correct"] is not None:
+            assert torch.equal(a["correct"], b["correct"]), i
+    for k in ("mp", "mr", "map50", "map75", "map", "seen"):
+        assert rg[k] == pytest.approx(rc[k], rel=1e-6, abs=1e-9), k
+    assert np.array_equal(rg["nt"], rc["nt"]) and rg["nt"].sum() == 2 + 3 + 4 + 5
+    # ---- and the engine against the fp32 module tree on the same retouched image ---------------------------------------
+    with torch.no_grad():
+        for i in (0, 3):
+            ref = det(cache[i][0])[0].numpy()
+            got = cache[i][1].numpy()
+            rel = np.abs(got - ref) / (np.abs(ref) + 1.0)
+            assert rel.max() < 3e-2, (i, rel.max())

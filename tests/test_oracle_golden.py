@@ -104,3 +104,32 @@ def test_torch_policy_step_all_filters_vs_selected_only(golden, oracle_mod):
     ids = np.array([j if j >= 0 else -1 for j in sel.tolist()], np.int32)
     ref = oracle_mod.forward(img.numpy(), ids, packed, clip=True)
     np.testing.assert_allclose(full.numpy(), ref, rtol=0, atol=5e-7)
+
+
+# ---- mid-size fixtures (1 x 3 x 96 x 160: an interior larger than an NLM tile / a conv strip) ------------
+
+@pytest.mark.parametrize("name", ["NLM", "USM", "Shr", "ShrV2"])
+def test_midsize_stencils_match_reference(golden, oracle_mod, name):
+    g = golden("midsize")
+    out = oracle_mod.forward(g["img"], OPS[name], g[f"{name}.param"], clip=True)
+    ref = g[f"{name}.forward"]
+    if name in BIT_EXACT:
+        assert np.array_equal(out, ref), f"{name}: {np.abs(out - ref).max()}"
+    else:
+        assert np.abs(out - ref).max() <= ABS_TOL, np.abs(out - ref).max()
+    # and the 64 x 64 pooling of the reference's result, bit for bit (windows of 1-2 rows x 2-3 columns)
+    assert np.array_equal(oracle_mod.pool64(ref), g[f"{name}.pooled"])
+
+
+def test_midsize_pooling_bit_exact(golden, oracle_mod):
+    g = golden("midsize")
+    assert np.array_equal(oracle_mod.pool64(g["pool.img"]), g["pool.out"])       # 180 x 160: 3-4 row overlapping windows
+
+
+@pytest.mark.parametrize("name", ["NLM", "USM", "Shr", "ShrV2"])
+def test_torch_restatement_midsize(golden, name):
+    import torch
+    from oracle import torch_ref
+    g = golden("midsize")
+    out = torch_ref.forward(OPS[name], torch.from_numpy(g["img"]), torch.from_numpy(g[f"{name}.param"])).numpy()
+    np.testing.assert_allclose(out, g[f"{name}.forward"], rtol=0, atol=1e-6)
