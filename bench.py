@@ -10,8 +10,8 @@ N GPUs = N independent replicas (one process per GPU, no data-path collective): 
     python bench.py --gpus 1 --steps 20 --warmup 3
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-Prints ONE JSON line (rank 0). Extra objects: `roofline` (dominant kernel: the 256x256 ping-pong implicit-GEMM conv,
-timed per launch with HIP events on the launch stream, inside the network), `isp` (per-step ISP kernel times vs the HBM roof)
+Prints ONE JSON line (rank 0). Extra objects: `roofline` (dominant kernel = the conv kernel with the largest total time,
+timed per launch with HIP events on the launch stream, inside the network, beside the ISP stream; the next three in `other_kernels`), `isp` (per-step ISP kernel times vs the HBM roof)
 and `cpu_baseline` (the reference's op chain restated on torch-CPU + plain torch-CPU detector on a bounded sample,
 host cores of this box; 1 warm-up + 3 repeats, min/median).
 """
@@ -215,27 +215,66 @@ def build_pipeline(step, engine, x0, cut=None, gate=None):
     return prime, run
 
 
-def time_isp_kernels(x0, sched, iters=10):
-    """Per-op ISP kernel time (HIP events on the launch stream), algorithmic 24 B/px."""
+def time_isp_kernels(x0, sched, iters=12):
+    """Per-op ISP kernel time (HIP events on the launch stream), algorithmic 24 B/px. Two figures per op:
+      ms / GBps / frac_hbm   on a ROTATING set of 3 input / output buffer pairs (6 x 88.5 MB = 531 MB at config 2, more
+                             than the 256 MB Infinity Cache): every launch reads lines that have left the cache — HBM rate;
+      warm_ms / warm_GBps    the same launch repeated on ONE pair (what rounds 1-2 reported): part of its traffic is
+                             Infinity-Cache resident when the tensors fit."""
     from adaptiveisp_amd import _lib
     B, _, H, W = x0.shape
     npar = {0: 1, 1: 1, 2: 9, 3: 1, 4: 1, 5: 8, 6: 1, 7: 1, 8: 1, 9: 3}
-    out = torch.empty_like(x0)
+    ins = [x0] + [x0.clone() for _ in range(2)]
+    outs = [torch.empty_like(x0) for _ in range(3)]
     res = {}
-    for op in sorted(set(sched)):
-        p = torch.rand(B, npar[op], device=x0.device) * 0.8 + 0.6
-        n = 3 if op == 4 else iters
-        _lib.process(op, x0, p, clip=True, out=out)
+
+    def timed(op, p, n, rotate):
+        for k in range(3):
+            _lib.process(op, ins[k], p, clip=True, out=outs[k])
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        for _ in range(n):
-            _lib.process(op, x0, p, clip=True, out=out)
+        for i in range(n):
+            k = i % 3 if rotate else 0
+            _lib.process(op, ins[k], p, clip=True, out=outs[k])
         e1.record()
         torch.cuda.synchronize()
-        ms = e0.elapsed_time(e1) / n
+        return e0.elapsed_time(e1) / n
+
+    pools = [torch.empty((B, 3, 64, 64), dtype=torch.float32, device=x0.device) for _ in range(3)]
+
+    def timed_step(op, p, n):
+        """The RL step's form of the launch: host-known op + the next step's 64x64 pooling out of the same launch."""
+        for k in range(3):
+            _lib.forward(ins[k], None, p, clip=True, out=outs[k], pooled=pools[k], host_op=op)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for i in range(n):
+            _lib.forward(ins[i % 3], None, p, clip=True, out=outs[i % 3], pooled=pools[i % 3], host_op=op)
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / n
+
+    for k in range(3):
+        _lib.pool64(ins[k])
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for i in range(iters):
+        _lib.pool64(ins[i % 3])
+    e1.record()
+    torch.cuda.synchronize()
+    res["pool64"] = {"ms": round(e0.elapsed_time(e1) / iters, 4), "bytes_per_px": 12}
+    for op in sorted(set(sched)):
+        p = torch.rand(B, npar[op], device=x0.device) * 0.8 + 0.6
+        n = 3 if op == 4 else iters
+        ms, warm = timed(op, p, n, True), timed(op, p, n, False)
         gbs = 24.0 * B * H * W / (ms * 1e-3) / 1e9
-        res[NAMES[op]] = {"ms": round(ms, 4), "GBps": round(gbs, 1), "frac_hbm": round(gbs / HBM_PEAK_GBS, 3)}
+        res[NAMES[op]] = {"ms": round(ms, 4), "GBps": round(gbs, 1), "frac_hbm": round(gbs / HBM_PEAK_GBS, 3),
+                          "warm_ms": round(warm, 4), "warm_GBps": round(24.0 * B * H * W / (warm * 1e-3) / 1e9, 1),
+                          # the launch as the RL step issues it: + the next step's pooled planes (fused; NLM: + a pooling launch)
+                          "with_pool_ms": round(timed_step(op, torch.nn.functional.pad(p, (0, 24 - p.shape[1])), n), 4)}
         if op == 4:        # NLM is bound by the fp32 VALU, not HBM: 4.6 kflop/px in the reference's arithmetic (SURVEY 8(d))
             tf = 4.6e3 * B * H * W / (ms * 1e-3) / 1e12
             res[NAMES[op]].update({"bound": "fp32 valu", "ref_arith_TFLOPs": round(tf, 1), "peak_TFLOPs": 157.3,
@@ -243,12 +282,14 @@ def time_isp_kernels(x0, sched, iters=10):
     return res
 
 
-def time_dominant_conv(engine, x, reps=3):
-    """Average launch duration of the dominant kernel = the conv variant that carries the most flops of this forward,
-    measured IN the network: the whole detector forward runs in plan order and every launch of that kernel is
-    bracketed by a HIP event pair on the launch stream (inputs come from the layer before, not from a warm repeat of
-    the same layer — one launch at a time on hot caches reads 10 % faster). rocprofv3 --kernel-trace --stats of the same
-    command (profiles/) reports the same kernel's average without the ~5 us the event pair adds."""
+def time_conv_kernels(engine, x, reps=3, beside=None):
+    """Per-launch duration of EVERY conv kernel of the detector, measured IN the network and in the arrangement the
+    headline is timed in: the whole forward runs in plan order on its stream, every conv launch bracketed by a HIP event
+    pair on that stream, while `beside()` (the ISP episode of the next batch: pooling, policy, NLM, ...) runs on a second
+    stream as in the two-stream pipeline — the detector's workgroups share the CUs with NLM's there, which is what
+    rocprofv3 --kernel-trace --stats of the same command sees (profiles/). Returns per kernel variant: launches per
+    forward, average launch ms, flops per launch, TFLOP/s, and its share of the summed conv time; the DOMINANT kernel is
+    the one with the largest total TIME (round 2 picked by flops, which favoured the better-running variant)."""
     FUSED = 58                     # pseudo-variant: variant 50 with the next block's 1x1 fused into its epilogue
 
     def entry(kind, args):
@@ -262,45 +303,56 @@ def time_dominant_conv(engine, x, reps=3):
             return FUSED, fl + 2.0 * B * Ho * Wo * cout * args[20]
         return args[16], fl
 
-    by_variant = {}
-    for kind, fn, args in engine.plan:
-        v, fl = entry(kind, args)
-        if v is not None:
-            by_variant[v] = by_variant.get(v, 0.0) + fl
-    dominant = max(by_variant, key=by_variant.get)
     pairs = []
 
-    def bracket(fn, flops):
+    def bracket(fn, variant, flops):
         def call(*a):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             rc = fn(*a)
             e1.record()
-            pairs.append((e0, e1, flops))
+            pairs.append((e0, e1, variant, flops))
             return rc
         return call
 
-    plan, wrapped, nsel = engine.plan, [], 0
+    plan, wrapped, per_fwd = engine.plan, [], {}
     for kind, fn, args in plan:
         v, fl = entry(kind, args)
-        if v == dominant:
-            wrapped.append((kind, bracket(fn, fl), args))
-            nsel += 1
+        if v is not None:
+            wrapped.append((kind, bracket(fn, v, fl), args))
+            per_fwd[v] = per_fwd.get(v, 0) + 1
         else:
             wrapped.append((kind, fn, args))
+    side = torch.cuda.Stream()
     engine(x)
     torch.cuda.synchronize()
     engine.plan = wrapped
     try:
         for _ in range(reps):
+            if beside is not None:
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    beside()
             engine(x)
+            if beside is not None:
+                torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
     finally:
         engine.plan = plan
-    tot_ms = sum(e0.elapsed_time(e1) for e0, e1, _ in pairs)
-    tot_fl = sum(fl for _, _, fl in pairs)
-    n = len(pairs)
-    # whole detector forward, for the end-to-end TFLOP/s
+    stats = {}
+    for e0, e1, v, fl in pairs:
+        st = stats.setdefault(v, {"ms": 0.0, "flops": 0.0, "n": 0})
+        st["ms"] += e0.elapsed_time(e1)
+        st["flops"] += fl
+        st["n"] += 1
+    total = sum(st["ms"] for st in stats.values())
+    table = []
+    for v, st in stats.items():
+        table.append({"variant": v, "kernel": CONV_KERNEL_NAMES.get(v, f"conv variant {v}"), "launches_per_step": per_fwd[v],
+                      "avg_launch_ms": st["ms"] / st["n"], "flops_per_launch": st["flops"] / st["n"],
+                      "tflops": st["flops"] / (st["ms"] * 1e-3) / 1e12, "share_of_conv_time": st["ms"] / total})
+    table.sort(key=lambda r: -r["share_of_conv_time"])
+    # whole detector forward alone on its stream, for the end-to-end TFLOP/s
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(reps):
@@ -308,10 +360,7 @@ def time_dominant_conv(engine, x, reps=3):
     e1.record()
     torch.cuda.synchronize()
     det_ms = e0.elapsed_time(e1) / reps
-    return {"variant": dominant, "launches_per_forward": nsel, "avg_launch_ms": tot_ms / max(n, 1),
-            "tflops": tot_fl / (tot_ms * 1e-3) / 1e12 if tot_ms else 0.0,
-            "flops_per_launch": tot_fl / max(n, 1), "detector_ms": det_ms,
-            "detector_tflops": engine.flops / (det_ms * 1e-3) / 1e12}
+    return {"kernels": table, "detector_ms": det_ms, "detector_tflops": engine.flops / (det_ms * 1e-3) / 1e12}
 
 
 def pmc_traffic(kernel_name):
@@ -321,7 +370,7 @@ def pmc_traffic(kernel_name):
     import glob
     key = kernel_name.split("::")[-1].replace(" ", "")
     if not key:
-        return None
+        return None, None
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")), reverse=True):
         try:
             table = json.load(open(path))
@@ -331,8 +380,8 @@ def pmc_traffic(kernel_name):
         hit = [r for r in recs if key in r["kernel"].replace(" ", "")]
         n = sum(r["launches"] for r in hit)
         if n:
-            return sum(r["hbm_bytes_per_launch"] * r["launches"] for r in hit) / n
-    return None
+            return sum(r["hbm_bytes_per_launch"] * r["launches"] for r in hit) / n, os.path.relpath(path, ROOT)
+    return None, None
 
 
 def _timed(fn, repeats=3):
@@ -417,7 +466,7 @@ def cpu_baseline(a, sched):
 
 
 def prepare_gpu_run(a, dev):
-    """Workload, eager warm-up, hipGraph capture and the two-stream pipeline -> (run, single_run, graphed, pipelined, engine, x0, sched)."""
+    """Workload, eager warm-up, hipGraph capture and the two-stream pipeline -> (run, single_run, graphed, pipelined, engine, x0, sched, step)."""
     step, engine, agent, x0, sched = build_workload(a, dev)
 
     run = step
@@ -452,7 +501,7 @@ def prepare_gpu_run(a, dev):
             print(f"[bench] hipGraph capture unavailable ({type(e).__name__}: {e}); launching eagerly", file=sys.stderr)
             torch.cuda.synchronize()
             run = step
-    return run, single_run, graphed, pipelined, engine, x0, sched
+    return run, single_run, graphed, pipelined, engine, x0, sched, step
 
 
 def main():
@@ -504,10 +553,10 @@ def main():
     if dry:
         run, sched, Hp = (lambda: time.sleep(0.002)), SCHEDULES[a.schedule], (a.height + 31) // 32 * 32
         graphed = pipelined = False
-        single_run = engine = x0 = None
+        single_run = engine = x0 = step = None
         a.no_detail = a.no_cpu_baseline = True
     else:
-        run, single_run, graphed, pipelined, engine, x0, sched = prepare_gpu_run(a, dev)
+        run, single_run, graphed, pipelined, engine, x0, sched, step = prepare_gpu_run(a, dev)
         Hp = engine.Hp
     for _ in range(a.warmup):
         run()
@@ -550,18 +599,27 @@ def main():
         line["single_stream"] = {"value": round(a.batch * a.steps / dt1, 2), "unit": "images/sec", "n_gpus": 1,
                                  "ms_per_step": round(dt1 / a.steps * 1e3, 3)}
     if rank == 0 and not a.no_detail:
-        d = time_dominant_conv(engine, x0)
-        line["roofline"] = {"bound": "mfma", "kernel": CONV_KERNEL_NAMES.get(d["variant"], f"conv variant {d['variant']}"),
-                            "achieved": round(d["tflops"], 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                            "frac": round(d["tflops"] / MFMA_BF16_PEAK_TFLOPS, 4),
-                            # the committed PMC passes are of the BASELINE config: other launch sizes get no traffic figure
-                            "traffic": pmc_traffic(CONV_KERNEL_NAMES.get(d["variant"], ""))
-                            if (a.batch, a.height, a.width) == (8, 720, 1280) else None,
-                            "avg_launch_ms": round(d["avg_launch_ms"], 4), "launches_per_step": d["launches_per_forward"],
-                            "flops_per_launch": d["flops_per_launch"]}
+        d = time_conv_kernels(engine, x0, beside=step.isp_chain if pipelined else None)
+
+        def roof(r):
+            traffic, src = (pmc_traffic(r["kernel"]) if (a.batch, a.height, a.width) == (8, 720, 1280) else (None, None))
+            return {"bound": "mfma", "kernel": r["kernel"], "achieved": round(r["tflops"], 1), "peak": MFMA_BF16_PEAK_TFLOPS,
+                    "unit": "TFLOP/s", "frac": round(r["tflops"] / MFMA_BF16_PEAK_TFLOPS, 4),
+                    # separate --pmc passes of this workload, committed under profiles/ (not observed by THIS run); only for
+                    # the BASELINE config's launch sizes
+                    "traffic": traffic, "traffic_source": src,
+                    "avg_launch_ms": round(r["avg_launch_ms"], 4), "launches_per_step": r["launches_per_step"],
+                    "flops_per_launch": r["flops_per_launch"], "share_of_conv_time": round(r["share_of_conv_time"], 3)}
+
+        line["roofline"] = roof(d["kernels"][0])        # dominant = largest total time
+        line["roofline"]["measured"] = ("HIP event pair around every launch, in the network, " +
+                                        ("ISP episode of the next batch on a second stream (the headline's arrangement)"
+                                         if pipelined else "single stream"))
+        line["roofline"]["other_kernels"] = [roof(r) for r in d["kernels"][1:4]]
         line["detector"] = {"ms": round(d["detector_ms"], 3), "tflops": round(d["detector_tflops"], 1),
                             "gflop_per_image": round(engine.flops / a.batch / 1e9, 1)}
         line["isp"] = {"bound": "hbm", "peak_GBps": HBM_PEAK_GBS, "bytes_per_px": 24,
+                       "note": "ms/GBps: rotating buffers (HBM); warm_*: one buffer pair repeated (partly Infinity Cache); with_pool_ms: the RL step's launch incl. the next step's 64x64 pooling",
                        "kernels": time_isp_kernels(x0, sched)}
     if rank == 0 and not a.no_cpu_baseline and world == 1:
         try:

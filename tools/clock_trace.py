@@ -125,6 +125,9 @@ def main():
     summarize(r3, 0.0, 0.05, label="detector graph: replays 1-10 of 200")
     summarize(r3, 0.05, 0.5, label="detector graph: replays 11-100 of 200")
     summarize(r3, 0.5, 1.0, label="detector graph: replays 101-200 of 200")
+    c = r3["clk"][(r3["mid"] >= r3["t0"]) & (r3["mid"] <= r3["t1"])]
+    print("# detector graph, all 200 replays: clock percentiles MHz  p5 %.0f  p10 %.0f  p25 %.0f  p50 %.0f  p75 %.0f  p90 %.0f" %
+          tuple(np.percentile(c, q) for q in (5, 10, 25, 50, 75, 90)))
     # rocm-smi view, if this user can read it
     for cmd in (["rocm-smi", "--showclocks"], ["amd-smi", "metric", "--clock"]):
         try:

@@ -1,16 +1,22 @@
 #!/usr/bin/env python3
-"""tests/parity_tolerances.json from the errors measured on the MI355X (profiles/round3_parity_margins.txt, written by a
-`pytest -m gpu` session: tests/_margins.py). Per label: rtol = r4 (= min(cap, 4 x the measured relative error on elements
-with |ref| >= 1e-3), atol = min(cap, 4 x need_atol) where need_atol is what the absolute term had to cover with that rtol;
-both rounded UP to two significant digits; floors of 2.4e-7 (two fp32 ulp) on rtol and 1e-9 on atol so that an exact
-match on one box does not make a one-ulp difference on the next a failure. A label whose cap is 0 stays exact."""
+"""tests/parity_tolerances.json from the errors measured on the MI355X (profiles/round3_parity_margins*.txt, each written by
+a `pytest -m gpu` session: tests/_margins.py). Per label, over the measured runs:
+  deterministic labels (the HIP kernels against goldens / the oracle: every run measures the same error)
+      rtol = r4 = min(cap, 4 x the relative error on elements with |ref| >= 1e-3)
+      atol = min(cap, 4 x need_atol)      (what the absolute term had to cover with that rtol)
+  labels whose error differs from run to run (they pass through MIOpen / rocBLAS in the PyTorch head, critic and autograd
+  paths, whose reductions are not run-to-run reproducible)
+      rtol = min(cap, 4 x the LARGEST relative error of any run), atol = min(cap, 4 x the LARGEST absolute error of any run)
+both rounded UP to two significant digits; floors of 2.4e-7 (two fp32 ulp) on rtol and 1e-9 on atol so that an exact match
+on one box does not make a one-ulp difference on the next a failure. A label whose cap is 0 stays exact."""
+import glob
 import json
 import math
 import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "profiles", "round3_parity_margins.txt")
+files = sys.argv[1:] or sorted(glob.glob(os.path.join(ROOT, "profiles", "round3_parity_margins*.txt")))
 
 
 def up(v, digits=2):
@@ -20,14 +26,31 @@ def up(v, digits=2):
     return round(math.ceil(v / 10 ** e) * 10 ** e, 12)
 
 
-table = {}
-for ln in open(src):
-    if ln.startswith("#") or "|" not in ln:
-        continue
-    f = [x.strip() for x in ln.split("|")]
-    label, r4, need, cap_r, cap_a = f[0], float(f[4]), float(f[5]), float(f[9]), float(f[10])
-    rtol = min(cap_r, up(max(r4, 2.4e-7))) if cap_r > 0 else 0.0
-    atol = min(cap_a, up(max(4.0 * need, 1e-9))) if cap_a > 0 else 0.0
+runs = {}
+for path in files:
+    for ln in open(path):
+        if ln.startswith("#") or "|" not in ln:
+            continue
+        f = [x.strip() for x in ln.split("|")]
+        runs.setdefault(f[0], []).append(dict(max_abs=float(f[2]), max_rel=float(f[3]), r4=float(f[4]), need=float(f[5]),
+                                              cap_r=float(f[9]), cap_a=float(f[10])))
+def family(label):
+    return label.split(":")[0].split("#")[0]
+
+
+# one member of a test's labels varying marks the whole test (same library path)
+loose = {family(k) for k, rs in runs.items() if len({(r["max_abs"], r["max_rel"]) for r in rs}) > 1}
+table, nondet = {}, []
+for label, rs in sorted(runs.items()):
+    cap_r, cap_a = max(r["cap_r"] for r in rs), max(r["cap_a"] for r in rs)
+    varies = family(label) in loose
+    if varies:
+        nondet.append(label)
+        rtol = min(cap_r, up(max(4.0 * max(r["max_rel"] for r in rs), 2.4e-7))) if cap_r > 0 else 0.0
+        atol = min(cap_a, up(max(4.0 * max(r["max_abs"] for r in rs), 1e-9))) if cap_a > 0 else 0.0
+    else:
+        rtol = min(cap_r, up(max(max(r["r4"] for r in rs), 2.4e-7))) if cap_r > 0 else 0.0
+        atol = min(cap_a, up(max(4.0 * max(r["need"] for r in rs), 1e-9))) if cap_a > 0 else 0.0
     table[label] = {"rtol": rtol, "atol": atol}
 json.dump(table, open(os.path.join(ROOT, "tests", "parity_tolerances.json"), "w"), indent=0, sort_keys=True)
-print(f"{len(table)} labels -> tests/parity_tolerances.json")
+print(f"{len(table)} labels from {len(files)} run(s) -> tests/parity_tolerances.json; {len(nondet)} vary from run to run: {nondet}")
