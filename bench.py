@@ -131,7 +131,7 @@ def build_workload(a, dev):
     return step, engine, agent, x0, sched
 
 
-def build_pipeline(step, engine, x0, cut=None, gate=None):
+def build_pipeline(step, engine, x0, cut=None, gate=None, detector_eager=False):
     """Two-stage software pipeline over consecutive batches, captured as two hipGraphs (even / odd): one replay runs
     one ISP episode's worth of work (latency-bound: pooling, policy heads, one filter kernel per RL step) on one stream
     and the detector forward of batch i (MFMA-bound) on another. Every replay still does one whole ISP pass and one
@@ -146,7 +146,11 @@ def build_pipeline(step, engine, x0, cut=None, gate=None):
     in one process at config 2 (ms per step): no cut 4.36; cut in front of the NLM step 4.32 (either side of its policy
     half); NLM alone first, detector released after it 4.365; two or three half-steps alone 4.44-4.46. The step is the
     sum of the CU time of detector, NLM and the pointwise kernels in every arrangement — running NLM alone buys nothing,
-    so the two do not fragment each other's CUs either."""
+    so the two do not fragment each other's CUs either.
+
+    detector_eager: the measuring form of the SAME arrangement — the graphs hold only the ISP stream's part and `run()`
+    launches the detector eagerly on the second stream beside the graph replay, so that its launches can be bracketed by
+    HIP events (event-record nodes inside a captured graph are not available on this ROCm: tools/graph_event_probe.py)."""
     sched = step.sched
     nh = 2 * len(sched)
     if cut is None:
@@ -190,14 +194,16 @@ def build_pipeline(step, engine, x0, cut=None, gate=None):
             if gate:                                     # the ISP stream's first half-steps run alone
                 c = step.isp_chain(out=xbuf[p] if cut + gate >= nh else None, start=cut, stop=min(cut + gate, nh), carry=c,
                                    with_carry=True)
-            side.wait_stream(cur)
-            with torch.cuda.stream(side), torch.no_grad():
-                engine(xbuf[1 - p])                      # detector of the batch the previous replay retouched
+            if not detector_eager:
+                side.wait_stream(cur)
+                with torch.cuda.stream(side), torch.no_grad():
+                    engine(xbuf[1 - p])                  # detector of the batch the previous replay retouched
             if cut + gate < nh:
                 step.isp_chain(out=xbuf[p], start=cut + gate, carry=c)   # rest of batch i+1 -> hand-over buffer
             if cut:
                 head(p)                                  # first half-steps of batch i+2 -> mid-episode slot
-            cur.wait_stream(side)
+            if not detector_eager:
+                cur.wait_stream(side)
         graphs.append(g)
     state = {"i": 0}
 
@@ -208,7 +214,16 @@ def build_pipeline(step, engine, x0, cut=None, gate=None):
         state["i"] = 0
 
     def run():
-        graphs[state["i"] & 1].replay()
+        p = state["i"] & 1
+        if detector_eager:
+            cur = torch.cuda.current_stream()
+            side.wait_stream(cur)
+            graphs[p].replay()                           # the ISP stream's part of this step ...
+            with torch.cuda.stream(side), torch.no_grad():
+                engine(xbuf[1 - p])                      # ... beside the detector, launch by launch
+            cur.wait_stream(side)
+        else:
+            graphs[p].replay()
         state["i"] += 1
 
     run.xbuf, run.state = xbuf, state                    # (for the race screens: replay k leaves its episode in xbuf[k & 1])
@@ -282,12 +297,13 @@ def time_isp_kernels(x0, sched, iters=12):
     return res
 
 
-def time_conv_kernels(engine, x, reps=3, beside=None):
+def time_conv_kernels(engine, x, reps=4, runner=None):
     """Per-launch duration of EVERY conv kernel of the detector, measured IN the network and in the arrangement the
     headline is timed in: the whole forward runs in plan order on its stream, every conv launch bracketed by a HIP event
-    pair on that stream, while `beside()` (the ISP episode of the next batch: pooling, policy, NLM, ...) runs on a second
-    stream as in the two-stream pipeline — the detector's workgroups share the CUs with NLM's there, which is what
-    rocprofv3 --kernel-trace --stats of the same command sees (profiles/). Returns per kernel variant: launches per
+    pair on that stream, while the ISP stream's part of the step (`runner` = build_pipeline(..., detector_eager=True): a
+    hipGraph replay of the ISP half-steps of the next batches, NLM first) runs beside it as in the two-stream pipeline — the
+    detector's workgroups share the CUs with NLM's there, which is what rocprofv3 --kernel-trace --stats of the same
+    command sees (profiles/). Without a runner: the detector alone on its stream. Returns per kernel variant: launches per
     forward, average launch ms, flops per launch, TFLOP/s, and its share of the summed conv time; the DOMINANT kernel is
     the one with the largest total TIME (round 2 picked by flops, which favoured the better-running variant)."""
     FUSED = 58                     # pseudo-variant: variant 50 with the next block's 1x1 fused into its epilogue
@@ -323,19 +339,15 @@ def time_conv_kernels(engine, x, reps=3, beside=None):
             per_fwd[v] = per_fwd.get(v, 0) + 1
         else:
             wrapped.append((kind, fn, args))
-    side = torch.cuda.Stream()
     engine(x)
     torch.cuda.synchronize()
     engine.plan = wrapped
     try:
         for _ in range(reps):
-            if beside is not None:
-                side.wait_stream(torch.cuda.current_stream())
-                with torch.cuda.stream(side):
-                    beside()
-            engine(x)
-            if beside is not None:
-                torch.cuda.current_stream().wait_stream(side)
+            if runner is not None:
+                runner()
+            else:
+                engine(x)
         torch.cuda.synchronize()
     finally:
         engine.plan = plan
@@ -381,6 +393,22 @@ def pmc_traffic(kernel_name):
         n = sum(r["launches"] for r in hit)
         if n:
             return sum(r["hbm_bytes_per_launch"] * r["launches"] for r in hit) / n, os.path.relpath(path, ROOT)
+    return None, None
+
+
+def rocprof_reference(kernel_name):
+    """(average launch ms, file) of `kernel_name` in the newest committed rocprofv3 --kernel-trace --stats summary of this
+    bench (profiles/*_rocprofv3_kernel_stats.csv) — printed beside the live figure; (None, None) if absent."""
+    import csv
+    import glob
+    key = kernel_name.split("::")[-1].replace(" ", "")
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_rocprofv3_kernel_stats.csv")), reverse=True):
+        try:
+            for r in csv.DictReader(open(path)):
+                if key and key in r["Name"].replace(" ", ""):
+                    return float(r["AverageNs"]) * 1e-6, os.path.relpath(path, ROOT)
+        except Exception:
+            continue
     return None, None
 
 
@@ -599,17 +627,27 @@ def main():
         line["single_stream"] = {"value": round(a.batch * a.steps / dt1, 2), "unit": "images/sec", "n_gpus": 1,
                                  "ms_per_step": round(dt1 / a.steps * 1e3, 3)}
     if rank == 0 and not a.no_detail:
-        d = time_conv_kernels(engine, x0, beside=step.isp_chain if pipelined else None)
+        runner = None
+        if pipelined:
+            mprime, runner = build_pipeline(step, engine, x0, detector_eager=True)
+            mprime()
+            runner(); runner()
+            torch.cuda.synchronize()
+        d = time_conv_kernels(engine, x0, runner=runner)
 
         def roof(r):
             traffic, src = (pmc_traffic(r["kernel"]) if (a.batch, a.height, a.width) == (8, 720, 1280) else (None, None))
+            ref_ms, ref_src = rocprof_reference(r["kernel"]) if (a.batch, a.height, a.width) == (8, 720, 1280) else (None, None)
             return {"bound": "mfma", "kernel": r["kernel"], "achieved": round(r["tflops"], 1), "peak": MFMA_BF16_PEAK_TFLOPS,
                     "unit": "TFLOP/s", "frac": round(r["tflops"] / MFMA_BF16_PEAK_TFLOPS, 4),
                     # separate --pmc passes of this workload, committed under profiles/ (not observed by THIS run); only for
                     # the BASELINE config's launch sizes
                     "traffic": traffic, "traffic_source": src,
                     "avg_launch_ms": round(r["avg_launch_ms"], 4), "launches_per_step": r["launches_per_step"],
-                    "flops_per_launch": r["flops_per_launch"], "share_of_conv_time": round(r["share_of_conv_time"], 3)}
+                    "flops_per_launch": r["flops_per_launch"], "share_of_conv_time": round(r["share_of_conv_time"], 3),
+                    # the committed profile of the same command (graph replay, both streams inside one graph): its average
+                    # includes the few launches that time-slice a CU with an NLM workgroup (std dev ~ the mean)
+                    "rocprof_avg_launch_ms": round(ref_ms, 4) if ref_ms else None, "rocprof_source": ref_src}
 
         line["roofline"] = roof(d["kernels"][0])        # dominant = largest total time
         line["roofline"]["measured"] = ("HIP event pair around every launch, in the network, " +
