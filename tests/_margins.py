@@ -17,6 +17,7 @@ import os
 import numpy as np
 
 RECORDS = {}
+NOTES = []          # free-form measured figures (one line each), written below the table
 _TABLE_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "parity_tolerances.json")
 try:          # PARITY_MEASURE=1: assert the call-site caps only (the run that (re)measures the margins the table is made from)
     TABLE = {} if os.environ.get("PARITY_MEASURE") == "1" else json.load(open(_TABLE_PATH))
@@ -68,7 +69,7 @@ def close(label, got, ref, rtol, atol=0.0, err_msg=""):
 
 
 def dump(path):
-    if not RECORDS:
+    if not RECORDS and not NOTES:
         return
     lines = ["# label | assertions | max abs err | max rel err (|ref| >= 1e-3) | r4 | need_atol | share of asserted tolerance used "
              "| asserted rtol | asserted atol | cap rtol | cap atol"]
@@ -76,5 +77,6 @@ def dump(path):
         r = RECORDS[k]
         lines.append(f"{k} | {r['n']} | {r['max_abs']:.3e} | {r['max_rel']:.3e} | {r['r4']:.3e} | {r['need_atol']:.3e} | "
                      f"{r['used']:.3f} | {r['rtol']:g} | {r['atol']:g} | {r['cap_r']:g} | {r['cap_a']:g}")
+    lines += ["# " + n for n in NOTES]
     with open(path, "w") as f:
         f.write("\n".join(lines) + "\n")

@@ -120,7 +120,24 @@ def test_backward_to_image_vs_fp32_autograd(B, H, W):
     assert torch.isfinite(gh).all()
     rel = ((gh - gr).norm() / gr.norm()).item()
     cos = F.cosine_similarity(gh.reshape(1, -1), gr.reshape(1, -1)).item()
-    assert rel < 0.08 and cos > 0.995, (rel, cos)
+    # what bf16 activations / gradients cost through 75 layers, measured with an INDEPENDENT bf16 implementation of the same
+    # network: the PyTorch module tree under autocast (MIOpen bf16 convs, bf16 activations, fp32 master weights)
+    xa = x.clone().requires_grad_(True)
+    boxed_a = torch.cat([boxed.detach()[:, :, :top], xa, boxed.detach()[:, :, top + H:]], 2) if Hp != H else xa
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        raws_a = det(boxed_a)
+    sum((r.float() * w).sum() for r, w in zip(raws_a, R)).backward()
+    rel_a = ((xa.grad - gr).norm() / gr.norm()).item()
+    cos_a = F.cosine_similarity(xa.grad.reshape(1, -1), gr.reshape(1, -1)).item()
+    msg = (f"detector image gradient vs fp32 autograd at {B}x{H}x{W}: HIP engine rel {rel:.4f} cos {cos:.6f} | "
+           f"torch autocast-bf16 rel {rel_a:.4f} cos {cos_a:.6f}")
+    print(msg)
+    import _margins
+    _margins.NOTES.append(msg)
+    # measured on the MI355X (profiles/round3_parity_margins.txt): HIP engine 1.24-1.26 % / cosine 0.99992, the independent
+    # bf16 run 1.64-1.68 % / 0.99989 — the engine (fp32 accumulation in every kernel) is closer to fp32 than MIOpen's bf16
+    assert rel < 0.025 and cos > 0.9995, (rel, cos)
+    assert rel <= 1.25 * rel_a, (rel, rel_a)
     # a stale backward (another forward ran in between) must fail loudly, not use overwritten buffers
     xs = x.clone().requires_grad_(True)
     stale = eng(xs)
