@@ -40,6 +40,41 @@ def test_argument_checks_without_gpu():
     assert L.adaisp_process(99, p, p, p, 1, 1, 2, 2, 0, None) == -2          # unknown op
     assert L.adaisp_process(2, p, p, p, 1, 1, 2, 2, 0, None) == -1           # CCM needs 9 params, stride 1
     assert L.adaisp_process(3, p, p, p, 1, 1, 2, 2, 0, None) == -3           # stencil in place
+    # the host-known-op form of the RL step: same checks as adaisp_process, and never in place (it may be a stencil step)
+    q = ctypes.cast((ctypes.c_float * 16)(), ctypes.c_void_p)
+    assert L.adaisp_forward_uniform(0, None, None, None, None, 1, 1, 8, 8, 0, None) == -1
+    assert L.adaisp_forward_uniform(99, p, q, None, p, 1, 1, 2, 2, 0, None) == -2
+    assert L.adaisp_forward_uniform(2, p, q, None, p, 1, 1, 2, 2, 0, None) == -1
+    assert L.adaisp_forward_uniform(0, p, p, None, p, 1, 1, 2, 2, 0, None) == -3
+    assert L.adaisp_forward_uniform(0, p, q, None, p, 1, 1, 2, 2, 0, None) == -4          # H, W < 3
+
+
+def test_fused_pooling_geometry_is_host_side_and_total():
+    """The cut of the fused-pooling kernels (isp_internal.h: PoolGeom), restated: every pixel column is owned by exactly one
+    strip, every strip's read span covers what it owns and fits 64 lanes x 4 px, for the BASELINE sizes and awkward widths."""
+    def win_lo(o, n): return (o * n) // 64
+    def win_hi(o, n): return ((o + 1) * n + 63) // 64
+    for W in (64, 68, 72, 100, 128, 200, 512, 640, 1000, 1280, 1920, 3840, 4096):
+        geom = None
+        for strips in range(1, 17):
+            cps = (64 + strips - 1) // strips
+            if (64 + cps - 1) // cps != strips:
+                continue
+            c0 = lambda s: min(s * cps, 64)                                            # noqa: E731
+            lo = lambda s: W if c0(s) >= 64 else win_lo(c0(s), W) & ~3                  # noqa: E731
+            end = lambda s: (win_hi(c0(s + 1) - 1, W) + 3) & ~3                         # noqa: E731
+            if all(end(s) - lo(s) <= 256 for s in range(strips)):
+                geom = (cps, strips, lo, end)
+                break
+        assert geom is not None, W
+        cps, strips, lo, end = geom
+        owned = []
+        for s in range(strips):
+            assert lo(s) % 4 == 0 and end(s) % 4 == 0 and lo(s) < end(s) <= W and end(s) >= lo(s + 1)
+            for ox in range(min(s * cps, 64), min((s + 1) * cps, 64)):                 # its pool columns lie inside its span
+                assert lo(s) <= win_lo(ox, W) and win_hi(ox, W) <= end(s)
+            owned += list(range(lo(s), lo(s + 1)))
+        assert owned == list(range(W)), W
 
 
 def test_libadayolo_exports_header_symbols():
