@@ -167,24 +167,68 @@ class Agent(nn.Module):
             return self._forward_fast(x, z, states, progress, high_res, selected_filter_id, out=out)
         if out is not None:
             raise ValueError("`out` is only supported on the fused eval path (eval mode, autograd off)")
-        num_filters = len(self.filters)
-        selection_noise = z[:, 0:1]
-
-        x_down = self.down_sample(x)
         if not self.cfg.shared_feature_extractor:
             raise ValueError("current just support shared_feature_extractor")
+        x_down = self.down_sample(x)
+        coef = (1.0 - progress) * self.cfg.exploration_penalty
+        coef_t = torch.full((1,), coef, dtype=torch.float32, device=x.device)
+        packed, op_ids, selected, surrogate, penalty, new_states, pdf, table, masks = self.policy_heads(
+            x_down, z[:, 0:1], states, coef_t, train=bool(train), forced_id=selected_filter_id, with_masks=True)
+
+        filter_debug_info = []
+        for j, flt in enumerate(self.filters):
+            n = flt.get_num_filter_parameters()
+            p0 = table[0, j, :n]
+            if hasattr(flt, "curve_steps"):                    # curve filters keep the reference's [steps,ch,1,1] view
+                p0 = p0.reshape(flt.curve_steps, -1, 1, 1)
+            flt.mask_parameters = masks[j] if masks is not None else None
+            flt.mask = flt.get_mask(x, flt.mask_parameters)
+            filter_debug_info.append({'filter_parameters': p0, 'mask': flt.mask[0]})
+
+        # pixels: only the selected filter runs
+        x = self._apply_isp(x, packed, op_ids)
+        if high_res is not None:
+            high_res_output = self._apply_isp(high_res, packed, op_ids)
+
+        debug_info = {
+            'state': states,
+            'selected_filter_id': selected[0],
+            'filter_debug_info': filter_debug_info,
+            'pdf': pdf[0],
+            'selected_filter': selected,
+        }
+
+        def debugger(debug_info, combined=True):
+            raise NotImplementedError("the drawing debugger needs cv2 and is outside the ISP hot path")
+
+        debugger.width = int(x.shape[2])
+        if self.cfg.clamp:
+            x = torch.clip(x, min=0.0, max=5.0)
+        if high_res is None:
+            return (x, new_states, surrogate, penalty), debug_info, debugger
+        return (x, new_states, high_res_output), debug_info, debugger
+
+    def policy_heads(self, x_down, noise, states, entropy_coef, train=True, forced_id=None, with_masks=False):
+        """Everything of a step between the 64x64-pooled image and the pixels (agent.py:97-149, 234-280): both CNN trunks,
+        every filter's heads and regressor, the selector's pdf, sampling / arg-max, one-hot bookkeeping, state update and
+        penalties — tensors in, tensors out, no host-side data dependence. `noise` [B,1] = z[:, 0:1]; `entropy_coef` a 1-element tensor = (1 - progress) *
+        cfg.exploration_penalty. Returns (packed [B,w], op_ids int32 [B], selected int64 [B], surrogate [B,1], penalty
+        [B,1], new_states [B,3+F], pdf [B,F], params_table [B,F,w]) and, with `with_masks`, the list of fc_mask outputs
+        (unused while masking is off, isp/filters.py:161-162)."""
+        num_filters = len(self.filters)
         net_in = enrich_image_input(self.cfg, x_down, states)
         filter_features = self.feature_extractor(net_in)
 
         # every filter's heads (cheap), no pixels yet
-        params, filter_debug_info = [], []
+        params, masks = [], []
         for flt in self.filters:
-            feats, mask_parameters = flt.extract_parameters(filter_features)
-            p = flt.filter_param_regressor(feats)
-            flt.mask_parameters = mask_parameters
-            flt.mask = flt.get_mask(x, mask_parameters)
-            params.append(p)
-            filter_debug_info.append({'filter_parameters': p[0], 'mask': flt.mask[0]})
+            hidden = flt.lrelu(flt.fc1(filter_features))
+            params.append(flt.filter_param_regressor(flt.fc_filter(hidden)))
+            if with_masks:
+                masks.append(flt.fc_mask(hidden))
+        B = x_down.shape[0]
+        table = torch.stack([torch.nn.functional.pad(p.reshape(B, -1), (0, self._param_width - p[0].numel()))
+                             for p in params], dim=1)                       # [B,F,width]
 
         # action selection
         selector = self.lrelu(self.fc1(self.action_selection(net_in)))
@@ -192,35 +236,17 @@ class Agent(nn.Module):
         pdf = pdf * (1 - self.cfg.exploration) + self.cfg.exploration * 1.0 / num_filters
         pdf = pdf / (torch.sum(pdf, dim=1, keepdim=True) + 1e-30)
         entropy = torch.sum(-pdf * torch.log(pdf), dim=1)[:, None]
-        random_filter_id = pdf_sample(pdf, selection_noise)
-        max_filter_id = torch.argmax(pdf, dim=1).to(torch.int32)
-        if selected_filter_id is not None:
-            selected_filter_id = torch.full((max_filter_id.shape[0],), int(selected_filter_id), dtype=torch.int64,
-                                            device=max_filter_id.device)
+        if forced_id is not None:
+            selected = torch.full((B,), int(forced_id), dtype=torch.int64, device=x_down.device)
+        elif train:
+            selected = pdf_sample(pdf, noise).to(torch.int64)
         else:
-            selected_filter_id = (train * random_filter_id + (1 - train) * max_filter_id).to(torch.int64)
-        filter_one_hot = one_hot(num_filters, selected_filter_id)
+            selected = torch.argmax(pdf, dim=1).to(torch.int64)
+        filter_one_hot = one_hot(num_filters, selected)
         surrogate = torch.sum(filter_one_hot * torch.log(pdf + 1e-10), dim=1, keepdim=True)
-
-        # pixels: only the selected filter runs
-        op_ids = self._op_ids(selected_filter_id)
-        packed = self._packed_params(params, selected_filter_id)
-        x = self._apply_isp(x, packed, op_ids)
-        if high_res is not None:
-            high_res_output = self._apply_isp(high_res, packed, op_ids)
-
-        debug_info = {
-            'state': states,
-            'selected_filter_id': selected_filter_id[0],
-            'filter_debug_info': filter_debug_info,
-            'pdf': pdf[0],
-            'selected_filter': selected_filter_id,
-        }
-
-        def debugger(debug_info, combined=True):
-            raise NotImplementedError("the drawing debugger needs cv2 and is outside the ISP hot path")
-
-        debugger.width = int(x.shape[2])
+        op_ids = self._op_ids(selected)
+        idx = selected.clamp(0, num_filters - 1).view(B, 1, 1).expand(B, 1, self._param_width)
+        packed = table.gather(1, idx).squeeze(1)                # row b = parameters of filter selected[b] (zeros' row for -1 is never read: op ZERO)
 
         # state update (reference agent.py:234-259)
         step = states[:, STATE_STEP_DIM:STATE_STEP_DIM + 1]
@@ -230,27 +256,17 @@ class Agent(nn.Module):
         assert filter_usage.dim() == filter_one_hot.dim()
         early_stop_penalty = (1 - is_last_step) * submitted * self.cfg.early_stop_penalty
         usage_penalty = torch.sum(filter_usage * filter_one_hot, dim=1, keepdim=True)
-        new_states = [None] * (STATE_DROPOUT_BEGIN + 1)
-        new_states[STATE_REWARD_DIM] = submitted
-        new_states[STATE_STOPPED_DIM] = submitted
-        new_states[STATE_STEP_DIM] = step + 1
-        new_states[STATE_STEP_DIM + 1] = torch.maximum(filter_usage, filter_one_hot)
-        new_states = torch.cat(new_states, dim=1)
+        new_states = torch.cat([submitted, submitted, step + 1, torch.maximum(filter_usage, filter_one_hot)], dim=1)
 
-        if self.cfg.clamp:
-            x = torch.clip(x, min=0.0, max=5.0)
-
-        entropy_penalty = (1.0 - progress) * self.cfg.exploration_penalty * (-entropy + math.log(num_filters))
+        entropy_penalty = entropy_coef * (-entropy + math.log(num_filters))
         runtime_penalty = 0.0
         if self.cfg.filter_runtime_penalty:
-            runtime_penalty = torch.sum(filter_one_hot * self.runtime.to(x.device), dim=1, keepdim=True)
+            runtime_penalty = torch.sum(filter_one_hot * self.runtime.to(x_down.device), dim=1, keepdim=True)
             runtime_penalty = self.cfg.filter_runtime_penalty_lambda * runtime_penalty
         # mean(clip(x - 1, min=0)^2) of the reference (agent.py:279) is identically 0: the kernel has already
         # clipped x to [0,1], so the full-resolution pass that term would cost is skipped.
         over_range = torch.zeros_like(entropy)
         penalty = over_range + entropy_penalty + usage_penalty * self.cfg.filter_usage_penalty + \
             early_stop_penalty + runtime_penalty
-
-        if high_res is None:
-            return (x, new_states, surrogate, penalty), debug_info, debugger
-        return (x, new_states, high_res_output), debug_info, debugger
+        out = (packed, op_ids, selected, surrogate, penalty, new_states, pdf, table)
+        return out + (masks,) if with_masks else out
