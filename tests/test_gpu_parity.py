@@ -376,7 +376,7 @@ def test_4k_denoise_sharpen_vs_oracle(oracle_mod):
 # ---- the next step's 64x64 pooling out of the filter launch (row a-fuse) --------------------------------------
 
 FUSE_SHAPES = [(2, 720, 1280), (1, 512, 512), (1, 640, 640), (1, 2160, 3840), (2, 100, 72), (1, 96, 200), (3, 64, 64),
-               (1, 65, 4100), (2, 40, 56), (1, 70, 102)]
+               (1, 65, 4100), (2, 40, 56), (1, 70, 102), (1, 360, 1920), (1, 128, 1000), (1, 1080, 1916)]
 
 
 @pytest.mark.parametrize("shape", FUSE_SHAPES)
