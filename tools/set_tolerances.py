@@ -6,7 +6,10 @@ a `pytest -m gpu` session: tests/_margins.py). Per label, over the measured runs
       atol = min(cap, 4 x need_atol)      (what the absolute term had to cover with that rtol)
   labels whose error differs from run to run (they pass through MIOpen / rocBLAS in the PyTorch head, critic and autograd
   paths, whose reductions are not run-to-run reproducible)
-      rtol = min(cap, 4 x the LARGEST relative error of any run), atol = min(cap, 4 x the LARGEST absolute error of any run)
+      rtol = min(cap, 16 x the LARGEST relative error of any run), atol = min(cap, 16 x the LARGEST absolute error of any
+      run) — their error is a draw from the libraries' reduction order (atomics in the backward kernels) and was seen to vary
+      up to 9x between runs (critic_to_actor_gradient:f9: 2.6e-9, 4.2e-9, 2.3e-8), so 4x one sample is not a bound; 16x the
+      worst of three (and never below 1/50 of the cap) still leaves these assertions 4 - 50x tighter than in round 2
 both rounded UP to two significant digits; floors of 2.4e-7 (two fp32 ulp) on rtol and 1e-9 on atol so that an exact match
 on one box does not make a one-ulp difference on the next a failure. A label whose cap is 0 stays exact."""
 import glob
@@ -46,8 +49,8 @@ for label, rs in sorted(runs.items()):
     varies = family(label) in loose
     if varies:
         nondet.append(label)
-        rtol = min(cap_r, up(max(4.0 * max(r["max_rel"] for r in rs), 2.4e-7))) if cap_r > 0 else 0.0
-        atol = min(cap_a, up(max(4.0 * max(r["max_abs"] for r in rs), 1e-9))) if cap_a > 0 else 0.0
+        rtol = min(cap_r, up(max(16.0 * max(r["max_rel"] for r in rs), cap_r / 50.0, 2.4e-7))) if cap_r > 0 else 0.0
+        atol = min(cap_a, up(max(16.0 * max(r["max_abs"] for r in rs), cap_a / 50.0, 1e-9))) if cap_a > 0 else 0.0
     else:
         rtol = min(cap_r, up(max(max(r["r4"] for r in rs), 2.4e-7))) if cap_r > 0 else 0.0
         atol = min(cap_a, up(max(4.0 * max(r["need"] for r in rs), 1e-9))) if cap_a > 0 else 0.0
