@@ -162,3 +162,56 @@ def test_train_iteration_at_the_config4_per_rank_shape():
     dead = [n for n, p in tr.agent.named_parameters() if p not in tr.agent_optimizer.state]
     assert dead and all("fc_mask" in n for n in dead)
     assert all(p.grad is None for p in tr.agent.parameters())
+
+
+def test_input_batch_loss_on_a_second_stream_changes_nothing():
+    """rl.train_iteration runs the detection loss of the INPUT batch on a second stream beside the agent's forward (the
+    retouched batch's forward, on the same engine buffers, waits for it). Both per-image losses the iteration used must be
+    exactly what the engine gives for those batches on one stream afterwards (same kernels, same inputs: bit for bit), over
+    three iterations on changing inputs; and the one-stream order (ADAISP_TRAIN_OVERLAP=0) passes the same check."""
+    from _synth import synth_state_dict, synth_yolo_state_dict, test_image
+    from adaptiveisp_amd.agent import Agent
+    from adaptiveisp_amd.config import cfg
+    from adaptiveisp_amd.rl import train_iteration
+    from adaptiveisp_amd.value import Value
+    from adaptiveisp_amd.yolo import YoloTrainEngine, yolov3
+    from adaptiveisp_amd.yolo.loss import DetectionLoss, assign_labels_packed, default_hyp
+    B, H, W = 4, 64, 96
+    det = yolov3()
+    det.load_state_dict(synth_yolo_state_dict(det))
+    det = det.to(DEV).train()
+    for m in det.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.eval()
+    for p in det.parameters():
+        p.requires_grad_(False)
+    eng = YoloTrainEngine(det, B, H, W, device=DEV)
+    loss_fn = DetectionLoss(det.model[-1].anchors, nc=80, hyp=default_hyp(80, W), device=DEV)
+    for overlap in ("1", "0"):
+        os.environ["ADAISP_TRAIN_OVERLAP"] = overlap
+        try:
+            torch.manual_seed(0)
+            agent = Agent(cfg, shape=(16, 64, 64), device=DEV)
+            agent.load_state_dict(synth_state_dict(agent, seed=0))
+            agent = agent.to(DEV).train()
+            value = Value(cfg, shape=(19, 64, 64))
+            value.load_state_dict(synth_state_dict(value, seed=1))
+            value = value.to(DEV).train()
+            opts = [torch.optim.Adam(agent.parameters(), lr=1e-3), torch.optim.Adam(value.parameters(), lr=1e-3)]
+            for i in range(3):
+                imgs = torch.from_numpy(test_image(B, H, W, seed=30 + i, special=False)).to(DEV)
+                z = torch.full((B, cfg.z_dim), 0.2 + 0.25 * i, device=DEV)
+                states = torch.zeros(B, cfg.num_state_dim, device=DEV)
+                labels = [torch.tensor([[0, 1 + b + i, 0.5, 0.5, 0.3, 0.4]]) for b in range(B)]
+                out = train_iteration(cfg, agent, value, eng, loss_fn, imgs, z, states, labels, 0.1, opts)
+                torch.cuda.synchronize()
+                with torch.no_grad():
+                    packed = assign_labels_packed(loss_fn, eng.head_shapes(), labels, imgs.device)
+                    l_in = eng.per_sample_loss(loss_fn, imgs, packed).clone()
+                    l_re = eng.per_sample_loss(loss_fn, out["retouch"], packed).clone()
+                assert torch.equal(out["detect_loss_input"], l_in), (overlap, i)
+                assert torch.equal(out["detect_loss_retouch"], l_re), (overlap, i)
+                assert float((l_in - l_re).abs().max()) > 0          # the two batches do differ: a mixed-up pass would show
+                assert torch.isfinite(out["reward"]).all()
+        finally:
+            del os.environ["ADAISP_TRAIN_OVERLAP"]
