@@ -67,6 +67,7 @@ class Agent(nn.Module):
         self._param_width = max(f.get_num_filter_parameters() for f in self.filters)
         self._fast = None            # fused eval path (policy_fast.FastPolicy), built on first use
         self._ones_mask = None
+        self._head_cache = None      # per-filter regressor constants of the batched training heads
         self._pool_cache = None      # (weakref to the image the last eval step returned, its version, its 64x64 pooling)
         self.use_fast_eval = True
 
@@ -172,8 +173,10 @@ class Agent(nn.Module):
         x_down = self.down_sample(x)
         coef = (1.0 - progress) * self.cfg.exploration_penalty
         coef_t = torch.full((1,), coef, dtype=torch.float32, device=x.device)
-        packed, op_ids, selected, surrogate, penalty, new_states, pdf, table, masks = self.policy_heads(
-            x_down, z[:, 0:1], states, coef_t, train=bool(train), forced_id=selected_filter_id, with_masks=True)
+        res = self.policy_heads(
+            x_down, z[:, 0:1], states, coef_t, train=bool(train), forced_id=selected_filter_id, with_masks=not train)
+        packed, op_ids, selected, surrogate, penalty, new_states, pdf, table = res[:8]
+        masks = res[8] if len(res) > 8 else None            # fc_mask outputs: eval only (unused while masking is off)
 
         filter_debug_info = []
         for j, flt in enumerate(self.filters):
@@ -182,7 +185,12 @@ class Agent(nn.Module):
             if hasattr(flt, "curve_steps"):                    # curve filters keep the reference's [steps,ch,1,1] view
                 p0 = p0.reshape(flt.curve_steps, -1, 1, 1)
             flt.mask_parameters = masks[j] if masks is not None else None
-            flt.mask = flt.get_mask(x, flt.mask_parameters)
+            if flt.use_masking():
+                flt.mask = flt.get_mask(x, flt.mask_parameters)
+            else:                                              # Filter.get_mask with masking off: ones(1,1,1,1) — one shared
+                if self._ones_mask is None or self._ones_mask.device != x.device:      # tensor instead of a fill launch per filter
+                    self._ones_mask = torch.ones((1, 1, 1, 1), dtype=torch.float32, device=x.device)
+                flt.mask = self._ones_mask
             filter_debug_info.append({'filter_parameters': p0, 'mask': flt.mask[0]})
 
         # pixels: only the selected filter runs
@@ -208,6 +216,64 @@ class Agent(nn.Module):
             return (x, new_states, surrogate, penalty), debug_info, debugger
         return (x, new_states, high_res_output), debug_info, debugger
 
+    # ------------------------------------------------------------------------------------------
+    # Training path: the ten filters' heads as ONE chain of batched ops. Per filter the reference runs fc1 (4096 -> 128),
+    # LeakyReLU, fc_filter (128 -> n) and a regressor of a handful of element-wise ops on a [B, n] tensor: ~40 tiny launches
+    # forward and ~90 backward per filter pair of passes, i.e. most of the ~750 launches of the agent in one RL iteration,
+    # each a few microseconds of dependent latency on an otherwise idle GPU. Here: the fc1 weights concatenated into one
+    # [F*128, 4096] matrix (one GEMM), the fc_filter weights scattered into a zero-padded [F, width, 128] stack (one batched
+    # GEMM), and the five regressor forms (include/adaisp.h: adaisp_regressor_kind — the same table the fused eval kernel
+    # uses) evaluated on the whole [B, F, width] tensor with per-filter constants and masks. Same parameters (the stacks are
+    # built from them inside autograd: gradients reach every nn.Linear as before), same formulas per element; matmul
+    # summation order differs from ten separate nn.Linear calls, so results agree to fp32 rounding, not bit for bit
+    # (tests/test_host_logic.py::test_batched_heads_match_the_per_filter_heads). `agent.batched_heads = False` restores the loop.
+    batched_heads = True
+
+    def _head_consts(self, device):
+        c = self._head_cache
+        if c is not None and c["device"] == device:
+            return c
+        if not all(f._regressor is not None for f in self.filters):
+            return None
+        F, pw = len(self.filters), self._param_width
+        specs = [f.regressor_spec() for f in self.filters]                 # (op, n, kind, lo, scale, bias)
+        t = lambda v: torch.tensor(v, dtype=torch.float32, device=device).view(1, F, 1)   # noqa: E731
+        kind = [sp[2] for sp in specs]
+        keep = torch.ones(1, F, pw, device=device)
+        for j, sp in enumerate(specs):
+            if sp[2] == 4:                                                  # white balance: the R gain is pinned (features * [0,1,1])
+                keep[0, j, 0] = 0.0
+        rows = [j * pw + k for j, sp in enumerate(specs) for k in range(sp[1])]
+        valid = torch.zeros(1, F, pw, device=device)
+        for j, sp in enumerate(specs):
+            valid[0, j, :sp[1]] = 1.0                                       # slots beyond a filter's n stay zero, as in the padded loop
+        b = lambda ks: torch.tensor([k in ks for k in kind], device=device).view(1, F, 1)   # noqa: E731
+        c = self._head_cache = dict(device=device, lo=t([sp[3] for sp in specs]), scale=t([sp[4] for sp in specs]),
+                                    bias=t([sp[5] for sp in specs]), keep=keep, is_exp=b((1, 4)), is_sig=b((2,)),
+                                    is_tanh=b((3,)), is_wb=b((4,)).view(1, F), valid=valid,
+                                    rows=torch.tensor(rows, dtype=torch.int64, device=device))
+        return c
+
+    def _heads_batched(self, features):
+        c = self._head_consts(features.device)
+        F, pw, B = len(self.filters), self._param_width, features.shape[0]
+        hid = self.cfg.fc1_size
+        w1 = torch.cat([f.fc1.weight for f in self.filters], 0)            # [F*hid, D]
+        b1 = torch.cat([f.fc1.bias for f in self.filters], 0)
+        hidden = torch.nn.functional.leaky_relu(torch.nn.functional.linear(features, w1, b1), 0.2).view(B, F, hid)
+        wr = torch.cat([f.fc_filter.weight for f in self.filters], 0)      # [sum n, hid]
+        br = torch.cat([f.fc_filter.bias for f in self.filters], 0)
+        wf = wr.new_zeros(F * pw, hid).index_copy(0, c["rows"], wr).view(F, pw, hid)
+        bf = br.new_zeros(F * pw).index_copy(0, c["rows"], br).view(F, 1, pw)
+        x = torch.baddbmm(bf, hidden.transpose(0, 1), wf.transpose(1, 2)).transpose(0, 1)      # [B,F,pw]
+        base = (torch.tanh(x * c["keep"] + c["bias"]) * 0.5 + 0.5) * c["scale"] + c["lo"]       # tanh_range (isp/filters.py:25-34)
+        out = torch.where(c["is_exp"], torch.exp(base), base)               # gamma, white balance
+        out = torch.where(c["is_sig"], torch.sigmoid(x), out)               # NLM, S+, BW
+        out = torch.where(c["is_tanh"], torch.tanh(x), out)                 # contrast
+        lum = 1e-5 + 0.27 * out[..., 0] + 0.67 * out[..., 1] + 0.06 * out[..., 2]               # isp/filters.py:204-206
+        norm = torch.where(c["is_wb"], 1.0 / lum, torch.ones_like(lum))
+        return out * (norm[..., None] * c["valid"])
+
     def policy_heads(self, x_down, noise, states, entropy_coef, train=True, forced_id=None, with_masks=False):
         """Everything of a step between the 64x64-pooled image and the pixels (agent.py:97-149, 234-280): both CNN trunks,
         every filter's heads and regressor, the selector's pdf, sampling / arg-max, one-hot bookkeeping, state update and
@@ -220,15 +286,19 @@ class Agent(nn.Module):
         filter_features = self.feature_extractor(net_in)
 
         # every filter's heads (cheap), no pixels yet
-        params, masks = [], []
-        for flt in self.filters:
-            hidden = flt.lrelu(flt.fc1(filter_features))
-            params.append(flt.filter_param_regressor(flt.fc_filter(hidden)))
-            if with_masks:
-                masks.append(flt.fc_mask(hidden))
         B = x_down.shape[0]
-        table = torch.stack([torch.nn.functional.pad(p.reshape(B, -1), (0, self._param_width - p[0].numel()))
-                             for p in params], dim=1)                       # [B,F,width]
+        masks = []
+        if train and not with_masks and self.batched_heads and self._head_consts(x_down.device) is not None:
+            table = self._heads_batched(filter_features)                    # [B,F,width], ten heads as three matmuls
+        else:
+            params = []
+            for flt in self.filters:
+                hidden = flt.lrelu(flt.fc1(filter_features))
+                params.append(flt.filter_param_regressor(flt.fc_filter(hidden)))
+                if with_masks:
+                    masks.append(flt.fc_mask(hidden))
+            table = torch.stack([torch.nn.functional.pad(p.reshape(B, -1), (0, self._param_width - p[0].numel()))
+                                 for p in params], dim=1)                   # [B,F,width]
 
         # action selection
         selector = self.lrelu(self.fc1(self.action_selection(net_in)))

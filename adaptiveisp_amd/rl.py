@@ -58,10 +58,12 @@ def lr_lambda(max_iter):
 
 
 def train_iteration(cfg, agent, value, detector, loss_fn, imgs, z, states, labels, progress, optimizers, buckets=None,
-                    use_truncated=True, max_bri=0.9):
+                    use_truncated=True, max_bri=0.9, on_retouch=None):
     """One optimisation step (train.py:255-351). `detector(x)` must return the three raw head maps with autograd
     through to x (the frozen reward model); `buckets` (adaptiveisp_amd.dist.GradBucket per model) enables the
-    data-parallel gradient all-reduce before the 1e-5 clip. Returns the scalars of td_losses plus the retouched batch."""
+    data-parallel gradient all-reduce before the 1e-5 clip. `on_retouch(retouch)` is called as soon as the retouched batch
+    is enqueued (the trainer starts its NaN / brightness guard there, long before the iteration's backward is launched).
+    Returns the scalars of td_losses plus the retouched batch."""
     from . import dist as adist
     from .yolo.loss import batched_per_sample_loss as per_sample_loss
     from .yolo.loss import assign_labels, assign_labels_packed
@@ -79,15 +81,21 @@ def train_iteration(cfg, agent, value, detector, loss_fn, imgs, z, states, label
             with torch.cuda.stream(side), torch.no_grad():
                 l_in = detector.per_sample_loss(loss_fn, imgs, packed)
             (retouch, new_states, surrogate, penalty), _, _ = agent((imgs, z, states), progress)
+            if on_retouch is not None:
+                on_retouch(retouch.detach())
             cur.wait_stream(side)                           # the engine's buffers are free again
             l_in.record_stream(cur)
         else:
             (retouch, new_states, surrogate, penalty), _, _ = agent((imgs, z, states), progress)
+            if on_retouch is not None:
+                on_retouch(retouch.detach())
             with torch.no_grad():
                 l_in = detector.per_sample_loss(loss_fn, imgs, packed)
         l_re = detector.per_sample_loss(loss_fn, retouch, packed)
     else:
         (retouch, new_states, surrogate, penalty), _, _ = agent((imgs, z, states), progress)
+        if on_retouch is not None:
+            on_retouch(retouch.detach())
         with torch.no_grad():
             p_in = detector(imgs)
             assigned = assign_labels(loss_fn, p_in, labels)      # same labels, same map shapes for both batches

@@ -41,6 +41,7 @@ class Trainer:
         self.value_scheduler = torch.optim.lr_scheduler.LambdaLR(self.value_optimizer, lr_lambda=lf)
         self.buckets = [adist.GradBucket(agent, value)]          # ONE flattened bucket = one collective per iteration
         self.iter = 0
+        self._flag_host = None
         adist.broadcast_parameters([agent, value], src=0)
         self.history = []
 
@@ -51,31 +52,72 @@ class Trainer:
         progress = float(it) / self.max_iter_step
         feed = self.replay.get_feed_dict_and_states(self.batch_size)
         labels = [torch.as_tensor(lb) for lb in feed["label"]]
+        guard = {}
+
+        def start_guard(retouch):
+            """The reference's check of the retouched batch (train.py:374-381: NaN / too dark / too bright -> the records are
+            dropped instead of re-entering the pool). Its inputs exist as soon as the filters have run, so it is launched
+            THEN, on a second stream, with its one flag copied to pinned host memory behind an event: the host reads it after
+            it has enqueued the rest of the iteration without waiting for that rest (a `bool(tensor)` on the main stream at
+            the end of the iteration drains the GPU every iteration)."""
+            if not retouch.is_cuda:
+                mean = torch.mean(retouch)
+                guard["bad"] = bool((~torch.isfinite(retouch)).any() | (mean < 0.01) | (mean > self.max_bri))
+                return
+            from .rl import _side_stream
+            cur, side = torch.cuda.current_stream(), _side_stream(retouch.device)
+            if self._flag_host is None:
+                self._flag_host = torch.empty((1,), dtype=torch.bool, pin_memory=True)
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                mean = torch.mean(retouch)
+                bad = ((~torch.isfinite(retouch)).any() | (mean < 0.01) | (mean > self.max_bri)).reshape(1)
+                self._flag_host.copy_(bad, non_blocking=True)
+                guard["event"] = torch.cuda.Event()
+                guard["event"].record(side)
+            retouch.record_stream(side)
+
         out = train_iteration(self.cfg, self.agent, self.value, self.detector, self.loss_fn, feed["im"], feed["z"],
                               feed["state"], labels, progress, [self.agent_optimizer, self.value_optimizer],
-                              buckets=self.buckets, use_truncated=self.use_truncated, max_bri=self.max_bri)
+                              buckets=self.buckets, use_truncated=self.use_truncated, max_bri=self.max_bri,
+                              on_retouch=start_guard)
         self.agent_scheduler.step()
         self.value_scheduler.step()
         retouch = out["retouch"]
-        mean = torch.mean(retouch)
-        bad = bool((~torch.isfinite(retouch)).any() | (mean < 0.01) | (mean > self.max_bri))   # one host sync, as the reference
+        if "event" in guard:
+            guard["event"].synchronize()                     # that flag only: the iteration's backward may still be running
+            bad = bool(self._flag_host[0])
+        else:
+            bad = guard["bad"]
         if bad:
             self.replay.drop_batch(feed["records"])
         else:
             self.replay.replace_memory(feed["records"], retouch, out["new_states"])
-        rec = dict(iter=it, agent_loss=float(out["agent_loss"].detach()), value_loss=float(out["value_loss"].detach()),
-                   reward=float(out["reward"].detach().mean()), dropped=bad)
+        # losses stay device tensors here: converting them would wait for the whole iteration; `materialize()` (called by
+        # train() at its end, by save(), and by anyone who wants numbers) turns them into floats
+        rec = dict(iter=it, agent_loss=out["agent_loss"].detach(), value_loss=out["value_loss"].detach(),
+                   reward=out["reward"].detach().mean(), dropped=bad)
         self.history.append(rec)
         self.iter += 1
+        if it % 256 == 255:
+            self.materialize()                               # (bounds the number of live 0-dim device tensors)
         if self.save_dir and self.rank == 0 and it % self.cfg.save_model_freq == 0 and it > 0:
             self.save(it)
         return rec
+
+    def materialize(self):
+        """History entries as plain floats (one synchronisation for all that are still device tensors)."""
+        for rec in self.history:
+            for k in ("agent_loss", "value_loss", "reward"):
+                if isinstance(rec[k], torch.Tensor):
+                    rec[k] = float(rec[k])
+        return self.history
 
     def train(self, iters=None):
         n = self.max_iter_step + 1 if iters is None else iters
         for _ in range(n):
             self.step()
-        return self.history
+        return self.materialize()
 
     def save(self, it):
         os.makedirs(self.save_dir, exist_ok=True)

@@ -143,3 +143,52 @@ def test_config1_plumbing_640_three_steps(oracle_mod):
             assert float(st2[0, 2]) == step + 1 and float(st2[0, 3 + k]) == 1.0 and int(dbg["selected_filter"][0]) == k
             assert float(y.min()) >= 0.0 and float(y.max()) <= 1.0 and torch.isfinite(pen).all()
             x, st = y, st2
+
+
+def test_batched_heads_match_the_per_filter_heads():
+    """Agent._heads_batched (training path: the ten filters' fc1 / fc_filter / regressor as three matmuls and one
+    element-wise pass over [B, F, width]) against the per-filter loop it replaces: every filter's regressed parameters and
+    the gradient of every head parameter, to fp32 rounding (the matmuls sum in another order); padded slots never leak."""
+    import torch
+    from _engine import cpu_agent
+    from adaptiveisp_amd.config import cfg
+    ag = cpu_agent(cfg, seed=0).train()
+    torch.manual_seed(3)
+    B, F, pw = 5, len(ag.filters), ag._param_width
+    feats = torch.randn(B, cfg.feature_extractor_dims) * 0.7
+    G = torch.randn(B, F, pw)
+
+    def loop():
+        ps = []
+        for flt in ag.filters:
+            p = flt.filter_param_regressor(flt.fc_filter(flt.lrelu(flt.fc1(feats))))
+            ps.append(torch.nn.functional.pad(p.reshape(B, -1), (0, pw - p[0].numel())))
+        return torch.stack(ps, 1)
+
+    heads = [p for flt in ag.filters for p in (flt.fc1.weight, flt.fc1.bias, flt.fc_filter.weight, flt.fc_filter.bias)]
+    ref = loop()
+    valid = torch.zeros(F, pw, dtype=torch.bool)
+    for j, flt in enumerate(ag.filters):
+        valid[j, :flt.get_num_filter_parameters()] = True
+    (ref * G * valid).sum().backward()
+    gref = [p.grad.clone() for p in heads]
+    ag.zero_grad(set_to_none=True)
+    got = ag._heads_batched(feats)
+    assert got.shape == (B, F, pw) and torch.isfinite(got).all()
+    torch.testing.assert_close(got[:, valid], ref[:, valid], rtol=2e-5, atol=2e-6)
+    (got * G * valid).sum().backward()
+    for p, g in zip(heads, gref):
+        torch.testing.assert_close(p.grad, g, rtol=1e-4, atol=1e-5 * max(1.0, float(g.abs().max())))
+    assert all(flt.fc_mask.weight.grad is None for flt in ag.filters)
+    # the training path of policy_heads uses it; eval (and `batched_heads = False`) keeps the loop
+    x_down, z, st = torch.rand(B, 3, 64, 64), torch.rand(B, 1), torch.zeros(B, cfg.num_state_dim)
+    coef = torch.tensor([0.01])
+    for p in ag.modules():
+        if isinstance(p, torch.nn.Dropout):
+            p.p = 0.0
+    a = ag.policy_heads(x_down, z, st, coef, train=True)
+    ag.batched_heads = False
+    b = ag.policy_heads(x_down, z, st, coef, train=True)
+    assert torch.equal(a[2], b[2]) and torch.equal(a[5], b[5])                   # selections, states
+    torch.testing.assert_close(a[0], b[0], rtol=2e-5, atol=2e-6)                 # packed parameters of the selected filters
+    torch.testing.assert_close(a[4], b[4], rtol=1e-5, atol=1e-6)
