@@ -13,6 +13,35 @@ static void magic_div(unsigned d, unsigned* magic, int* sh) {
     *sh = L - 1;
 }
 
+// Shared checks + derived fields of a conv launch (every conv entry point below). ADAYOLO_OK or the error to return.
+static int conv_args(ConvArgs& a, const void* in, int in_cstride, const void* weight, const float* bias, const void* residual,
+                     int res_cstride, void* out, int out_cstride, int B, int H, int W, int Cin, int Cout, int ksize, int stride,
+                     int act) {
+    if (!in || !weight || !bias || !out) return ADAYOLO_EINVAL;
+    if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return ADAYOLO_EINVAL;
+    if ((ksize != 1 && ksize != 3) || (stride != 1 && stride != 2)) return ADAYOLO_ESHAPE;
+    if (Cin % 8 || Cout % 8 || in_cstride % 8 || out_cstride % 8 || in_cstride < Cin || out_cstride < Cout)
+        return ADAYOLO_ESHAPE;
+    if (residual && (res_cstride % 8 || res_cstride < Cout)) return ADAYOLO_ESHAPE;
+    if (act != ADAYOLO_ACT_NONE && act != ADAYOLO_ACT_SILU) return ADAYOLO_EINVAL;
+    a.in = static_cast<const unsigned short*>(in); a.in_cs = in_cstride;
+    a.w = static_cast<const unsigned short*>(weight); a.bias = bias;
+    a.res = static_cast<const unsigned short*>(residual); a.res_cs = res_cstride;
+    a.out = static_cast<unsigned short*>(out); a.out_cs = out_cstride;
+    a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
+    a.ks = ksize; a.stride = stride; a.pad = ksize / 2; a.act = act;
+    a.Ho = (H + 2 * a.pad - ksize) / stride + 1;
+    a.Wo = (W + 2 * a.pad - ksize) / stride + 1;
+    const long M = (long)B * a.Ho * a.Wo;
+    if (M > 0x7fffffffL || (long)B * H * W * in_cstride > 0x7fffffffffL) return ADAYOLO_ESHAPE;
+    a.M = (int)M; a.mtiles = a.ntiles = 0;
+    a.w2 = nullptr; a.bias2 = nullptr; a.out2 = nullptr; a.out2_cs = 0;
+    a.pre = nullptr; a.pre_cs = 0;
+    magic_div((unsigned)(a.Ho * a.Wo), &a.magic_hw, &a.sh_hw);
+    magic_div((unsigned)a.Wo, &a.magic_w, &a.sh_w);
+    return ADAYOLO_OK;
+}
+
 extern "C" {
 
 int adayolo_abi_version(void) { return ADAYOLO_ABI_VERSION; }
@@ -32,29 +61,10 @@ const char* adayolo_strerror(int code) {
 int adayolo_conv_fwd_variant(const void* in, int in_cstride, const void* weight, const float* bias,
                              const void* residual, int res_cstride, void* out, int out_cstride, int B, int H, int W,
                              int Cin, int Cout, int ksize, int stride, int act, int variant, void* stream) {
-    if (!in || !weight || !bias || !out) return ADAYOLO_EINVAL;
-    if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return ADAYOLO_EINVAL;
-    if ((ksize != 1 && ksize != 3) || (stride != 1 && stride != 2)) return ADAYOLO_ESHAPE;
-    if (Cin % 8 || Cout % 8 || in_cstride % 8 || out_cstride % 8 || in_cstride < Cin || out_cstride < Cout)
-        return ADAYOLO_ESHAPE;
-    if (residual && (res_cstride % 8 || res_cstride < Cout)) return ADAYOLO_ESHAPE;
-    if (act != ADAYOLO_ACT_NONE && act != ADAYOLO_ACT_SILU) return ADAYOLO_EINVAL;
     ConvArgs a;
-    a.in = static_cast<const unsigned short*>(in); a.in_cs = in_cstride;
-    a.w = static_cast<const unsigned short*>(weight); a.bias = bias;
-    a.res = static_cast<const unsigned short*>(residual); a.res_cs = res_cstride;
-    a.out = static_cast<unsigned short*>(out); a.out_cs = out_cstride;
-    a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
-    a.ks = ksize; a.stride = stride; a.pad = ksize / 2; a.act = act;
-    a.Ho = (H + 2 * a.pad - ksize) / stride + 1;
-    a.Wo = (W + 2 * a.pad - ksize) / stride + 1;
-    const long M = (long)B * a.Ho * a.Wo;
-    if (M > 0x7fffffffL || (long)B * H * W * in_cstride > 0x7fffffffffL) return ADAYOLO_ESHAPE;
-    a.M = (int)M; a.mtiles = a.ntiles = 0;
-    a.w2 = nullptr; a.bias2 = nullptr; a.out2 = nullptr; a.out2_cs = 0;
-    a.pre = nullptr; a.pre_cs = 0;
-    magic_div((unsigned)(a.Ho * a.Wo), &a.magic_hw, &a.sh_hw);
-    magic_div((unsigned)a.Wo, &a.magic_w, &a.sh_w);
+    const int rc = conv_args(a, in, in_cstride, weight, bias, residual, res_cstride, out, out_cstride, B, H, W, Cin, Cout,
+                             ksize, stride, act);
+    if (rc != ADAYOLO_OK) return rc;
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (variant == 0) variant = ADAYOLO_DEFAULT_VARIANT;
     hipError_t e = hipErrorInvalidValue;
@@ -121,35 +131,51 @@ int adayolo_conv_fused1x1_fwd(const void* in, int in_cstride, const void* weight
 int adayolo_conv_keep_fwd(const void* in, int in_cstride, const void* weight, const float* bias, const void* residual,
                           int res_cstride, void* out, int out_cstride, void* pre, int pre_cstride, int B, int H, int W, int Cin,
                           int Cout, int ksize, int stride, int act, int variant, void* stream) {
-    if (!in || !weight || !bias || !out || !pre) return ADAYOLO_EINVAL;
-    if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return ADAYOLO_EINVAL;
-    if ((ksize != 1 && ksize != 3) || (stride != 1 && stride != 2)) return ADAYOLO_ESHAPE;
-    if (Cin % 8 || Cout % 8 || in_cstride % 8 || out_cstride % 8 || pre_cstride % 8 || in_cstride < Cin || out_cstride < Cout ||
-        pre_cstride < Cout)
-        return ADAYOLO_ESHAPE;
-    if (residual && (res_cstride % 8 || res_cstride < Cout)) return ADAYOLO_ESHAPE;
-    if (act != ADAYOLO_ACT_NONE && act != ADAYOLO_ACT_SILU) return ADAYOLO_EINVAL;
+    if (!pre) return ADAYOLO_EINVAL;
+    ConvArgs a;
+    const int rc = conv_args(a, in, in_cstride, weight, bias, residual, res_cstride, out, out_cstride, B, H, W, Cin, Cout,
+                             ksize, stride, act);
+    if (rc != ADAYOLO_OK) return rc;
+    if (pre_cstride % 8 || pre_cstride < Cout) return ADAYOLO_ESHAPE;
     const bool dma2 = variant == 5 || variant == 22 || variant == 26 || variant == 27;
     if (!dma2 && variant != 60) return ADAYOLO_EINVAL;       // the kernels whose epilogue has the second output
-    ConvArgs a;
-    a.in = static_cast<const unsigned short*>(in); a.in_cs = in_cstride;
-    a.w = static_cast<const unsigned short*>(weight); a.bias = bias;
-    a.res = static_cast<const unsigned short*>(residual); a.res_cs = res_cstride;
-    a.out = static_cast<unsigned short*>(out); a.out_cs = out_cstride;
-    a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
-    a.ks = ksize; a.stride = stride; a.pad = ksize / 2; a.act = act;
-    a.Ho = (H + 2 * a.pad - ksize) / stride + 1;
-    a.Wo = (W + 2 * a.pad - ksize) / stride + 1;
-    const long M = (long)B * a.Ho * a.Wo;
-    if (M > 0x7fffffffL || (long)B * H * W * in_cstride > 0x7fffffffffL) return ADAYOLO_ESHAPE;
-    a.M = (int)M; a.mtiles = a.ntiles = 0;
-    magic_div((unsigned)(a.Ho * a.Wo), &a.magic_hw, &a.sh_hw);
-    magic_div((unsigned)a.Wo, &a.magic_w, &a.sh_w);
-    a.w2 = nullptr; a.bias2 = nullptr; a.out2 = nullptr; a.out2_cs = 0;
     a.pre = static_cast<unsigned short*>(pre); a.pre_cs = pre_cstride;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const hipError_t e = dma2 ? launch_conv_dma2(a, s, variant) : launch_conv_pp128(a, s, variant);
     if (e == hipErrorInvalidValue) return ADAYOLO_ESHAPE;    // this kernel does not serve the shape: the caller keeps two launches
+    return e == hipSuccess ? ADAYOLO_OK : ADAYOLO_ELAUNCH;
+}
+
+size_t adayolo_conv_splitk_workspace_bytes(int B, int H, int W, int Cin, int Cout, int ksize, int stride, int variant) {
+    if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || (ksize != 1 && ksize != 3) || (stride != 1 && stride != 2))
+        return 0;
+    if (variant < ADAYOLO_SPLITK_BASE + 2 || variant > ADAYOLO_SPLITK_BASE + 16) return 0;
+    ConvArgs a;
+    a.Cin = Cin; a.Cout = Cout; a.ks = ksize;
+    const int pad = ksize / 2;
+    const long M = (long)B * ((H + 2 * pad - ksize) / stride + 1) * ((W + 2 * pad - ksize) / stride + 1);
+    if (M > 0x7fffffffL) return 0;
+    a.M = (int)M;
+    return conv_pp128_splitk_bytes(a, variant - ADAYOLO_SPLITK_BASE);
+}
+
+int adayolo_conv_splitk_fwd(const void* in, int in_cstride, const void* weight, const float* bias, const void* residual,
+                            int res_cstride, void* out, int out_cstride, void* pre, int pre_cstride, int B, int H, int W,
+                            int Cin, int Cout, int ksize, int stride, int act, int variant, void* workspace,
+                            size_t workspace_bytes, void* stream) {
+    if (!workspace) return ADAYOLO_EINVAL;
+    if (variant < ADAYOLO_SPLITK_BASE + 2 || variant > ADAYOLO_SPLITK_BASE + 16) return ADAYOLO_EINVAL;
+    ConvArgs a;
+    const int rc = conv_args(a, in, in_cstride, weight, bias, residual, res_cstride, out, out_cstride, B, H, W, Cin, Cout,
+                             ksize, stride, act);
+    if (rc != ADAYOLO_OK) return rc;
+    if (pre && (pre_cstride % 8 || pre_cstride < Cout)) return ADAYOLO_ESHAPE;
+    a.pre = static_cast<unsigned short*>(pre); a.pre_cs = pre ? pre_cstride : 0;
+    const size_t need = conv_pp128_splitk_bytes(a, variant - ADAYOLO_SPLITK_BASE);
+    if (need == 0) return ADAYOLO_ESHAPE;                    // this split does not serve the shape
+    if (workspace_bytes < need) return ADAYOLO_EINVAL;
+    const hipError_t e = launch_conv_pp128_splitk(a, static_cast<hipStream_t>(stream), variant - ADAYOLO_SPLITK_BASE, workspace,
+                                                  workspace_bytes);
     return e == hipSuccess ? ADAYOLO_OK : ADAYOLO_ELAUNCH;
 }
 

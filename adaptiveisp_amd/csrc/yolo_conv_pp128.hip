@@ -75,7 +75,7 @@ constexpr int kATile = BM * kRow;             // 32 KB
 constexpr int kBuf = (BM + BN) * kRow;        // one k-tile: 48 KB
 constexpr int kRing = 3 * kBuf;               // 144 KB
 constexpr int kEpiPitch = 144;                // bytes per pixel row of a wave's private epilogue region (64 ch + pad)
-constexpr int kSmem = kRing + BN * 4;         // + bias; the epilogue (8 x 64 x 144 B = 72 KB) overlays the finished ring
+constexpr int kSmem = kRing + BN * 4 + 16;    // + bias + the split-K ticket; the epilogue (8 x 64 x 144 B = 72 KB) overlays the finished ring
 
 struct KPos {                                 // wave-uniform position of a k-tile
     int c0, kh, kw, tap;
@@ -84,15 +84,30 @@ struct KPos {                                 // wave-uniform position of a k-ti
 
 // ABL: 0 real kernel, 5 no DMA instructions in the k-loop, 6 no epilogue, 7 activation DMA for one tap in nine
 // (measurement builds; profiles/round2_conv_pp_ablation.txt)
-template <int ABL>
+//
+// SPLIT (variants 100 + S, round 3): the k-tiles of one output tile are cut into S = a.ksplit equal ranges, one workgroup
+// each — for the layers whose pixel count leaves most CUs without a tile (8 x 16 x 16 px at 1024 channels: 32 tiles of 144
+// k-tiles; the training shapes of config 4). Every workgroup stores its fp32 accumulators to a.partial in its own lane
+// order (16 B per lane, 1 KB per wave and instruction), takes a ticket of the tile, and the workgroup that draws the last
+// one adds the S partial tiles IN SPLIT ORDER (its own included, read back: the sum does not depend on who arrives last)
+// and runs the ordinary epilogue. The partials may cross XCDs, i.e. L2s: they are stored and loaded at device scope (sc1)
+// and ordered by s_waitcnt vmcnt(0) + the ticket atomic — NOT by __threadfence(), whose release is a write-back of the
+// whole L2 per workgroup (measured on 1024 -> 512 k3 @ 8x16x16, S = 8: k-loop 18.8 us, + partial stores 23.4, + fence and
+// ticket 97; with sc1 accesses instead 27.8, + the last workgroup's S x 128 KB read-back and epilogue 43).
+// Workgroup -> (tile, range) with the range varying fastest: the S workgroups of a tile are neighbours on one XCD
+// (2-4 us better than tile-fastest).
+template <int ABL, bool SPLIT>
 __global__ __launch_bounds__(512) void k_conv_pp128(const ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float* bias_s = reinterpret_cast<float*>(smem + kRing);
+    int* ticket_s = reinterpret_cast<int*>(smem + kRing + BN * 4);
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave & 3, wn = wave >> 2;             // wn is also the ping-pong group
-    const int lid = xcd_remap(blockIdx.x, a.mtiles * a.ntiles);
+    const int ntile = a.mtiles * a.ntiles;
+    const int gid = xcd_remap(blockIdx.x, SPLIT ? ntile * a.ksplit : ntile);
+    const int lid = SPLIT ? gid / a.ksplit : gid, kpart = SPLIT ? gid - lid * a.ksplit : 0;   // the ranges of a tile are neighbours
     const int m0 = (lid / a.ntiles) * BM, n0 = (lid % a.ntiles) * BN;
     const unsigned long long zaddr = (unsigned long long)(const void*)g_zero16;
 
@@ -138,7 +153,7 @@ __global__ __launch_bounds__(512) void k_conv_pp128(const ConvArgs a) {
         }
     };
     const int cpt = a.Cin / BK;
-    const int nK = a.ks * a.ks * cpt;
+    const int nK = SPLIT ? a.ks * a.ks * cpt / a.ksplit : a.ks * a.ks * cpt;     // k-tiles of THIS workgroup
 
     auto advance = [&](KPos& p) {
         p.c0 += BK;
@@ -165,6 +180,13 @@ __global__ __launch_bounds__(512) void k_conv_pp128(const ConvArgs a) {
 
     // ---- prologue, in the steady-state issue order: W0(0); A(0); W1(0), W0(1); A(1); W1(1), W0(2); A(2)
     KPos q0{0, 0, 0, 0, 0, 0};
+    if (SPLIT) {                                         // first k-tile of this workgroup's range
+        const int t0 = kpart * nK;
+        q0.tap = t0 / cpt; q0.c0 = (t0 - q0.tap * cpt) * BK;
+        q0.kh = q0.tap / a.ks; q0.kw = q0.tap - q0.kh * a.ks;
+        q0.aoff = 2 * (((long)q0.kh * a.W + q0.kw) * a.in_cs + q0.c0);
+        q0.woff = 2 * ((long)q0.tap * a.Cin + q0.c0);
+    }
     KPos q1 = q0; advance(q1);
     KPos q2 = q1; advance(q2);
     if (wave == 0 && lane < 32) dma16((unsigned long long)(a.bias + n0) + 16 * lane, bias_s);   // 512 B: half a wave
@@ -288,6 +310,64 @@ __global__ __launch_bounds__(512) void k_conv_pp128(const ConvArgs a) {
         return;
     }
 
+    if constexpr (SPLIT) {
+        // partial tiles cross XCDs, i.e. L2s: stores and loads at DEVICE scope (sc1: written through / read past the
+        // non-coherent lines), ordered by s_waitcnt + the ticket — a __threadfence() here is a whole-L2 write-back per
+        // workgroup (measured: +70 us on a 25 us launch)
+        constexpr int kSc1 = 16;
+        const int S = a.ksplit;
+        const __amdgpu_buffer_rsrc_t rsP = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)(a.partial + (long)lid * S * (BM * BN)), 0, 0xFFFFFF00u, 0x00020000u);
+        const int mine = (kpart * 16 * 512 + tid) * 16;              // byte offset of this lane's first 16 B
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const u32x4 v = {__float_as_uint(acc[ni][mi][4 * g]), __float_as_uint(acc[ni][mi][4 * g + 1]),
+                                     __float_as_uint(acc[ni][mi][4 * g + 2]), __float_as_uint(acc[ni][mi][4 * g + 3])};
+                    __builtin_amdgcn_raw_buffer_store_b128(v, rsP, mine + ((ni * 2 + mi) * 4 + g) * (512 * 16), 0, kSc1);
+                }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's partials are written through
+        __syncthreads();
+        if (tid == 0) *ticket_s = __hip_atomic_fetch_add(a.tickets + lid, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        if (*ticket_s != S - 1) return;
+        if (tid == 0) __hip_atomic_store(a.tickets + lid, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // for the next launch
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[ni][mi][e] = 0.0f;
+        // S rounds of 16 loads per lane, the next round in flight while this one is added (a reducing CU pulls S x 128 KB)
+        u32x4 va[16], vb[16];
+        auto fetch = [&](u32x4 (&v)[16], int sp) {
+            const int src = (sp * 16 * 512 + tid) * 16;
+#pragma unroll
+            for (int j = 0; j < 16; ++j)
+                v[j] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsP, src + j * (512 * 16), 0, kSc1));
+        };
+        auto add = [&](const u32x4 (&v)[16]) {
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) acc[ni][mi][4 * g + c] += __uint_as_float(v[(ni * 2 + mi) * 4 + g][c]);
+        };
+        fetch(va, 0);
+        for (int sp = 0; sp < S; sp += 2) {
+            if (sp + 1 < S) fetch(vb, sp + 1);
+            add(va);
+            if (sp + 2 < S) fetch(va, sp + 2);
+            if (sp + 1 < S) add(vb);
+        }
+    }
+
     // ---- epilogue: wave-private LDS transpose (see yolo_conv_pp.hip), 32 px x 64 ch at a time, 128-byte row segments
     unsigned char* my = smem + wave * (64 * kEpiPitch);
     // see yolo_conv_pp.hip: compile-time activation / residual copies, bias and pointers hoisted, batched reads and stores
@@ -371,10 +451,10 @@ __global__ __launch_bounds__(512) void k_conv_pp128(const ConvArgs a) {
     }
 }
 
-template <int ABL>
+template <int ABL, bool SPLIT = false>
 static hipError_t launch(ConvArgs a, hipStream_t s) {
     static_assert(kSmem <= 160 * 1024, "LDS budget");
-    auto kern = k_conv_pp128<ABL>;
+    auto kern = k_conv_pp128<ABL, SPLIT>;
     static bool configured = false;
     if (!configured) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -384,11 +464,34 @@ static hipError_t launch(ConvArgs a, hipStream_t s) {
     }
     a.mtiles = (a.M + BM - 1) / BM;
     a.ntiles = a.Cout / BN;
-    hipLaunchKernelGGL(kern, dim3(a.mtiles * a.ntiles), dim3(512), kSmem, s, a);
+    hipLaunchKernelGGL(kern, dim3(a.mtiles * a.ntiles * (SPLIT ? a.ksplit : 1)), dim3(512), kSmem, s, a);
     return hipGetLastError();
 }
 
 }  // namespace pp128
+
+// Split-K form: S ranges of k-tiles per output tile. Served when the k-tiles divide evenly into ranges of at least
+// kMinRange, and the tile count leaves CUs free (otherwise the plain kernel is the better one anyway). Returns the bytes of
+// workspace the launch needs (tickets, then S fp32 partial tiles per output tile), 0 = not served.
+size_t conv_pp128_splitk_bytes(const ConvArgs& a, int S) {
+    constexpr int kMinRange = 4;
+    if (a.Cin % 64 || a.Cout % 128 || S < 2 || S > 16) return 0;
+    const int nK = a.ks * a.ks * (a.Cin / pp128::BK);
+    if (nK % S || nK / S < kMinRange) return 0;
+    const long tiles = (long)((a.M + pp128::BM - 1) / pp128::BM) * (a.Cout / pp128::BN);
+    if (tiles * S > 512) return 0;
+    return (size_t)((tiles * 4 + 1023) / 1024 * 1024) + (size_t)tiles * S * (pp128::BM * pp128::BN * 4);
+}
+
+hipError_t launch_conv_pp128_splitk(ConvArgs a, hipStream_t s, int S, void* workspace, size_t workspace_bytes) {
+    const size_t need = conv_pp128_splitk_bytes(a, S);
+    if (need == 0 || !workspace || workspace_bytes < need) return hipErrorInvalidValue;
+    const long tiles = (long)((a.M + pp128::BM - 1) / pp128::BM) * (a.Cout / pp128::BN);
+    a.ksplit = S;
+    a.tickets = static_cast<int*>(workspace);
+    a.partial = reinterpret_cast<float*>(static_cast<unsigned char*>(workspace) + (tiles * 4 + 1023) / 1024 * 1024);
+    return pp128::launch<0, true>(a, s);
+}
 
 // variant 60 = the kernel; with -DADAYOLO_MEASURE 65 / 66 = measurement builds. hipErrorInvalidValue -> not served.
 hipError_t launch_conv_pp128(ConvArgs a, hipStream_t s, int variant) {

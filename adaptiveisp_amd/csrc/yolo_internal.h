@@ -24,6 +24,9 @@ struct ConvArgs {
     // training forward (yolo_conv_dma2.hip / yolo_conv_pp128.hip): when set, the bf16 pre-activation (conv + bias) is stored
     // here and the activation is applied to that ROUNDED value — bit for bit what adayolo_silu_fwd makes of it
     unsigned short* pre; int pre_cs;
+    // split-K (yolo_conv_pp128.hip, variants 100 + S): S workgroups per output tile, fp32 partial tiles + one ticket per tile
+    // in the caller's workspace; 1 = every other kernel
+    float* partial = nullptr; int* tickets = nullptr; int ksplit = 1;
 };
 
 // Epilogue math on channel pairs: packed fp32 (v_pk_add/mul_f32 do two channels per issue slot; the two transcendentals
@@ -59,6 +62,8 @@ hipError_t launch_conv_dma2(ConvArgs a, hipStream_t s, int variant);  // lean-ad
 hipError_t launch_conv_small(ConvArgs a, hipStream_t s, int variant); // 3x3, Cin 32/64, whole K resident (yolo_conv_small.hip)
 hipError_t launch_conv_pp(ConvArgs a, hipStream_t s, int variant);    // 256x256 ping-pong wave groups (yolo_conv_pp.hip)
 hipError_t launch_conv_pp128(ConvArgs a, hipStream_t s, int variant); // 256x128 ping-pong, 3-deep ring (yolo_conv_pp128.hip)
+size_t conv_pp128_splitk_bytes(const ConvArgs& a, int S);               // workspace of the split-K form, 0 = shape not served
+hipError_t launch_conv_pp128_splitk(ConvArgs a, hipStream_t s, int S, void* workspace, size_t workspace_bytes);
 hipError_t launch_conv_pq(ConvArgs a, hipStream_t s, int variant);    // 256x128, 4 waves, two workgroups per CU (yolo_conv_pq.hip)
 hipError_t launch_conv_ws(ConvArgs a, hipStream_t s, int variant);    // 3x3 s1, Cin 32 / 64: weights in registers, patch in LDS, persistent (yolo_conv_ws.hip)
 hipError_t launch_stem(const float* img, const float* w, const float* bias, void* out, int out_cs, int B, int H,

@@ -106,7 +106,7 @@ class YoloEngine:
         args = [ctypes.c_void_p(src.ptr), src.cs, ctypes.c_void_p(w.data_ptr()), ctypes.c_void_p(b.data_ptr()),
                 ctypes.c_void_p(res.ptr) if res is not None else None, res.cs if res is not None else 0,
                 ctypes.c_void_p(dst.ptr), dst.cs, self.B, src.H, src.W, src.C, cout, k, s, act, 0]   # last: variant
-        self.plan.append(("conv", self.L.adayolo_conv_fwd_variant, args))
+        self.plan.append(("conv", self._conv_launch, args))
         self.ops.append(dict(kind="conv", src=src, dst=dst, res=res, w=w, b=b, k=k, s=s, act=act, cout=cout))
         flops = 2.0 * self.B * dst.H * dst.W * cout * k * k * src.C
         self.flops += flops
@@ -224,10 +224,42 @@ class YoloEngine:
         self.views = view
 
     # ------------------------------------------------------------------------------------------
-    TUNE_CANDIDATES = (2, 5, 22, 26, 27, 40, 50, 60, 80, 85, 90)
+    SPLITK_BASE = 100                                    # include/adayolo.h: variant 100 + S = variant 60 with S ranges of k-tiles
+    SPLITK_CANDIDATES = (102, 103, 104, 106, 108, 112, 116)
+    TUNE_CANDIDATES = (2, 5, 22, 26, 27, 40, 50, 60, 80, 85, 90) + SPLITK_CANDIDATES
 
     def _plans(self):
         return [self.plan]
+
+    # ---- split-K launches take a workspace (fp32 partial tiles + tickets): one per engine, sized for every conv of its
+    #      plans and every split the library serves for it; zeroed once, the kernels leave the tickets zero
+    def _splitk_bytes(self, args, variant):
+        return int(self.L.adayolo_conv_splitk_workspace_bytes(*args[8:15], variant))
+
+    def _splitk_workspace(self):
+        ws = getattr(self, "_splitk_ws", None)
+        if ws is None:
+            need = 0
+            for plan in self._plans():
+                for kind, _, args in plan:
+                    if kind == "conv":
+                        need = max([need] + [self._splitk_bytes(args, v) for v in self.SPLITK_CANDIDATES])
+            if torch.cuda.is_current_stream_capturing():
+                raise _lib.AdayoloError("split-K workspace requested inside a graph capture: run the engine once before capturing")
+            t = torch.zeros(max(need, 16), dtype=torch.uint8, device=self.dev)
+            ws = self._splitk_ws = (t, ctypes.c_void_p(t.data_ptr()), ctypes.c_size_t(t.numel()))
+        return ws
+
+    def _tune_penalty(self, key, variant):
+        """ms added to a candidate's measured time (what choosing it costs elsewhere; the training engine's forward)."""
+        return 0.0
+
+    def _conv_launch(self, *a):
+        """adayolo_conv_fwd_variant's argument list (17 + stream); the split-K variants go to their own entry point."""
+        if a[16] >= self.SPLITK_BASE:
+            _, ptr, nbytes = self._splitk_workspace()
+            return self.L.adayolo_conv_splitk_fwd(*a[:8], None, 0, *a[8:17], ptr, nbytes, a[17])
+        return self.L.adayolo_conv_fwd_variant(*a)
 
     def autotune(self, reps=5, cache=None, retune=False, write=True):
         """Pick the fastest conv kernel variant per layer by timing it on this engine's own buffers (all variants
@@ -270,9 +302,11 @@ class YoloEngine:
                             continue                             # 256x128 ping-pong kernel: Cin % 64 == 0, Cout % 128 == 0
                         if 80 <= v < 90 and (args[11] % 32 or args[12] % 128):
                             continue                             # 256x128, two workgroups per CU: Cin % 32 == 0, Cout % 128 == 0
-                        if v >= 90 and not (args[13] == 3 and args[14] == 1 and args[11] in (32, 64) and args[12] % 64 == 0 and
-                                            args[15] == _lib.ACT_SILU):
+                        if 90 <= v < 100 and not (args[13] == 3 and args[14] == 1 and args[11] in (32, 64) and args[12] % 64 == 0 and
+                                                  args[15] == _lib.ACT_SILU):
                             continue                             # weights-in-registers kernel: 3x3 s1, Cin 32 / 64
+                        if v >= self.SPLITK_BASE and self._splitk_bytes(args, v) == 0:
+                            continue                             # this split does not serve the shape
                         args[16] = v
                         fn(*args, st)
                         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -283,6 +317,7 @@ class YoloEngine:
                             e1.record()
                             e1.synchronize()
                             t = min(t, e0.elapsed_time(e1))
+                        t += self._tune_penalty(key, v)
                         if t < best[1]:
                             best = (v, t)
                     chosen[key] = best[0]

@@ -36,7 +36,7 @@ class YoloTrainEngine(YoloEngine):
         args = [ctypes.c_void_p(src.ptr), src.cs, ctypes.c_void_p(w.data_ptr()), ctypes.c_void_p(b.data_ptr()),
                 ctypes.c_void_p(res.ptr) if res is not None else None, res.cs if res is not None else 0,
                 ctypes.c_void_p(dst.ptr), dst.cs, self.B, src.H, src.W, src.C, cout, k, s, act, 0]
-        return ("conv", self.L.adayolo_conv_fwd_variant, args)
+        return ("conv", self._conv_launch, args)
 
     def _build_train(self):
         L, B = self.L, self.B
@@ -157,6 +157,22 @@ class YoloTrainEngine(YoloEngine):
     def _plans(self):
         return [self.plan, [e for e in self.tfwd if e[0] == "conv"], [e for e in self.tbwd if e[0] == "conv"]]
 
+    def _tune_penalty(self, key, variant):
+        """A forward conv followed by SiLU runs as ONE launch only on the kernels that can store the pre-activation
+        (KEEP_VARIANTS); any other choice adds the adayolo_silu_fwd launch: pre-activation read, activation written
+        (+ residual read) at ~4 TB/s, + ~3 us of launch — an estimate, the choice only has to be right where it matters."""
+        if variant in self.KEEP_VARIANTS:
+            return 0.0
+        cost = getattr(self, "_silu_cost", None)
+        if cost is None:
+            cost = self._silu_cost = {}
+            for i, e in enumerate(self.tfwd[:-1]):
+                nxt = self.tfwd[i + 1]
+                if e[0] == "conv" and nxt[0] == "silu" and e[2][6].value == nxt[2][0].value:
+                    npix, C, has_res = nxt[2][6], nxt[2][7], nxt[2][2] is not None
+                    cost[tuple(e[2][8:16])] = 2.0 * npix * C * (3 if has_res else 2) / 4e9 + 0.003
+        return cost.get(key, 0.0)
+
     # ------------------------------------------------------------------------------------------
     def _run(self, plan, img=None, grad_img=None):
         st = _lib.stream_ptr()
@@ -176,7 +192,15 @@ class YoloTrainEngine(YoloEngine):
             if rc != 0:
                 _lib.check(rc, f"adayolo {kind}")
 
-    KEEP_VARIANTS = (5, 22, 26, 27, 60)            # kernels whose epilogue stores the pre-activation beside the activation
+    # kernels whose epilogue stores the pre-activation beside the activation
+    KEEP_VARIANTS = (5, 22, 26, 27, 60) + YoloEngine.SPLITK_CANDIDATES
+
+    def _conv_keep_launch(self, *a):
+        """adayolo_conv_keep_fwd's argument list (19 + stream); the split-K variants go to their own entry point."""
+        if a[18] >= self.SPLITK_BASE:
+            _, ptr, nbytes = self._splitk_workspace()
+            return self.L.adayolo_conv_splitk_fwd(*a[:19], ptr, nbytes, a[19])
+        return self.L.adayolo_conv_keep_fwd(*a)
 
     def _forward_plan(self):
         """tfwd with every [conv -> pre-activation, SiLU(+residual)] pair whose tuned kernel can do both in one launch
@@ -198,9 +222,9 @@ class YoloTrainEngine(YoloEngine):
                 # silu args: pre, pre_cs, res, res_cs, out, out_cs, npix, C
                 args = (a[0], a[1], a[2], a[3], sl[2], sl[3], sl[4], sl[5], a[6], a[7], a[8], a[9], a[10], a[11], a[12], a[13],
                         a[14], _lib.ACT_SILU, a[16])
-                rc = self.L.adayolo_conv_keep_fwd(*args, _lib.stream_ptr())   # probe once: ESHAPE = this kernel does not serve the shape
+                rc = self._conv_keep_launch(*args, _lib.stream_ptr())   # probe once: ESHAPE = this kernel does not serve the shape
                 if rc == 0:
-                    plan.append(("convkeep", self.L.adayolo_conv_keep_fwd, args))
+                    plan.append(("convkeep", self._conv_keep_launch, args))
                     i += 2
                     continue
             plan.append(e)

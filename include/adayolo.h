@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define ADAYOLO_ABI_VERSION 2
+#define ADAYOLO_ABI_VERSION 3
 
 #define ADAYOLO_ACT_NONE 0
 #define ADAYOLO_ACT_SILU 1
@@ -125,6 +125,25 @@ int adayolo_stem_down_fwd(const float* img, const float* w_stem, const float* b_
 int adayolo_conv_keep_fwd(const void* in, int in_cstride, const void* weight, const float* bias, const void* residual,
                           int res_cstride, void* out, int out_cstride, void* pre, int pre_cstride, int B, int H, int W, int Cin,
                           int Cout, int ksize, int stride, int act, int variant, void* stream);
+
+/*
+ * Split-K form of variant 60 for layers with few output tiles and a long reduction (e.g. Conv 512 -> 1024 k3 on 8 x 16 x 16
+ * pixels: 64 tiles of 72 k-tiles on 256 CUs — the shapes of the RL training step, config 4): variant =
+ * ADAYOLO_SPLITK_BASE + S, 2 <= S <= 16. The k-tiles (64 input channels of one tap) of every 256 px x 128 ch output tile
+ * are cut into S equal ranges, one workgroup each; fp32 partial tiles go through `workspace`, the workgroup that finishes
+ * a tile last adds them in range order (deterministic) and applies bias / activation / residual (and stores `pre` when
+ * given, as adayolo_conv_keep_fwd). Same layouts and checks as adayolo_conv_fwd_variant; Cin % 64 == 0, Cout % 128 == 0,
+ * the k-tile count divisible by S with at least 4 per range, tiles x S <= 512 — ESHAPE otherwise.
+ * `workspace`: adayolo_conv_splitk_workspace_bytes(...) bytes (0 = this split does not serve the shape), ZEROED ONCE by
+ * the caller before the first launch (every launch leaves its tickets zero); one workspace serves the launches of one
+ * stream, launches that may overlap need their own.
+ */
+#define ADAYOLO_SPLITK_BASE 100
+size_t adayolo_conv_splitk_workspace_bytes(int B, int H, int W, int Cin, int Cout, int ksize, int stride, int variant);
+int adayolo_conv_splitk_fwd(const void* in, int in_cstride, const void* weight, const float* bias, const void* residual,
+                            int res_cstride, void* out, int out_cstride, void* pre, int pre_cstride, int B, int H, int W,
+                            int Cin, int Cout, int ksize, int stride, int act, int variant, void* workspace,
+                            size_t workspace_bytes, void* stream);
 
 /* adayolo_stem_fwd with the activation selectable (ADAYOLO_ACT_NONE keeps the pre-activation for training). */
 int adayolo_stem_fwd_act(const float* img, const float* weight, const float* bias, void* out, int out_cstride,

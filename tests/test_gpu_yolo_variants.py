@@ -25,8 +25,19 @@ def _table():
     return {tuple(int(x) for x in k.split(",")): int(v) for k, v in json.load(open(TUNE)).items()}
 
 
-def _serves(v, cin, cout, k, s):
-    """Shapes a variant is specialised for (adayolo.h: other shapes fall through to the default kernel)."""
+SPLITK_BASE = 100
+
+
+def _splitk_bytes(v, B, H, W, cin, cout, k, s):
+    from adaptiveisp_amd.yolo import _lib
+    return int(_lib.load().adayolo_conv_splitk_workspace_bytes(B, H, W, cin, cout, k, s, v))
+
+
+def _serves(v, cin, cout, k, s, bhw=None):
+    """Shapes a variant is specialised for (adayolo.h: other shapes fall through to the default kernel; a split-K variant
+    serves what adayolo_conv_splitk_workspace_bytes says it serves and nothing else)."""
+    if v >= SPLITK_BASE:
+        return bhw is not None and _splitk_bytes(v, *bhw, cin, cout, k, s) > 0
     if 40 <= v < 50:
         return k == 3 and cin in (32, 64)
     if 50 <= v < 60:
@@ -40,19 +51,31 @@ def _serves(v, cin, cout, k, s):
     return True
 
 
-def _run_variant(x, w, b, res, k, s, act, v, reps=4):
+def _run_variant(x, w, b, res, k, s, act, v, reps=4, pre=None):
     from adaptiveisp_amd.yolo import _lib
     L = _lib.load()
     B, H, W, cin = x.shape
     cout = w.shape[0]
     Ho, Wo = (H - 1) // s + 1, (W - 1) // s + 1
     first = None
+    ws = None
+    if v >= SPLITK_BASE:                                # ONE zeroed workspace for all launches: each must leave its tickets zero
+        ws = torch.zeros(_splitk_bytes(v, B, H, W, cin, cout, k, s), dtype=torch.uint8, device=DEV)
+        assert ws.numel() > 0, f"split variant {v} does not serve {(B, H, W, cin, cout, k, s)}"
     for _ in range(reps):
         out = torch.full((B, Ho, Wo, cout), float("nan"), dtype=torch.bfloat16, device=DEV)
-        rc = L.adayolo_conv_fwd_variant(ctypes.c_void_p(x.data_ptr()), cin, ctypes.c_void_p(w.data_ptr()),
-                                        ctypes.c_void_p(b.data_ptr()), ctypes.c_void_p(res.data_ptr()) if res is not None else None,
-                                        cout if res is not None else 0, ctypes.c_void_p(out.data_ptr()), cout, B, H, W, cin,
-                                        cout, k, s, act, v, _lib.stream_ptr())
+        common = (ctypes.c_void_p(x.data_ptr()), cin, ctypes.c_void_p(w.data_ptr()), ctypes.c_void_p(b.data_ptr()),
+                  ctypes.c_void_p(res.data_ptr()) if res is not None else None, cout if res is not None else 0,
+                  ctypes.c_void_p(out.data_ptr()), cout)
+        if ws is not None:
+            rc = L.adayolo_conv_splitk_fwd(*common, ctypes.c_void_p(pre.data_ptr()) if pre is not None else None,
+                                           cout if pre is not None else 0, B, H, W, cin, cout, k, s, act, v,
+                                           ctypes.c_void_p(ws.data_ptr()), ws.numel(), _lib.stream_ptr())
+        elif pre is not None:
+            rc = L.adayolo_conv_keep_fwd(*common, ctypes.c_void_p(pre.data_ptr()), cout, B, H, W, cin, cout, k, s, act, v,
+                                         _lib.stream_ptr())
+        else:
+            rc = L.adayolo_conv_fwd_variant(*common, B, H, W, cin, cout, k, s, act, v, _lib.stream_ptr())
         _lib.check(rc, "conv")
         torch.cuda.synchronize()
         if first is None:
@@ -118,12 +141,18 @@ RAGGED = [  # B, H, W, Cin, Cout, k, s, residual — partial tiles in M and N, t
 ]
 
 
+SPLIT_RAGGED = [  # long reductions on few pixels (what the split-K variants are for), ragged in M
+    (1, 5, 6, 1024, 512, 3, 1, True), (2, 9, 7, 512, 256, 3, 1, False), (3, 5, 5, 1024, 128, 1, 1, False),
+    (2, 13, 17, 256, 128, 3, 1, True), (1, 16, 16, 512, 1024, 3, 2, False), (8, 16, 16, 1024, 512, 3, 1, True),
+]
+
+
 @pytest.mark.parametrize("v", _used_variants())
 def test_every_tuned_variant_on_ragged_shapes(v):
     """Every variant the table can select, on small / odd / partial-tile shapes it serves, act on and off."""
     n = 0
-    for (B, H, W, cin, cout, k, s, use_res) in RAGGED:
-        if _serves(v, cin, cout, k, s):
+    for (B, H, W, cin, cout, k, s, use_res) in RAGGED + (SPLIT_RAGGED if v >= SPLITK_BASE else []):
+        if _serves(v, cin, cout, k, s, (B, H, W)):
             _check((B, H, W, cin, cout, k, s), v, use_res, acts=(0, 1))
             n += 1
     assert n >= 3, f"variant {v}: too few shapes exercised"
@@ -134,6 +163,8 @@ def test_variant_channel_slices(v):
     """Concat is free because convs read / write channel slices of wider tensors: strides larger than C, every variant."""
     from adaptiveisp_amd.yolo import _lib
     L = _lib.load()
+    if v >= SPLITK_BASE:
+        pytest.skip("split-K variants: slices are covered by test_splitk_conv (their own entry point)")
     cin, cout, k, s = (64, 256, 3, 1)
     g = torch.Generator(device="cpu").manual_seed(50 + v)
     wide_in = torch.randn(2, 21, 35, cin + 64, generator=g).to(torch.bfloat16).to(DEV)
@@ -272,3 +303,71 @@ def test_fused_entry_rejects_other_shapes():
     rc = L.adayolo_conv_fused1x1_fwd(P(t), 256, P(t), P(f), None, 0, P(t), 256, 1, 8, 8, 256, 256, 1, 1, 1, None, P(f), P(t), 128, 128,
                                      _lib.stream_ptr())
     assert rc != 0
+
+
+SPLITK_CASES = [  # B, H, W, Cin, Cout, k, s, residual: the deep layers of the 8 x 512 x 512 training step, forward and data gradient
+    (8, 16, 16, 512, 1024, 3, 1, True), (8, 16, 16, 1024, 512, 3, 1, True), (8, 32, 32, 512, 256, 3, 1, False),
+    (8, 32, 32, 256, 512, 3, 1, True), (8, 32, 32, 512, 1024, 3, 2, False), (8, 16, 16, 1024, 512, 1, 1, False),
+    (2, 13, 17, 256, 128, 3, 1, True), (1, 5, 6, 1024, 512, 3, 1, False),
+]
+
+
+@pytest.mark.parametrize("case", SPLITK_CASES, ids=lambda c: "x".join(map(str, c)))
+def test_splitk_conv(case):
+    """adayolo_conv_splitk_fwd, every split S the library serves for the shape: fp32 conv reference within the variants'
+    tolerance, four launches on ONE workspace bit-identical (deterministic range-order sum, tickets left zero), NaN-prefilled
+    outputs fully written; with `pre`: pre is the bf16 pre-activation and out == silu(pre) (+ residual) computed from
+    that rounded value (the contract of adayolo_conv_keep_fwd / adayolo_silu_fwd); channel-slice strides honoured."""
+    from adaptiveisp_amd.yolo import _lib
+    L = _lib.load()
+    B, H, W, cin, cout, k, s, use_res = case
+    served = [v for v in range(SPLITK_BASE + 2, SPLITK_BASE + 17) if _splitk_bytes(v, B, H, W, cin, cout, k, s) > 0]
+    assert served, f"no split serves {case}"
+    assert _splitk_bytes(SPLITK_BASE + 1, B, H, W, cin, cout, k, s) == 0 and _splitk_bytes(SPLITK_BASE + 17, B, H, W, cin, cout, k, s) == 0
+    g = torch.Generator(device="cpu").manual_seed(H * 131 + cin * 7 + cout)
+    x = torch.randn(B, H, W, cin, generator=g).to(torch.bfloat16).to(DEV)
+    w = (torch.randn(cout, k, k, cin, generator=g) / (k * k * cin) ** 0.5).to(torch.bfloat16).to(DEV)
+    b = torch.randn(cout, generator=g).to(DEV)
+    Ho, Wo = (H - 1) // s + 1, (W - 1) // s + 1
+    res = torch.randn(B, Ho, Wo, cout, generator=g).to(torch.bfloat16).to(DEV) if use_res else None
+    for v in served:
+        for act in (0, 1):
+            out = _run_variant(x, w, b, res, k, s, act, v)
+            ref = _reference(x, w, b, res, k, s, act)
+            assert torch.isfinite(out.float()).all(), f"v{v}: unwritten (NaN) outputs"
+            scale = max(1.0, ref.abs().max().item())
+            d = (out.float() - ref).abs()
+            assert d.max().item() <= 2e-2 * scale and d.mean().item() <= 2e-3 * scale, (v, act, d.max().item(), d.mean().item())
+        # training forward: second output
+        pre = torch.full((B, Ho, Wo, cout), float("nan"), dtype=torch.bfloat16, device=DEV)
+        out = _run_variant(x, w, b, res, k, s, 1, v, reps=2, pre=pre)
+        lin = _run_variant(x, w, b, None, k, s, 0, v, reps=1)
+        assert torch.equal(pre.view(torch.int16), lin.view(torch.int16)), f"v{v}: pre is not the conv + bias output"
+        two = torch.empty_like(out)
+        rc = L.adayolo_silu_fwd(ctypes.c_void_p(pre.data_ptr()), cout, ctypes.c_void_p(res.data_ptr()) if use_res else None,
+                                cout if use_res else 0, ctypes.c_void_p(two.data_ptr()), cout, B * Ho * Wo, cout, _lib.stream_ptr())
+        _lib.check(rc, "silu_fwd")
+        torch.cuda.synchronize()
+        assert torch.equal(two.view(torch.int16), out.view(torch.int16)), f"v{v}: out differs from silu_fwd(pre, residual)"
+    # channel slices of wider tensors, one split
+    v = served[len(served) // 2]
+    wide_in = torch.randn(B, H, W, cin + 64, generator=g).to(torch.bfloat16).to(DEV)
+    wide_out = torch.full((B, Ho, Wo, cout + 128), 7.0, dtype=torch.bfloat16, device=DEV)
+    xin, xout = wide_in[..., 32:32 + cin], wide_out[..., 64:64 + cout]
+    ws = torch.zeros(_splitk_bytes(v, B, H, W, cin, cout, k, s), dtype=torch.uint8, device=DEV)
+    rc = L.adayolo_conv_splitk_fwd(ctypes.c_void_p(xin.data_ptr()), cin + 64, ctypes.c_void_p(w.data_ptr()), ctypes.c_void_p(b.data_ptr()),
+                                   None, 0, ctypes.c_void_p(xout.data_ptr()), cout + 128, None, 0, B, H, W, cin, cout, k, s, 1, v,
+                                   ctypes.c_void_p(ws.data_ptr()), ws.numel(), _lib.stream_ptr())
+    _lib.check(rc, "splitk conv")
+    torch.cuda.synchronize()
+    ref = _reference(xin.contiguous(), w, b, None, k, s, 1)
+    assert (xout.float() - ref).abs().max().item() <= 2e-2 * max(1.0, ref.abs().max().item())
+    assert (wide_out[..., :64] == 7).all() and (wide_out[..., 64 + cout:] == 7).all()
+    assert int(ws[: 1024].view(torch.int32).abs().sum()) == 0, "tickets not left zero"
+    # argument checks of the entry point
+    small = torch.zeros(1024, dtype=torch.uint8, device=DEV)
+    args = (ctypes.c_void_p(x.data_ptr()), cin, ctypes.c_void_p(w.data_ptr()), ctypes.c_void_p(b.data_ptr()), None, 0,
+            ctypes.c_void_p(wide_out.data_ptr()), cout + 128, None, 0, B, H, W, cin, cout, k, s, 1)
+    assert L.adayolo_conv_splitk_fwd(*args, v, ctypes.c_void_p(small.data_ptr()), small.numel(), _lib.stream_ptr()) == -1   # EINVAL: workspace too small
+    assert L.adayolo_conv_splitk_fwd(*args, v, None, 0, _lib.stream_ptr()) == -1
+    assert L.adayolo_conv_splitk_fwd(*args, 60, ctypes.c_void_p(ws.data_ptr()), ws.numel(), _lib.stream_ptr()) == -1        # not a split variant
