@@ -179,6 +179,37 @@ int adayolo_conv_splitk_fwd(const void* in, int in_cstride, const void* weight, 
     return e == hipSuccess ? ADAYOLO_OK : ADAYOLO_ELAUNCH;
 }
 
+int adayolo_conv_dsilu_fwd(const void* in, int in_cstride, const void* weight, const float* bias, const void* residual,
+                           int res_cstride, void* out, int out_cstride, const void* pre, int pre_cstride, void* grad_pre,
+                           int gp_cstride, int B, int H, int W, int Cin, int Cout, int ksize, int stride, int variant,
+                           void* workspace, size_t workspace_bytes, void* stream) {
+    if (!pre || !grad_pre) return ADAYOLO_EINVAL;
+    ConvArgs a;
+    const int rc = conv_args(a, in, in_cstride, weight, bias, residual, res_cstride, out ? out : grad_pre,
+                             out ? out_cstride : gp_cstride, B, H, W, Cin, Cout, ksize, stride, ADAYOLO_ACT_NONE);
+    if (rc != ADAYOLO_OK) return rc;
+    if (pre_cstride % 8 || pre_cstride < Cout || gp_cstride % 8 || gp_cstride < Cout) return ADAYOLO_ESHAPE;
+    a.out = static_cast<unsigned short*>(out); a.out_cs = out ? out_cstride : 0;
+    a.pre = static_cast<unsigned short*>(const_cast<void*>(pre)); a.pre_cs = pre_cstride;      // an input here
+    a.gpre = static_cast<unsigned short*>(grad_pre); a.gpre_cs = gp_cstride;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    hipError_t e;
+    if (variant >= ADAYOLO_SPLITK_BASE + 2 && variant <= ADAYOLO_SPLITK_BASE + 16) {
+        const size_t need = conv_pp128_splitk_bytes(a, variant - ADAYOLO_SPLITK_BASE);
+        if (need == 0) return ADAYOLO_ESHAPE;
+        if (!workspace || workspace_bytes < need) return ADAYOLO_EINVAL;
+        e = launch_conv_pp128_splitk(a, s, variant - ADAYOLO_SPLITK_BASE, workspace, workspace_bytes);
+    } else if (variant == 5 || variant == 22 || variant == 26 || variant == 27) {
+        e = launch_conv_dma2(a, s, variant);
+    } else if (variant == 60) {
+        e = launch_conv_pp128(a, s, variant);
+    } else {
+        return ADAYOLO_EINVAL;                               // the kernels whose epilogue has this form
+    }
+    if (e == hipErrorInvalidValue) return ADAYOLO_ESHAPE;    // the named kernel does not serve the shape
+    return e == hipSuccess ? ADAYOLO_OK : ADAYOLO_ELAUNCH;
+}
+
 int adayolo_conv_fwd(const void* in, int in_cstride, const void* weight, const float* bias, const void* residual,
                      int res_cstride, void* out, int out_cstride, int B, int H, int W, int Cin, int Cout, int ksize,
                      int stride, int act, void* stream) {

@@ -268,7 +268,7 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void k_conv_igemm_dma32(const C
         const int m = m0 + ml, n = n0 + ch;
         if (m >= a.M || n >= a.Cout) continue;
         u32x4 v = *reinterpret_cast<const u32x4*>(Cs + ml * CP + ch);
-        if (a.pre) {                                          // training forward: keep the pre-activation, activate its bf16 value
+        if (a.pre && !a.gpre) {                               // training forward: keep the pre-activation, activate its bf16 value
             *reinterpret_cast<u32x4*>(a.pre + (long)m * a.pre_cs + n) = v;
             if (a.act == ADAYOLO_ACT_SILU) {
 #pragma unroll
@@ -285,6 +285,14 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void k_conv_igemm_dma32(const C
             }
         }
         if (ABL == 7 && v[0] != 0x12345678u) continue;        // ablation: everything but the global stores
+        if (a.gpre) {                                         // backward: v is dL/d(layer output); gpre = v * silu'(pre)
+            if (a.out) ADAYOLO_STORE(v, reinterpret_cast<u32x4*>(a.out + (long)m * a.out_cs + n));
+            const u32x4 p = *reinterpret_cast<const u32x4*>(a.pre + (long)m * a.pre_cs + n);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = dsilu_bf16x2(v[j], p[j]);
+            ADAYOLO_STORE(v, reinterpret_cast<u32x4*>(a.gpre + (long)m * a.gpre_cs + n));
+            continue;
+        }
         ADAYOLO_STORE(v, reinterpret_cast<u32x4*>(a.out + (long)m * a.out_cs + n));
     }
 }

@@ -371,9 +371,10 @@ __global__ __launch_bounds__(512) void k_conv_pp128(const ConvArgs a) {
     // ---- epilogue: wave-private LDS transpose (see yolo_conv_pp.hip), 32 px x 64 ch at a time, 128-byte row segments
     unsigned char* my = smem + wave * (64 * kEpiPitch);
     // see yolo_conv_pp.hip: compile-time activation / residual copies, bias and pointers hoisted, batched reads and stores
-    auto epilogue = [&](auto silu_tag, auto res_tag, auto keep_tag) {
+    auto epilogue = [&](auto silu_tag, auto res_tag, auto keep_tag, auto ds_tag) {
         // kKeep: the tile goes through LDS as the bf16 PRE-activation (kSilu off), is stored to a.pre, then activated
-        constexpr bool kKeep = decltype(keep_tag)::value, kAct = decltype(silu_tag)::value;
+        // kDs (backward): the result (+ residual) is dL/d(layer output), stored when a.out is set; a.gpre = it * silu'(a.pre)
+        constexpr bool kKeep = decltype(keep_tag)::value, kAct = decltype(silu_tag)::value, kDs = decltype(ds_tag)::value;
         constexpr bool kSilu = kAct && !kKeep, kRes = decltype(res_tag)::value;
         typedef __attribute__((ext_vector_type(2))) float f32x2v;
         float4 bq[2][4];
@@ -434,6 +435,27 @@ __global__ __launch_bounds__(512) void k_conv_pp128(const ConvArgs a) {
                         v[it][j] = pack_bf16x2(x.x, x.y);
                     }
             }
+            if (kDs) {
+                u32x4 p[4];
+#pragma unroll
+                for (int it = 0; it < 4; ++it) {
+                    p[it] = u32x4{0u, 0u, 0u, 0u};
+                    if (ok[it]) p[it] = *reinterpret_cast<const u32x4*>(a.pre + (long)(mrow + 8 * (4 * mi + it)) * a.pre_cs + n);
+                }
+                if (a.out) {
+#pragma unroll
+                    for (int it = 0; it < 4; ++it)
+                        if (ok[it]) __builtin_nontemporal_store(v[it], reinterpret_cast<u32x4*>(op + (4 * mi + it) * ostep));
+                }
+#pragma unroll
+                for (int it = 0; it < 4; ++it) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[it][j] = dsilu_bf16x2(v[it][j], p[it][j]);
+                    if (ok[it])
+                        __builtin_nontemporal_store(v[it], reinterpret_cast<u32x4*>(a.gpre + (long)(mrow + 8 * (4 * mi + it)) * a.gpre_cs + n));
+                }
+                continue;
+            }
 #pragma unroll
             for (int it = 0; it < 4; ++it)
                 if (ok[it]) __builtin_nontemporal_store(v[it], reinterpret_cast<u32x4*>(op + (4 * mi + it) * ostep));
@@ -441,13 +463,15 @@ __global__ __launch_bounds__(512) void k_conv_pp128(const ConvArgs a) {
     };
     const std::false_type no{};
     const std::true_type yes{};
-    if (a.pre) {
-        if (a.act == ADAYOLO_ACT_SILU) { if (a.res) epilogue(yes, yes, yes); else epilogue(yes, no, yes); }
-        else { if (a.res) epilogue(no, yes, yes); else epilogue(no, no, yes); }
+    if (a.gpre) {
+        if (a.res) epilogue(no, yes, no, yes); else epilogue(no, no, no, yes);
+    } else if (a.pre) {
+        if (a.act == ADAYOLO_ACT_SILU) { if (a.res) epilogue(yes, yes, yes, no); else epilogue(yes, no, yes, no); }
+        else { if (a.res) epilogue(no, yes, yes, no); else epilogue(no, no, yes, no); }
     } else if (a.act == ADAYOLO_ACT_SILU) {
-        if (a.res) epilogue(yes, yes, no); else epilogue(yes, no, no);
+        if (a.res) epilogue(yes, yes, no, no); else epilogue(yes, no, no, no);
     } else {
-        if (a.res) epilogue(no, yes, no); else epilogue(no, no, no);
+        if (a.res) epilogue(no, yes, no, no); else epilogue(no, no, no, no);
     }
 }
 

@@ -27,6 +27,10 @@ struct ConvArgs {
     // split-K (yolo_conv_pp128.hip, variants 100 + S): S workgroups per output tile, fp32 partial tiles + one ticket per tile
     // in the caller's workspace; 1 = every other kernel
     float* partial = nullptr; int* tickets = nullptr; int ksplit = 1;
+    // backward of the frozen detector (variants of the keep set): when gpre is set, `pre` is an INPUT (the layer's saved
+    // pre-activation), the conv result (+ residual) is the gradient of that layer's output — stored to `out` only when `out`
+    // is not null — and gpre = bf16(that bf16 value * silu'(pre)): adayolo_silu_bwd inside the producing launch
+    unsigned short* gpre = nullptr; int gpre_cs = 0;
 };
 
 // Epilogue math on channel pairs: packed fp32 (v_pk_add/mul_f32 do two channels per issue slot; the two transcendentals
@@ -37,6 +41,19 @@ __device__ __forceinline__ f32x2_pk silu_pk(f32x2_pk x);
 __device__ __forceinline__ unsigned silu_bf16x2(unsigned v) {
     typedef __bf16 bf16x2_pk __attribute__((ext_vector_type(2)));
     const f32x2_pk y = silu_pk(f32x2_pk{__uint_as_float(v << 16), __uint_as_float(v & 0xFFFF0000u)});
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(y, bf16x2_pk));
+}
+// g * silu'(p) on a bf16 pair, rounded back to bf16 — THE formula of the backward (k_silu_bwd and the conv epilogues that
+// absorb it must agree bit for bit, hence the explicit fma: nothing is left to contraction).
+// silu'(p) = s + p s (1 - s), s = sigmoid(p)
+__device__ __forceinline__ float dsilu_f32(float g, float p) {
+    const float s = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504088896341f * p));
+    return g * __builtin_fmaf(p * s, 1.0f - s, s);
+}
+__device__ __forceinline__ unsigned dsilu_bf16x2(unsigned g, unsigned p) {
+    typedef __bf16 bf16x2_pk __attribute__((ext_vector_type(2)));
+    const f32x2_pk y = {dsilu_f32(__uint_as_float(g << 16), __uint_as_float(p << 16)),
+                        dsilu_f32(__uint_as_float(g & 0xFFFF0000u), __uint_as_float(p & 0xFFFF0000u))};
     return __builtin_bit_cast(unsigned, __builtin_convertvector(y, bf16x2_pk));
 }
 __device__ __forceinline__ f32x2_pk silu_pk(f32x2_pk x) {

@@ -68,11 +68,7 @@ __global__ __launch_bounds__(256) void k_silu_bwd(const unsigned short* __restri
             const u32x4 p = *reinterpret_cast<const u32x4*>(pre + pix * pre_cs + ch);
             u32x4 o;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float a = lo_f(p[j]), b = hi_f(p[j]);
-                const float sa = sigmoidf_(a), sb = sigmoidf_(b);
-                o[j] = pk(lo_f(g[j]) * (sa + a * sa * (1.0f - sa)), hi_f(g[j]) * (sb + b * sb * (1.0f - sb)));
-            }
+            for (int j = 0; j < 4; ++j) o[j] = dsilu_bf16x2(g[j], p[j]);
             *reinterpret_cast<u32x4*>(gp + pix * gp_cs + ch) = o;
         }
         if (gres) {

@@ -84,7 +84,7 @@ class YoloTrainEngine(YoloEngine):
                 wt = wt.to(torch.bfloat16).contiguous()
                 dP, gimg = self._dense(dst.H, dst.W, 32), self._dense(dst.H, dst.W, 8)
                 self._keep.append(wt)
-                self._gimg = gimg
+                self._gimg, self._stem_dst, self._stem_dP = gimg, dst, dP
                 bwd.append([("dsilu", L.adayolo_silu_bwd, lambda dst=dst, P=P, dP=dP: (
                                 ctypes.c_void_p(G(dst).ptr), dst.cs, ctypes.c_void_p(P.ptr), P.cs, ctypes.c_void_p(dP.ptr),
                                 dP.cs, None, 0, 0, B * dst.H * dst.W, 32)),
@@ -114,7 +114,9 @@ class YoloTrainEngine(YoloEngine):
                 U = self._dense(src.H, src.W, cout) if s == 2 else None
                 bwd.append([("convbwd", None, dict(src=src, dst=dst, res=res, k=k, s=s, cout=cout, wt=wt, P=P, dP=dP, U=U))])
 
-        # resolve the backward launches in reverse order (accumulate-or-overwrite is decided here, once)
+        # resolve the backward launches in reverse order (accumulate-or-overwrite is decided here, once); `meta` says
+        # which views each launch reads and writes (what _backward_plan needs to move a SiLU' into its producer)
+        meta = self._tbwd_meta = []
         for group in reversed(bwd):
             for kind, fn, a in group:
                 if kind == "convbwd":
@@ -126,6 +128,8 @@ class YoloTrainEngine(YoloEngine):
                             ctypes.c_void_p(gdst.ptr), gdst.cs, ctypes.c_void_p(P.ptr), P.cs, ctypes.c_void_p(dP.ptr), dP.cs,
                             ctypes.c_void_p(gres.ptr) if gres is not None else None, gres.cs if gres is not None else 0, acc,
                             self.B * dst.H * dst.W, cout)))
+                        meta.append(dict(reads=[gdst] + ([gres] if acc else []), writes=[dP] + ([gres] if gres is not None else []),
+                                         gy=gdst, P=P, dP=dP, gres=gres, acc=acc))
                         if gres is not None:
                             mark(gres)
                         g_in = dP
@@ -134,6 +138,7 @@ class YoloTrainEngine(YoloEngine):
                     if s == 2:
                         self.tbwd.append(("zins", self.L.adayolo_zero_insert2x, (
                             ctypes.c_void_p(g_in.ptr), g_in.cs, ctypes.c_void_p(U.ptr), U.cs, self.B, dst.H, dst.W, src.H, src.W, cout)))
+                        meta.append(dict(reads=[g_in], writes=[U]))
                         g_in = U
                     gsrc = G(src)
                     acc_view = gsrc if is_written(gsrc) else None
@@ -141,17 +146,26 @@ class YoloTrainEngine(YoloEngine):
                     gin_view = _View(g_in.buf, g_in.coff, cout)
                     gin_view.H, gin_view.W = (src.H, src.W) if s == 2 else (dst.H, dst.W)
                     self.tbwd.append(self._conv_entry(gin_view, wt, zb(src.C), gsrc, k, 1, _lib.ACT_NONE, acc_view, src.C))
+                    meta.append(dict(reads=[gin_view] + ([acc_view] if acc_view is not None else []), writes=[gsrc], out=gsrc,
+                                     res=acc_view))
                     mark(gsrc)
                 elif kind == "upbwd":
                     _, src, dst = a
                     gsrc, gdst = G(src), G(dst)
                     self.tbwd.append(("upbwd", fn, (ctypes.c_void_p(gdst.ptr), gdst.cs, ctypes.c_void_p(gsrc.ptr), gsrc.cs,
                                                     int(is_written(gsrc)), self.B, src.H, src.W, src.C)))
+                    meta.append(dict(reads=[gdst] + ([gsrc] if is_written(gsrc) else []), writes=[gsrc]))
                     mark(gsrc)
-                elif kind == "dsilu":
+                elif kind == "dsilu":                                                   # the stem's
                     self.tbwd.append((kind, fn, a()))
+                    meta.append(dict(reads=[G(self._stem_dst)], writes=[self._stem_dP], gy=G(self._stem_dst), P=self._stem_pre,
+                                     dP=self._stem_dP, gres=None, acc=0))
+                elif kind == "conv":                                                    # the stem's data gradient
+                    self.tbwd.append((kind, fn, a))
+                    meta.append(dict(reads=[self._stem_dP], writes=[self._gimg], out=self._gimg, res=None))
                 else:
                     self.tbwd.append((kind, fn, a))
+                    meta.append(dict(reads=[self._gimg], writes=[]))
         self._graw = [G(v) for v in self.raw]
 
     def _plans(self):
@@ -159,18 +173,28 @@ class YoloTrainEngine(YoloEngine):
 
     def _tune_penalty(self, key, variant):
         """A forward conv followed by SiLU runs as ONE launch only on the kernels that can store the pre-activation
-        (KEEP_VARIANTS); any other choice adds the adayolo_silu_fwd launch: pre-activation read, activation written
-        (+ residual read) at ~4 TB/s, + ~3 us of launch — an estimate, the choice only has to be right where it matters."""
+        (KEEP_VARIANTS); any other choice adds the adayolo_silu_fwd launch of that layer, whose duration is measured here
+        (best of 5, once per layer shape) and added to the candidate's time."""
         if variant in self.KEEP_VARIANTS:
             return 0.0
         cost = getattr(self, "_silu_cost", None)
         if cost is None:
             cost = self._silu_cost = {}
+            st = _lib.stream_ptr()
             for i, e in enumerate(self.tfwd[:-1]):
                 nxt = self.tfwd[i + 1]
-                if e[0] == "conv" and nxt[0] == "silu" and e[2][6].value == nxt[2][0].value:
-                    npix, C, has_res = nxt[2][6], nxt[2][7], nxt[2][2] is not None
-                    cost[tuple(e[2][8:16])] = 2.0 * npix * C * (3 if has_res else 2) / 4e9 + 0.003
+                k = tuple(e[2][8:16]) if e[0] == "conv" else None
+                if k is not None and k not in cost and nxt[0] == "silu" and e[2][6].value == nxt[2][0].value:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    nxt[1](*nxt[2], st)
+                    t = float("inf")
+                    for _ in range(5):
+                        e0.record()
+                        nxt[1](*nxt[2], st)
+                        e1.record()
+                        e1.synchronize()
+                        t = min(t, e0.elapsed_time(e1))
+                    cost[k] = t
         return cost.get(key, 0.0)
 
     # ------------------------------------------------------------------------------------------
@@ -233,6 +257,89 @@ class YoloTrainEngine(YoloEngine):
         self.keep_fused = sum(1 for e in plan if e[0] == "convkeep")
         return plan
 
+    def _conv_dsilu_launch(self, *a):
+        """adayolo_conv_dsilu_fwd's argument list up to `variant` (20) + stream; the workspace is the engine's."""
+        if a[19] >= self.SPLITK_BASE:
+            _, ptr, nbytes = self._splitk_workspace()
+            return self.L.adayolo_conv_dsilu_fwd(*a[:20], ptr, nbytes, a[20])
+        return self.L.adayolo_conv_dsilu_fwd(*a[:20], None, 0, a[20])
+
+    def _backward_plan(self):
+        """tbwd with every SiLU' launch moved into the data-gradient conv that COMPLETES the gradient it reads
+        (adayolo_conv_dsilu_fwd, bit-identical to the pair), where that conv writes exactly the view, runs on a kernel with
+        that epilogue (KEEP_VARIANTS) and nothing else reads the gradient:
+          * no shortcut: the conv writes only dL/d(pre) — the layer-output gradient is never stored;
+          * Bottleneck.cv2 (its SiLU' also copied the output gradient into the block input's): the conv stores the output
+            gradient as well, and the conv that accumulated into the copy (cv1's data gradient) takes it from there as
+            its residual — the copy is gone. Only when the copy was the first write of that view and that conv the next.
+        Rebuilt when autotune changed a variant; ADAYOLO_TRAIN_FUSE_DSILU=0 keeps every launch."""
+        import os
+        sig = tuple(args[16] for kind, _, args in self.tbwd if kind == "conv")
+        cached = getattr(self, "_tbwd_fused", None)
+        if cached is not None and cached[0] == sig:
+            return cached[1]
+        E, M = self.tbwd, self._tbwd_meta
+        n = len(E)
+        key = lambda v: (id(v.buf), v.coff, v.C)                                        # noqa: E731
+        overlap = lambda a, b: a.buf is b.buf and a.coff < b.coff + b.C and b.coff < a.coff + a.C   # noqa: E731
+        touches = lambda m, v, what: any(overlap(x, v) for x in m[what])               # noqa: E731
+        drop, ds, res_from = set(), {}, {}
+
+        def fused_args(j, m, store):
+            a = list(E[j][2])
+            if j in res_from:
+                a[4], a[5] = ctypes.c_void_p(res_from[j].ptr), res_from[j].cs
+            return a[:6] + [a[6] if store else None, a[7] if store else 0, ctypes.c_void_p(m["P"].ptr), m["P"].cs,
+                            ctypes.c_void_p(m["dP"].ptr), m["dP"].cs] + a[8:15] + [a[16]]
+
+        def served(j, m, store):                          # one real launch: the named kernel must take the shape in this form
+            return self._conv_dsilu_launch(*fused_args(j, m, store), _lib.stream_ptr()) == 0
+
+        if os.environ.get("ADAYOLO_TRAIN_FUSE_DSILU", "1") == "1":
+            for i in range(n):
+                m = M[i]
+                if E[i][0] != "dsilu":
+                    continue
+                gy = m["gy"]
+                j = next((t for t in range(i - 1, -1, -1) if touches(M[t], gy, "writes")), None)
+                if j is None or E[j][0] != "conv" or key(M[j]["out"]) != key(gy) or E[j][2][16] not in self.KEEP_VARIANTS:
+                    continue
+                if any(touches(M[t], gy, "reads") for t in range(j + 1, i)):
+                    continue
+                if m["gres"] is None:
+                    if not any(touches(M[t], gy, "reads") for t in range(i + 1, n)) and served(j, m, False):
+                        ds[j] = (m, False)
+                        drop.add(i)
+                    continue
+                gres = m["gres"]
+                if m["acc"]:
+                    continue
+                k = next((t for t in range(i + 1, n) if touches(M[t], gres, "writes") or touches(M[t], gres, "reads")), None)
+                if (k is None or E[k][0] != "conv" or M[k]["res"] is None or key(M[k]["res"]) != key(gres) or
+                        key(M[k]["out"]) != key(gres)):
+                    continue
+                if any(touches(M[t], gy, "writes") for t in range(i + 1, k + 1)) or not served(j, m, True):
+                    continue
+                ds[j] = (m, True)
+                res_from[k] = gy
+                drop.add(i)
+        plan = []
+        for i in range(n):
+            if i in drop:
+                continue
+            kind, fn, a = E[i]
+            if i in ds:
+                plan.append(("convds", self._conv_dsilu_launch, fused_args(i, *ds[i])))
+            elif i in res_from:
+                a = list(a)
+                a[4], a[5] = ctypes.c_void_p(res_from[i].ptr), res_from[i].cs
+                plan.append((kind, fn, a))
+            else:
+                plan.append((kind, fn, a))
+        self._tbwd_fused = (sig, plan)
+        self.dsilu_fused = len(drop)
+        return plan
+
     # ---- launch sequences as hipGraphs --------------------------------------------------------------------------
     # A training iteration is ~450 detector launches (2 forwards of 75 convs + 72 SiLU kernels, one backward of ~150) next
     # to ~1000 small PyTorch launches, and it is the HOST that is saturated (tools/train_trace.sh: GPU busy 43 % of an
@@ -256,9 +363,9 @@ class YoloTrainEngine(YoloEngine):
                 side.wait_stream(torch.cuda.current_stream())
                 with torch.cuda.stream(side):             # warm-up outside the capture (lazy kernel attributes)
                     self._run(self._forward_plan(), img=st["img"])
-                    self._run(self.tbwd, grad_img=st["grad_img"])
+                    self._run(self._backward_plan(), grad_img=st["grad_img"])
                 torch.cuda.current_stream().wait_stream(side)
-                for key, plan, kw in (("fwd", self._forward_plan(), dict(img=st["img"])), ("bwd", self.tbwd, dict(grad_img=st["grad_img"]))):
+                for key, plan, kw in (("fwd", self._forward_plan(), dict(img=st["img"])), ("bwd", self._backward_plan(), dict(grad_img=st["grad_img"]))):
                     g = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(g):
                         self._run(plan, **kw)
@@ -282,7 +389,7 @@ class YoloTrainEngine(YoloEngine):
         with torch.cuda.device(self.dev):
             if st is None:
                 grad_img = torch.empty((self.B, 3, self.H, self.W), dtype=torch.float32, device=self.dev)
-                self._run(self.tbwd, grad_img=grad_img)
+                self._run(self._backward_plan(), grad_img=grad_img)
                 return grad_img
             st["bwd"].replay()
             return st["grad_img"].clone()

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define ADAYOLO_ABI_VERSION 3
+#define ADAYOLO_ABI_VERSION 4
 
 #define ADAYOLO_ACT_NONE 0
 #define ADAYOLO_ACT_SILU 1
@@ -144,6 +144,20 @@ int adayolo_conv_splitk_fwd(const void* in, int in_cstride, const void* weight, 
                             int res_cstride, void* out, int out_cstride, void* pre, int pre_cstride, int B, int H, int W,
                             int Cin, int Cout, int ksize, int stride, int act, int variant, void* workspace,
                             size_t workspace_bytes, void* stream);
+
+/*
+ * Backward of `Conv` + SiLU through the FROZEN detector, one layer's SiLU' inside the launch that completes its gradient:
+ * g = conv(in, weight) + bias (+ residual) is dL/d(output of the layer whose pre-activation is `pre`), rounded to bf16;
+ * `out` (may be NULL: not needed again) receives g, `grad_pre` receives bf16(g * silu'(pre)) computed from that ROUNDED g —
+ * bit for bit adayolo_conv_fwd_variant(..., ADAYOLO_ACT_NONE) into a buffer followed by adayolo_silu_bwd on it.
+ * `in` / `weight` are what the data-gradient conv takes anyway (dL/d(pre) of the consumer layer, its weights transposed
+ * and flipped). Variants 5 / 22 / 26 / 27 / 60 and the split-K ones (then with their workspace, see above; NULL / 0
+ * otherwise); EINVAL for any other, ESHAPE when the named kernel does not take the shape.
+ */
+int adayolo_conv_dsilu_fwd(const void* in, int in_cstride, const void* weight, const float* bias, const void* residual,
+                           int res_cstride, void* out, int out_cstride, const void* pre, int pre_cstride, void* grad_pre,
+                           int gp_cstride, int B, int H, int W, int Cin, int Cout, int ksize, int stride, int variant,
+                           void* workspace, size_t workspace_bytes, void* stream);
 
 /* adayolo_stem_fwd with the activation selectable (ADAYOLO_ACT_NONE keeps the pre-activation for training). */
 int adayolo_stem_fwd_act(const float* img, const float* weight, const float* bias, void* out, int out_cstride,

@@ -291,7 +291,9 @@ def test_conv_keep_fwd_equals_conv_then_silu(variant):
 def test_graph_replay_and_fused_train_forward_change_nothing():
     """The training engine at the config-4 per-rank shape with the tuning table: (a) launch sequences replayed from
     hipGraphs, (b) conv + SiLU pairs of the forward replaced by adayolo_conv_keep_fwd where the tuned kernel has the
-    second output — against the same engine with both switched off: raw head maps and image gradient bit for bit."""
+    second output, (c) the SiLU' launches of the backward absorbed by the data-gradient conv that completes their input
+    (adayolo_conv_dsilu_fwd; the Bottleneck's gradient copy read in place) — against the same engine with all three
+    switched off: raw head maps and image gradient bit for bit."""
     import os
     from _synth import synth_yolo_state_dict, test_image
     from adaptiveisp_amd.yolo import YoloTrainEngine, yolov3
@@ -307,6 +309,7 @@ def test_graph_replay_and_fused_train_forward_change_nothing():
     results = []
     for graph, keep in (("0", "0"), ("1", "1")):
         os.environ["ADAYOLO_TRAIN_GRAPH"], os.environ["ADAYOLO_TRAIN_KEEP"] = graph, keep
+        os.environ["ADAYOLO_TRAIN_FUSE_DSILU"] = keep                   # (c) SiLU' inside the conv that completes its gradient
         try:
             eng = YoloTrainEngine(det, B, H, W, device=DEV)
             eng.autotune(cache=cache, write=False)
@@ -323,11 +326,74 @@ def test_graph_replay_and_fused_train_forward_change_nothing():
             if keep == "1":
                 assert eng.keep_fused >= 20, eng.keep_fused              # most Conv layers of the forward are single launches
                 assert eng._graphs["fwd"] is not None and eng._graphs["bwd"] is not None
+                # the SiLU' launches whose producing conv runs on a kernel with that epilogue are gone (the rest stay)
+                assert eng.dsilu_fused >= 20, eng.dsilu_fused
+                assert sum(1 for e in eng._backward_plan() if e[0] == "dsilu") == 72 - eng.dsilu_fused
+            else:
+                assert eng.dsilu_fused == 0 and sum(1 for e in eng._backward_plan() if e[0] == "dsilu") == 72
             results.append(outs[1])
         finally:
             os.environ.pop("ADAYOLO_TRAIN_GRAPH", None)
             os.environ.pop("ADAYOLO_TRAIN_KEEP", None)
+            os.environ.pop("ADAYOLO_TRAIN_FUSE_DSILU", None)
     (raw_a, grad_a), (raw_b, grad_b) = results
     for a, b in zip(raw_a, raw_b):
         assert torch.equal(a, b)
     assert torch.equal(grad_a, grad_b)
+
+
+@pytest.mark.parametrize("variant", [5, 22, 26, 27, 60, 104])
+def test_conv_dsilu_fwd_equals_conv_then_silu_bwd(variant):
+    """adayolo_conv_dsilu_fwd (one launch: g = conv + residual rounded to bf16, optionally stored; grad_pre = g * silu'(pre))
+    == adayolo_conv_fwd_variant(ACT_NONE) + adayolo_silu_bwd, bit for bit, with and without the stored gradient, on
+    channel slices, on every shape the kernel serves (the split-K variant with its workspace)."""
+    from adaptiveisp_amd.yolo import _lib
+    L = _lib.load()
+    st = _lib.stream_ptr()
+    served = 0
+    for (B, H, W, cin, cout, k, use_res) in [(8, 16, 16, 1024, 512, 3, True), (8, 32, 32, 512, 256, 3, False), (3, 33, 17, 256, 128, 1, True),
+                                             (1, 9, 7, 128, 128, 3, False), (2, 40, 24, 128, 64, 1, True), (2, 24, 40, 64, 32, 3, False)]:
+        ws, nws = None, 0
+        if variant >= 100:
+            nws = int(L.adayolo_conv_splitk_workspace_bytes(B, H, W, cin, cout, k, 1, variant))
+            if nws == 0:
+                continue
+            ws = torch.zeros(nws, dtype=torch.uint8, device=DEV)
+        g = torch.Generator().manual_seed(H * 7 + cin + variant)
+        x = torch.randn(B, H, W, cin, generator=g).to(torch.bfloat16).to(DEV)
+        w = (torch.randn(cout, k, k, cin, generator=g) / (k * k * cin) ** 0.5).to(torch.bfloat16).to(DEV)
+        zb = torch.zeros(cout, device=DEV)
+        pre = (torch.randn(B, H, W, cout + 8, generator=g) * 2).to(torch.bfloat16).to(DEV)[..., 8:]      # a channel slice
+        res = torch.randn(B, H, W, cout, generator=g).to(torch.bfloat16).to(DEV) if use_res else None
+        nan = lambda c=cout: torch.full((B, H, W, c), float("nan"), dtype=torch.bfloat16, device=DEV)  # noqa: E731
+        gy_ref, gp_ref = nan(), nan()
+        if variant >= 100:
+            rc = L.adayolo_conv_splitk_fwd(_p(x), cin, _p(w), _p(zb), _p(res) if use_res else None, cout if use_res else 0, _p(gy_ref), cout,
+                                           None, 0, B, H, W, cin, cout, k, 1, 0, variant, _p(ws), nws, st)
+        else:
+            rc = L.adayolo_conv_fwd_variant(_p(x), cin, _p(w), _p(zb), _p(res) if use_res else None, cout if use_res else 0, _p(gy_ref), cout,
+                                            B, H, W, cin, cout, k, 1, 0, variant, st)
+        assert rc == 0
+        assert L.adayolo_silu_bwd(_p(gy_ref), cout, _p(pre), cout + 8, _p(gp_ref), cout, None, 0, 0, B * H * W, cout, st) == 0
+        for store in (True, False):
+            gy, wide = nan(), nan(cout + 16)
+            gp = wide[..., 8:8 + cout]
+            rc = L.adayolo_conv_dsilu_fwd(_p(x), cin, _p(w), _p(zb), _p(res) if use_res else None, cout if use_res else 0,
+                                          _p(gy) if store else None, cout if store else 0, _p(pre), cout + 8, _p(gp), cout + 16,
+                                          B, H, W, cin, cout, k, 1, variant, _p(ws) if ws is not None else None, nws, st)
+            if rc == -2:
+                break
+            assert rc == 0, (rc, variant)
+            torch.cuda.synchronize()
+            assert torch.equal(gp.contiguous().view(torch.int16), gp_ref.view(torch.int16)), (variant, B, H, W, cin, cout, store)
+            if store:
+                assert torch.equal(gy.view(torch.int16), gy_ref.view(torch.int16))
+            assert torch.isnan(wide[..., :8].float()).all() and torch.isnan(wide[..., 8 + cout:].float()).all()   # neighbours untouched
+        else:
+            served += 1
+    assert served >= 2, (variant, served)
+    # a kernel without this epilogue / missing pointers
+    assert L.adayolo_conv_dsilu_fwd(_p(x), cin, _p(w), _p(zb), None, 0, None, 0, _p(pre), cout + 8, _p(gp), cout + 16, B, H, W, cin, cout,
+                                    k, 1, 50, None, 0, st) == -1
+    assert L.adayolo_conv_dsilu_fwd(_p(x), cin, _p(w), _p(zb), None, 0, None, 0, None, 0, _p(gp), cout + 16, B, H, W, cin, cout,
+                                    k, 1, 5, None, 0, st) == -1

@@ -29,6 +29,9 @@ for p in det.parameters():
 for name in ([os.environ["TRAIN_BENCH_ONLY"]] if os.environ.get("TRAIN_BENCH_ONLY") else ["hip", "torch"]):
     agent = Agent(cfg, shape=(16, 64, 64), device=DEV).to(DEV)
     value = Value(cfg, shape=(19, 64, 64)).to(DEV)
+    if os.environ.get("TRAIN_BENCH_CHANNELS_LAST") == "1":           # experiment: NHWC weights for the policy / critic trunks
+        agent = agent.to(memory_format=torch.channels_last)
+        value = value.to(memory_format=torch.channels_last)
     loss_fn = DetectionLoss(det.model[-1].anchors, nc=80, hyp=default_hyp(80, HW), device=DEV)
     replay = DeviceReplayMemory(cfg, SyntheticSource((3, HW, HW), seed=1, device=DEV), B, DEV, (3, HW, HW), rng=random.Random(1))
     detector = YoloTrainEngine(det, B, HW, HW, device=DEV) if name == "hip" else det

@@ -52,7 +52,7 @@ print("variants in use: inference", sorted(set(inf.tuned.values())), "training",
 tr._forward_raw(x)
 st = tr._graph("fwd")
 print(f"training forward (graph replay)              {timeit(st['fwd'].replay):.3f} ms   ({tr.keep_fused} conv+SiLU pairs in one launch)")
-print(f"training backward (graph replay)             {timeit(st['bwd'].replay):.3f} ms")
+print(f"training backward (graph replay)             {timeit(st['bwd'].replay):.3f} ms   ({tr.dsilu_fused} of 72 SiLU' launches inside their producing conv)")
 
 
 def per_launch(plan, **kw):
@@ -78,13 +78,14 @@ def per_launch(plan, **kw):
 
 def describe(e):
     kind, fn, a = e
-    if kind in ("conv", "convkeep"):
-        off = 2 if kind == "convkeep" else 0
+    if kind in ("conv", "convkeep", "convds"):
+        off = {"conv": 0, "convkeep": 2, "convds": 4}[kind]
         Bc, H, W, cin, cout, k, s = a[8 + off:15 + off]
-        v = a[16 + off]
+        v = a[19] if kind == "convds" else a[16 + off]
         Ho, Wo = (H - 1) // s + 1, (W - 1) // s + 1
         fl = 2.0 * Bc * Ho * Wo * cout * k * k * cin
-        by = 2.0 * Bc * (H * W * cin + Ho * Wo * cout * (2 if kind == "convkeep" else 1) + (Ho * Wo * cout if a[4] else 0))
+        nout = {"conv": 1, "convkeep": 2, "convds": 3 if a[6] else 2}[kind]          # outputs (+ the pre-activation read)
+        by = 2.0 * Bc * (H * W * cin + Ho * Wo * cout * nout + (Ho * Wo * cout if a[4] else 0))
         return f"{kind:8s} v{v:<3d} {cin:4d}->{cout:4d} k{k} s{s} @{H}x{W}", fl, by
     if kind in ("dsilu", "silu"):
         npix, C = a[-2], a[-1]
@@ -94,7 +95,7 @@ def describe(e):
 
 
 for name, plan, kw in (("training forward", tr._forward_plan(), dict(img=x)),
-                       ("training backward", tr.tbwd, dict(grad_img=torch.empty_like(x)))):
+                       ("training backward", tr._backward_plan(), dict(grad_img=torch.empty_like(x)))):
     ms = per_launch(plan, **kw)
     print(f"\n{name}: {len(plan)} launches, {sum(ms):.3f} ms summed (launch by launch, not overlapped)")
     kinds = {}
