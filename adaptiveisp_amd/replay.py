@@ -125,16 +125,25 @@ class DeviceReplayMemory:
 
 
 class SyntheticSource:
-    """Stand-in for the dataset object (no dataset in the container): seeded images U^2.2*0.5 with a few boxes."""
+    """Stand-in for the dataset object (no dataset in the container): seeded images U^2.2*0.5 with a few boxes. With a
+    GPU device the pixels are drawn ON the device (its own seeded generator): a real loader prepares batches in worker
+    processes beside the training loop (dataset.py:921-931 behind a DataLoader), which a stand-in that draws 6 MB of
+    randoms per image on the training thread is not — 13 ms of host time per refill at 8 x 512 x 512."""
 
     def __init__(self, image_shape, nc=80, seed=0, device="cpu", max_boxes=3):
         self.shape, self.nc, self.count = tuple(image_shape), nc, 0
         self.g = torch.Generator(device="cpu").manual_seed(seed)
         self.device, self.max_boxes = device, max_boxes
+        self.gd = None
+        if torch.device(device).type == "cuda":
+            self.gd = torch.Generator(device=device).manual_seed(seed)
 
     def get_next_batch(self, n):
         C, H, W = self.shape
-        ims = (torch.rand(n, C, H, W, generator=self.g) ** 2.2 * 0.5).to(self.device)
+        if self.gd is not None:
+            ims = torch.rand(n, C, H, W, generator=self.gd, device=self.device) ** 2.2 * 0.5
+        else:
+            ims = (torch.rand(n, C, H, W, generator=self.g) ** 2.2 * 0.5).to(self.device)
         labels, paths, shapes = [], [], []
         for i in range(n):
             k = int(torch.randint(1, self.max_boxes + 1, (1,), generator=self.g))

@@ -40,10 +40,33 @@ for name in ([os.environ["TRAIN_BENCH_ONLY"]] if os.environ.get("TRAIN_BENCH_ONL
     tr = Trainer(cfg, agent, value, detector, loss_fn, replay, batch_size=B)
     tr.train(2)
     torch.cuda.synchronize()
+    waited = [0.0]
+    _ev_sync, _cpu = torch.cuda.Event.synchronize, torch.Tensor.cpu
+
+    def _timed(fn):
+        def call(*a, **k):
+            t = time.perf_counter()
+            r = fn(*a, **k)
+            waited[0] += time.perf_counter() - t
+            return r
+        return call
+    torch.cuda.Event.synchronize, torch.Tensor.cpu = _timed(_ev_sync), _timed(_cpu)   # the host's waits for the GPU
+    prof = None
+    if os.environ.get("TRAIN_BENCH_PROFILE"):                     # host profile of the steady state only (tools/train_host_profile.sh)
+        import cProfile
+        prof = cProfile.Profile()
+        prof.enable()
     t0 = time.perf_counter()
     tr.train(iters)
+    t_host = time.perf_counter() - t0
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / iters
+    if prof is not None:
+        prof.disable()
+        prof.dump_stats(os.environ["TRAIN_BENCH_PROFILE"])
+    torch.cuda.Event.synchronize, torch.Tensor.cpu = _ev_sync, _cpu
+    print(f"      host: {t_host / iters * 1e3:.1f} ms / iteration, of which {waited[0] / iters * 1e3:.1f} ms waiting for the GPU (guard event, "
+          f".cpu() copies) -> {(t_host - waited[0]) / iters * 1e3:.1f} ms of enqueue work")
     # detector forward+backward alone
     x = torch.rand(B, 3, HW, HW, device=DEV, requires_grad=True)
     for _ in range(2):
