@@ -147,13 +147,15 @@ int adayolo_conv_keep_fwd(const void* in, int in_cstride, const void* weight, co
 }
 
 size_t adayolo_conv_splitk_workspace_bytes(int B, int H, int W, int Cin, int Cout, int ksize, int stride, int variant) {
-    if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || (ksize != 1 && ksize != 3) || (stride != 1 && stride != 2))
+    if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || ksize < 1 || ksize > 3 || (stride != 1 && stride != 2))
         return 0;
     if (variant < ADAYOLO_SPLITK_BASE + 2 || variant > ADAYOLO_SPLITK_BASE + 16) return 0;
     ConvArgs a;
     a.Cin = Cin; a.Cout = Cout; a.ks = ksize;
     const int pad = ksize / 2;
-    const long M = (long)B * ((H + 2 * pad - ksize) / stride + 1) * ((W + 2 * pad - ksize) / stride + 1);
+    // ksize 2 = the stride-2 data gradient's form (adayolo_conv_s2grad_fwd: H x W is its Ho x Wo grid, Cout = 4 x channels)
+    const long M = ksize == 2 ? (long)B * H * W
+                              : (long)B * ((H + 2 * pad - ksize) / stride + 1) * ((W + 2 * pad - ksize) / stride + 1);
     if (M > 0x7fffffffL) return 0;
     a.M = (int)M;
     return conv_pp128_splitk_bytes(a, variant - ADAYOLO_SPLITK_BASE);
@@ -207,6 +209,50 @@ int adayolo_conv_dsilu_fwd(const void* in, int in_cstride, const void* weight, c
         return ADAYOLO_EINVAL;                               // the kernels whose epilogue has this form
     }
     if (e == hipErrorInvalidValue) return ADAYOLO_ESHAPE;    // the named kernel does not serve the shape
+    return e == hipSuccess ? ADAYOLO_OK : ADAYOLO_ELAUNCH;
+}
+
+int adayolo_conv_s2grad_fwd(const void* grad_out, int go_cstride, const void* weight4, const float* bias4, const void* residual,
+                            int res_cstride, void* grad_in, int gi_cstride, const void* pre, int pre_cstride, void* grad_pre,
+                            int gp_cstride, int B, int Ho, int Wo, int Cout, int Cin, int variant, void* workspace,
+                            size_t workspace_bytes, void* stream) {
+    if (!grad_out || !weight4 || !bias4 || (!grad_in && !grad_pre) || (!pre != !grad_pre)) return ADAYOLO_EINVAL;
+    if (B <= 0 || Ho <= 0 || Wo <= 0 || Cin <= 0 || Cout <= 0) return ADAYOLO_EINVAL;
+    if (Cin % 8 || Cout % 8 || go_cstride % 8 || go_cstride < Cout) return ADAYOLO_ESHAPE;
+    if (grad_in && (gi_cstride % 8 || gi_cstride < Cin)) return ADAYOLO_ESHAPE;
+    if (residual && (res_cstride % 8 || res_cstride < Cin)) return ADAYOLO_ESHAPE;
+    if (pre && (pre_cstride % 8 || pre_cstride < Cin || gp_cstride % 8 || gp_cstride < Cin)) return ADAYOLO_ESHAPE;
+    const long M = (long)B * Ho * Wo;
+    if (4 * M > 0x7fffffffL || 4 * M * (gi_cstride > gp_cstride ? gi_cstride : gp_cstride) > 0x7fffffffffL) return ADAYOLO_ESHAPE;
+    ConvArgs a;                                               // a 2x2 stride-1 conv over the Ho x Wo grid, zero beyond its far edges
+    a.in = static_cast<const unsigned short*>(grad_out); a.in_cs = go_cstride;
+    a.w = static_cast<const unsigned short*>(weight4); a.bias = bias4;
+    a.res = static_cast<const unsigned short*>(residual); a.res_cs = residual ? res_cstride : 0;
+    a.out = static_cast<unsigned short*>(grad_in); a.out_cs = grad_in ? gi_cstride : 0;
+    a.B = B; a.H = Ho; a.W = Wo; a.Cin = Cout; a.Cout = 4 * Cin;
+    a.ks = 2; a.stride = 1; a.pad = 0; a.act = ADAYOLO_ACT_NONE;
+    a.Ho = Ho; a.Wo = Wo; a.M = (int)M; a.mtiles = a.ntiles = 0;
+    a.w2 = nullptr; a.bias2 = nullptr; a.out2 = nullptr; a.out2_cs = 0;
+    a.pre = static_cast<unsigned short*>(const_cast<void*>(pre)); a.pre_cs = pre ? pre_cstride : 0;
+    a.gpre = static_cast<unsigned short*>(grad_pre); a.gpre_cs = grad_pre ? gp_cstride : 0;
+    a.d2s_c = Cin;
+    magic_div((unsigned)(Ho * Wo), &a.magic_hw, &a.sh_hw);
+    magic_div((unsigned)Wo, &a.magic_w, &a.sh_w);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    hipError_t e;
+    if (variant >= ADAYOLO_SPLITK_BASE + 2 && variant <= ADAYOLO_SPLITK_BASE + 16) {
+        const size_t need = conv_pp128_splitk_bytes(a, variant - ADAYOLO_SPLITK_BASE);
+        if (need == 0) return ADAYOLO_ESHAPE;
+        if (!workspace || workspace_bytes < need) return ADAYOLO_EINVAL;
+        e = launch_conv_pp128_splitk(a, s, variant - ADAYOLO_SPLITK_BASE, workspace, workspace_bytes);
+    } else if (variant == 5 || variant == 22 || variant == 26 || variant == 27) {
+        e = launch_conv_dma2(a, s, variant);
+    } else if (variant == 60) {
+        e = launch_conv_pp128(a, s, variant);
+    } else {
+        return ADAYOLO_EINVAL;
+    }
+    if (e == hipErrorInvalidValue) return ADAYOLO_ESHAPE;
     return e == hipSuccess ? ADAYOLO_OK : ADAYOLO_ELAUNCH;
 }
 

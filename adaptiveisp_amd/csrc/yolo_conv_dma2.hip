@@ -268,15 +268,18 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void k_conv_igemm_dma32(const C
         const int m = m0 + ml, n = n0 + ch;
         if (m >= a.M || n >= a.Cout) continue;
         u32x4 v = *reinterpret_cast<const u32x4*>(Cs + ml * CP + ch);
+        long pix;
+        int nn;
+        epilogue_pos(a, m, n, pix, nn);                       // (m, n) itself, or its depth-to-space image (stride-2 data gradient)
         if (a.pre && !a.gpre) {                               // training forward: keep the pre-activation, activate its bf16 value
-            *reinterpret_cast<u32x4*>(a.pre + (long)m * a.pre_cs + n) = v;
+            *reinterpret_cast<u32x4*>(a.pre + pix * a.pre_cs + nn) = v;
             if (a.act == ADAYOLO_ACT_SILU) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) v[j] = silu_bf16x2(v[j]);
             }
         }
         if (a.res) {
-            const u32x4 r = *reinterpret_cast<const u32x4*>(a.res + (long)m * a.res_cs + n);
+            const u32x4 r = *reinterpret_cast<const u32x4*>(a.res + pix * a.res_cs + nn);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const float lo = bf16_to_f32((unsigned short)(v[j] & 0xFFFFu)) + bf16_to_f32((unsigned short)(r[j] & 0xFFFFu));
@@ -286,14 +289,14 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void k_conv_igemm_dma32(const C
         }
         if (ABL == 7 && v[0] != 0x12345678u) continue;        // ablation: everything but the global stores
         if (a.gpre) {                                         // backward: v is dL/d(layer output); gpre = v * silu'(pre)
-            if (a.out) ADAYOLO_STORE(v, reinterpret_cast<u32x4*>(a.out + (long)m * a.out_cs + n));
-            const u32x4 p = *reinterpret_cast<const u32x4*>(a.pre + (long)m * a.pre_cs + n);
+            if (a.out) ADAYOLO_STORE(v, reinterpret_cast<u32x4*>(a.out + pix * a.out_cs + nn));
+            const u32x4 p = *reinterpret_cast<const u32x4*>(a.pre + pix * a.pre_cs + nn);
 #pragma unroll
             for (int j = 0; j < 4; ++j) v[j] = dsilu_bf16x2(v[j], p[j]);
-            ADAYOLO_STORE(v, reinterpret_cast<u32x4*>(a.gpre + (long)m * a.gpre_cs + n));
+            ADAYOLO_STORE(v, reinterpret_cast<u32x4*>(a.gpre + pix * a.gpre_cs + nn));
             continue;
         }
-        ADAYOLO_STORE(v, reinterpret_cast<u32x4*>(a.out + (long)m * a.out_cs + n));
+        ADAYOLO_STORE(v, reinterpret_cast<u32x4*>(a.out + pix * a.out_cs + nn));
     }
 }
 

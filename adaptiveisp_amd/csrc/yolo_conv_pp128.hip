@@ -371,11 +371,13 @@ __global__ __launch_bounds__(512) void k_conv_pp128(const ConvArgs a) {
     // ---- epilogue: wave-private LDS transpose (see yolo_conv_pp.hip), 32 px x 64 ch at a time, 128-byte row segments
     unsigned char* my = smem + wave * (64 * kEpiPitch);
     // see yolo_conv_pp.hip: compile-time activation / residual copies, bias and pointers hoisted, batched reads and stores
-    auto epilogue = [&](auto silu_tag, auto res_tag, auto keep_tag, auto ds_tag) {
+    auto epilogue = [&](auto silu_tag, auto res_tag, auto keep_tag, auto ds_tag, auto d2s_tag) {
         // kKeep: the tile goes through LDS as the bf16 PRE-activation (kSilu off), is stored to a.pre, then activated
         // kDs (backward): the result (+ residual) is dL/d(layer output), stored when a.out is set; a.gpre = it * silu'(a.pre)
+        // kD2s (stride-2 data gradient): every tensor the epilogue touches is addressed depth-to-space (epilogue_pos)
         constexpr bool kKeep = decltype(keep_tag)::value, kAct = decltype(silu_tag)::value, kDs = decltype(ds_tag)::value;
-        constexpr bool kSilu = kAct && !kKeep, kRes = decltype(res_tag)::value;
+        constexpr bool kSilu = kAct && !kKeep, kRes = decltype(res_tag)::value, kD2s = decltype(d2s_tag)::value;
+        static_assert(!(kD2s && (kKeep || kAct)), "depth-to-space addressing serves the backward forms only");
         typedef __attribute__((ext_vector_type(2))) float f32x2v;
         float4 bq[2][4];
 #pragma unroll
@@ -396,11 +398,17 @@ __global__ __launch_bounds__(512) void k_conv_pp128(const ConvArgs a) {
             bool ok[4];
 #pragma unroll
             for (int it = 0; it < 4; ++it) ok[it] = mrow + 8 * (4 * mi + it) < a.M;
+            long px[4];                                          // kD2s: the pixel each row lands on, nn its channel there
+            int nn = n;
+            if (kD2s) {
+#pragma unroll
+                for (int it = 0; it < 4; ++it) epilogue_pos(a, ok[it] ? mrow + 8 * (4 * mi + it) : 0, n, px[it], nn);
+            }
             if (kRes) {                                          // in flight while this group's SiLUs are computed
 #pragma unroll
                 for (int it = 0; it < 4; ++it) {
                     r[it] = u32x4{0u, 0u, 0u, 0u};
-                    if (ok[it]) r[it] = *reinterpret_cast<const u32x4*>(rp + (4 * mi + it) * rstep);
+                    if (ok[it]) r[it] = *reinterpret_cast<const u32x4*>(kD2s ? a.res + px[it] * a.res_cs + nn : rp + (4 * mi + it) * rstep);
                 }
             }
 #pragma unroll
@@ -440,38 +448,48 @@ __global__ __launch_bounds__(512) void k_conv_pp128(const ConvArgs a) {
 #pragma unroll
                 for (int it = 0; it < 4; ++it) {
                     p[it] = u32x4{0u, 0u, 0u, 0u};
-                    if (ok[it]) p[it] = *reinterpret_cast<const u32x4*>(a.pre + (long)(mrow + 8 * (4 * mi + it)) * a.pre_cs + n);
+                    if (ok[it])
+                        p[it] = *reinterpret_cast<const u32x4*>(a.pre + (kD2s ? px[it] * a.pre_cs + nn
+                                                                               : (long)(mrow + 8 * (4 * mi + it)) * a.pre_cs + n));
                 }
                 if (a.out) {
 #pragma unroll
                     for (int it = 0; it < 4; ++it)
-                        if (ok[it]) __builtin_nontemporal_store(v[it], reinterpret_cast<u32x4*>(op + (4 * mi + it) * ostep));
+                        if (ok[it])
+                            __builtin_nontemporal_store(v[it], reinterpret_cast<u32x4*>(kD2s ? a.out + px[it] * a.out_cs + nn
+                                                                                             : op + (4 * mi + it) * ostep));
                 }
 #pragma unroll
                 for (int it = 0; it < 4; ++it) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) v[it][j] = dsilu_bf16x2(v[it][j], p[it][j]);
                     if (ok[it])
-                        __builtin_nontemporal_store(v[it], reinterpret_cast<u32x4*>(a.gpre + (long)(mrow + 8 * (4 * mi + it)) * a.gpre_cs + n));
+                        __builtin_nontemporal_store(v[it], reinterpret_cast<u32x4*>(
+                            a.gpre + (kD2s ? px[it] * a.gpre_cs + nn : (long)(mrow + 8 * (4 * mi + it)) * a.gpre_cs + n)));
                 }
                 continue;
             }
 #pragma unroll
             for (int it = 0; it < 4; ++it)
-                if (ok[it]) __builtin_nontemporal_store(v[it], reinterpret_cast<u32x4*>(op + (4 * mi + it) * ostep));
+                if (ok[it])
+                    __builtin_nontemporal_store(v[it], reinterpret_cast<u32x4*>(kD2s ? a.out + px[it] * a.out_cs + nn
+                                                                                     : op + (4 * mi + it) * ostep));
         }
     };
     const std::false_type no{};
     const std::true_type yes{};
-    if (a.gpre) {
-        if (a.res) epilogue(no, yes, no, yes); else epilogue(no, no, no, yes);
+    if (a.d2s_c) {                                       // stride-2 data gradient (act none, no kept pre-activation)
+        if (a.gpre) { if (a.res) epilogue(no, yes, no, yes, yes); else epilogue(no, no, no, yes, yes); }
+        else { if (a.res) epilogue(no, yes, no, no, yes); else epilogue(no, no, no, no, yes); }
+    } else if (a.gpre) {
+        if (a.res) epilogue(no, yes, no, yes, no); else epilogue(no, no, no, yes, no);
     } else if (a.pre) {
-        if (a.act == ADAYOLO_ACT_SILU) { if (a.res) epilogue(yes, yes, yes, no); else epilogue(yes, no, yes, no); }
-        else { if (a.res) epilogue(no, yes, yes, no); else epilogue(no, no, yes, no); }
+        if (a.act == ADAYOLO_ACT_SILU) { if (a.res) epilogue(yes, yes, yes, no, no); else epilogue(yes, no, yes, no, no); }
+        else { if (a.res) epilogue(no, yes, yes, no, no); else epilogue(no, no, yes, no, no); }
     } else if (a.act == ADAYOLO_ACT_SILU) {
-        if (a.res) epilogue(yes, yes, no, no); else epilogue(yes, no, no, no);
+        if (a.res) epilogue(yes, yes, no, no, no); else epilogue(yes, no, no, no, no);
     } else {
-        if (a.res) epilogue(no, yes, no, no); else epilogue(no, no, no, no);
+        if (a.res) epilogue(no, yes, no, no, no); else epilogue(no, no, no, no, no);
     }
 }
 

@@ -31,7 +31,25 @@ struct ConvArgs {
     // pre-activation), the conv result (+ residual) is the gradient of that layer's output — stored to `out` only when `out`
     // is not null — and gpre = bf16(that bf16 value * silu'(pre)): adayolo_silu_bwd inside the producing launch
     unsigned short* gpre = nullptr; int gpre_cs = 0;
+    // data gradient of a stride-2 conv as a 2x2 stride-1 conv over the (small) output-gradient grid whose 4*C output channels
+    // are the four pixel parities of the (large) input-gradient tensor: d2s_c = C > 0 makes the epilogue address out / res /
+    // pre / gpre depth-to-space — channel group p of pixel (b, i, j) is pixel (b, 2i + p/2, 2j + p%2) of [B, 2Ho, 2Wo, C]
+    int d2s_c = 0;
 };
+
+// (pixel, channel) of an epilogue element in the tensors it addresses: the identity, or the depth-to-space map above
+__device__ __forceinline__ void epilogue_pos(const ConvArgs& a, int m, int n, long& pix, int& nn) {
+    pix = m; nn = n;
+    if (a.d2s_c) {
+        const int b = a.sh_hw < 0 ? m : (int)(__umulhi((unsigned)m, a.magic_hw) >> a.sh_hw);
+        const int rem = m - b * (a.Ho * a.Wo);
+        const int i = a.sh_w < 0 ? rem : (int)(__umulhi((unsigned)rem, a.magic_w) >> a.sh_w);
+        const int j = rem - i * a.Wo;
+        const int p = n / a.d2s_c;
+        nn = n - p * a.d2s_c;
+        pix = ((long)(b * 2 * a.Ho + 2 * i + (p >> 1))) * (2 * a.Wo) + 2 * j + (p & 1);
+    }
+}
 
 // Epilogue math on channel pairs: packed fp32 (v_pk_add/mul_f32 do two channels per issue slot; the two transcendentals
 // stay per element) — the conv epilogues are VALU-bound on exactly this (128 SiLUs per lane in the 256x256 kernel).

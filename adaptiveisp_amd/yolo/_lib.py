@@ -6,9 +6,9 @@ import torch
 
 _HERE = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB_PATH = os.path.join(_HERE, "csrc", "libadayolo.so")
-ABI_VERSION = 4
+ABI_VERSION = 5
 ACT_NONE, ACT_SILU = 0, 1
-EXPORTS = ("adayolo_conv_fwd", "adayolo_conv_fwd_variant", "adayolo_conv_fused1x1_fwd", "adayolo_conv_keep_fwd", "adayolo_conv_splitk_fwd", "adayolo_conv_dsilu_fwd", "adayolo_conv_splitk_workspace_bytes", "adayolo_stem_fwd", "adayolo_upsample2x", "adayolo_detect_decode", "adayolo_nms", "adayolo_nms_workspace_bytes", "adayolo_stem_fwd_act", "adayolo_stem_down_fwd", "adayolo_letterbox_pack", "adayolo_silu_fwd", "adayolo_silu_bwd",
+EXPORTS = ("adayolo_conv_fwd", "adayolo_conv_fwd_variant", "adayolo_conv_fused1x1_fwd", "adayolo_conv_keep_fwd", "adayolo_conv_splitk_fwd", "adayolo_conv_dsilu_fwd", "adayolo_conv_s2grad_fwd", "adayolo_conv_splitk_workspace_bytes", "adayolo_stem_fwd", "adayolo_upsample2x", "adayolo_detect_decode", "adayolo_nms", "adayolo_nms_workspace_bytes", "adayolo_stem_fwd_act", "adayolo_stem_down_fwd", "adayolo_letterbox_pack", "adayolo_silu_fwd", "adayolo_silu_bwd",
            "adayolo_zero_insert2x", "adayolo_upsample2x_bwd", "adayolo_image_grad", "adayolo_detloss_fwd", "adayolo_detloss_bwd",
            "adayolo_strerror",
            "adayolo_abi_version")
@@ -80,6 +80,8 @@ def load():
     L.adayolo_conv_dsilu_fwd.argtypes = [vp, ci, vp, vp, vp, ci, vp, ci, vp, ci, vp, ci, ci, ci, ci, ci, ci, ci, ci, ci, vp,
                                          ctypes.c_size_t, vp]
     L.adayolo_conv_dsilu_fwd.restype = ci
+    L.adayolo_conv_s2grad_fwd.argtypes = [vp, ci, vp, vp, vp, ci, vp, ci, vp, ci, vp, ci, ci, ci, ci, ci, ci, ci, vp, ctypes.c_size_t, vp]
+    L.adayolo_conv_s2grad_fwd.restype = ci
     L.adayolo_nms_workspace_bytes.argtypes = [ci]
     L.adayolo_nms_workspace_bytes.restype = ctypes.c_size_t
     L.adayolo_strerror.argtypes = [ci]

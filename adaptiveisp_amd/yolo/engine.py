@@ -254,8 +254,15 @@ class YoloEngine:
         """ms added to a candidate's measured time (what choosing it costs elsewhere; the training engine's forward)."""
         return 0.0
 
+    S2GRAD_VARIANTS = (5, 22, 26, 27, 60) + SPLITK_CANDIDATES     # kernels that serve adayolo_conv_s2grad_fwd (listed with k = 2)
+
     def _conv_launch(self, *a):
-        """adayolo_conv_fwd_variant's argument list (17 + stream); the split-K variants go to their own entry point."""
+        """adayolo_conv_fwd_variant's argument list (17 + stream); the split-K variants go to their own entry point, and
+        k = 2 is the training engine's stride-2 data gradient (adayolo_conv_s2grad_fwd: H x W its Ho x Wo grid, Cin the
+        layer's output channels, Cout 4 x its input channels)."""
+        if a[13] == 2:
+            ptr, nbytes = (self._splitk_workspace()[1:]) if a[16] >= self.SPLITK_BASE else (None, 0)
+            return self.L.adayolo_conv_s2grad_fwd(*a[:8], None, 0, None, 0, a[8], a[9], a[10], a[11], a[12] // 4, a[16], ptr, nbytes, a[17])
         if a[16] >= self.SPLITK_BASE:
             _, ptr, nbytes = self._splitk_workspace()
             return self.L.adayolo_conv_splitk_fwd(*a[:8], None, 0, *a[8:17], ptr, nbytes, a[17])
@@ -264,8 +271,8 @@ class YoloEngine:
     def autotune(self, reps=5, cache=None, retune=False, write=True):
         """Pick the fastest conv kernel variant per layer by timing it on this engine's own buffers (all variants
         compute the same result; see include/adayolo.h). Like a vendor library's 'find' step. With `cache` (a JSON
-        path) the choices are loaded when every layer shape is present, otherwise measured and written back (atomically;
-        `write=False` for ranks other than 0 of a multi-process job)."""
+        path) the choice of every layer shape the table holds is loaded, the others are measured and written back
+        (atomically; `write=False` for ranks other than 0 of a multi-process job); `retune` measures all of them."""
         import json
         import os
         st = _lib.stream_ptr()
@@ -279,11 +286,12 @@ class YoloEngine:
                 table = {}
             # a table written by an older build may name variants this library no longer has: treat them as missing
             table = {k: v for k, v in table.items() if v in self.TUNE_CANDIDATES}
-            if keys <= set(table):
+            chosen = {k: table[k] for k in keys if k in table}       # only the layer shapes the table lacks are measured
+            if len(chosen) == len(keys):
                 for kind, fn, args in entries:
                     if kind == "conv":
-                        args[16] = table[tuple(args[8:16])]
-                self.tuned = {k: table[k] for k in keys}
+                        args[16] = chosen[tuple(args[8:16])]
+                self.tuned = chosen
                 self.fuse_pairs()
                 return self.tuned
         with torch.cuda.device(self.dev):
@@ -307,6 +315,8 @@ class YoloEngine:
                             continue                             # weights-in-registers kernel: 3x3 s1, Cin 32 / 64
                         if v >= self.SPLITK_BASE and self._splitk_bytes(args, v) == 0:
                             continue                             # this split does not serve the shape
+                        if args[13] == 2 and v not in self.S2GRAD_VARIANTS:
+                            continue                             # stride-2 data gradient: the kernels with that epilogue
                         args[16] = v
                         fn(*args, st)
                         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -15,6 +15,7 @@ converted from NHWC bf16 to the planar fp32 image layout without the letterbox r
 Gradients are bf16 tensors (fp32 accumulation inside every kernel), like the activations.
 """
 import ctypes
+import os
 
 import torch
 
@@ -32,10 +33,10 @@ class YoloTrainEngine(YoloEngine):
     def _dense(self, H, W, C):
         return _View(self._new(H, W, C), 0, C)
 
-    def _conv_entry(self, src, w, b, dst, k, s, act, res, cout):
+    def _conv_entry(self, src, w, b, dst, k, s, act, res, cout, variant=0):
         args = [ctypes.c_void_p(src.ptr), src.cs, ctypes.c_void_p(w.data_ptr()), ctypes.c_void_p(b.data_ptr()),
                 ctypes.c_void_p(res.ptr) if res is not None else None, res.cs if res is not None else 0,
-                ctypes.c_void_p(dst.ptr), dst.cs, self.B, src.H, src.W, src.C, cout, k, s, act, 0]
+                ctypes.c_void_p(dst.ptr), dst.cs, self.B, src.H, src.W, src.C, cout, k, s, act, variant]
         return ("conv", self._conv_launch, args)
 
     def _build_train(self):
@@ -111,8 +112,19 @@ class YoloTrainEngine(YoloEngine):
                 else:
                     P, dP = None, None
                     self.tfwd.append(self._conv_entry(src, w, b, dst, k, s, act, None, cout))
-                U = self._dense(src.H, src.W, cout) if s == 2 else None
-                bwd.append([("convbwd", None, dict(src=src, dst=dst, res=res, k=k, s=s, cout=cout, wt=wt, P=P, dP=dP, U=U))])
+                # stride 2: the data gradient as a 2x2 conv over the OUTPUT grid with depth-to-space stores
+                # (adayolo_conv_s2grad_fwd, include/adayolo.h) where the sizes are even; zero insertion + 3x3 otherwise
+                w4 = None
+                if s == 2 and k == 3 and src.H == 2 * dst.H and src.W == 2 * dst.W and os.environ.get("ADAYOLO_TRAIN_S2GRAD", "1") == "1":
+                    cin = src.C
+                    w4 = torch.zeros(4 * cin, 2, 2, cout, dtype=w.dtype, device=self.dev)
+                    KH = {(0, 0): 1, (1, 0): 2, (1, 1): 0}
+                    for (pa, dh), kh in KH.items():
+                        for (pb, dw), kw in KH.items():
+                            w4[(2 * pa + pb) * cin:(2 * pa + pb + 1) * cin, dh, dw] = w[:, kh, kw, :cin].t()
+                    self._keep.append(w4)
+                U = self._dense(src.H, src.W, cout) if (s == 2 and w4 is None) else None
+                bwd.append([("convbwd", None, dict(src=src, dst=dst, res=res, k=k, s=s, cout=cout, wt=wt, P=P, dP=dP, U=U, w4=w4))])
 
         # resolve the backward launches in reverse order (accumulate-or-overwrite is decided here, once); `meta` says
         # which views each launch reads and writes (what _backward_plan needs to move a SiLU' into its producer)
@@ -120,7 +132,7 @@ class YoloTrainEngine(YoloEngine):
         for group in reversed(bwd):
             for kind, fn, a in group:
                 if kind == "convbwd":
-                    src, dst, res, k, s, cout, wt, P, dP, U = (a[n] for n in ("src", "dst", "res", "k", "s", "cout", "wt", "P", "dP", "U"))
+                    src, dst, res, k, s, cout, wt, P, dP, U, w4 = (a[n] for n in ("src", "dst", "res", "k", "s", "cout", "wt", "P", "dP", "U", "w4"))
                     gdst = G(dst)
                     if P is not None:
                         gres, acc = (G(res), int(is_written(G(res)))) if res is not None else (None, 0)
@@ -135,6 +147,16 @@ class YoloTrainEngine(YoloEngine):
                         g_in = dP
                     else:
                         g_in = gdst                                                    # no activation: dP is dY itself
+                    if w4 is not None:                                                 # stride 2 without zero insertion
+                        gsrc = G(src)
+                        acc_view = gsrc if is_written(gsrc) else None
+                        gin_view = _View(g_in.buf, g_in.coff, cout)
+                        gin_view.H, gin_view.W = dst.H, dst.W
+                        self.tbwd.append(self._conv_entry(gin_view, w4, zb(4 * src.C), gsrc, 2, 1, _lib.ACT_NONE, acc_view, 4 * src.C, variant=5))
+                        meta.append(dict(reads=[gin_view] + ([acc_view] if acc_view is not None else []), writes=[gsrc], out=gsrc,
+                                         res=acc_view))
+                        mark(gsrc)
+                        continue
                     if s == 2:
                         self.tbwd.append(("zins", self.L.adayolo_zero_insert2x, (
                             ctypes.c_void_p(g_in.ptr), g_in.cs, ctypes.c_void_p(U.ptr), U.cs, self.B, dst.H, dst.W, src.H, src.W, cout)))
@@ -258,7 +280,11 @@ class YoloTrainEngine(YoloEngine):
         return plan
 
     def _conv_dsilu_launch(self, *a):
-        """adayolo_conv_dsilu_fwd's argument list up to `variant` (20) + stream; the workspace is the engine's."""
+        """adayolo_conv_dsilu_fwd's argument list up to `variant` (20) + stream; the workspace is the engine's. k = 2: the
+        stride-2 data gradient with the same epilogue (adayolo_conv_s2grad_fwd)."""
+        if a[17] == 2:
+            ptr, nbytes = (self._splitk_workspace()[1:]) if a[19] >= self.SPLITK_BASE else (None, 0)
+            return self.L.adayolo_conv_s2grad_fwd(*a[:12], a[12], a[13], a[14], a[15], a[16] // 4, a[19], ptr, nbytes, a[20])
         if a[19] >= self.SPLITK_BASE:
             _, ptr, nbytes = self._splitk_workspace()
             return self.L.adayolo_conv_dsilu_fwd(*a[:20], ptr, nbytes, a[20])

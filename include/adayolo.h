@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define ADAYOLO_ABI_VERSION 4
+#define ADAYOLO_ABI_VERSION 5
 
 #define ADAYOLO_ACT_NONE 0
 #define ADAYOLO_ACT_SILU 1
@@ -158,6 +158,24 @@ int adayolo_conv_dsilu_fwd(const void* in, int in_cstride, const void* weight, c
                            int res_cstride, void* out, int out_cstride, const void* pre, int pre_cstride, void* grad_pre,
                            int gp_cstride, int B, int H, int W, int Cin, int Cout, int ksize, int stride, int variant,
                            void* workspace, size_t workspace_bytes, void* stream);
+
+/*
+ * Data gradient of a STRIDE-2 `Conv` (k3, p1; yolov3.yaml's down-sampling layers) without zero insertion: over the
+ * Ho x Wo grid of grad_out = dL/d(pre-activation of that layer) [B,Ho,Wo,Cout], a 2x2 stride-1 convolution (taps (dh,dw) in
+ * {0,1}^2 read grad_out[i+dh, j+dw], zero beyond the far edges) with 4*Cin output channels, group p = 2a+b of which is the
+ * gradient of input pixel (2i+a, 2j+b): g [B,2Ho,2Wo,Cin] (+ residual, same shape) rounded to bf16 -> grad_in (may be NULL
+ * when grad_pre is given); with pre / grad_pre (both or neither) also grad_pre = bf16(g * silu'(pre)) as in
+ * adayolo_conv_dsilu_fwd. 16/9 of the multiply-adds of the exact form, 4/9 of adayolo_zero_insert2x + the 3x3 conv.
+ * weight4: bf16 [4*Cin][2][2][Cout] with
+ *     weight4[(2a+b)*Cin + c][dh][dw][co] = W[co][KH(a,dh)][KH(b,dw)][c],  KH(0,0) = 1, KH(1,0) = 2, KH(1,1) = 0,
+ * and zero for (parity 0, offset 1) (W = the layer's [Cout][3][3][Cin] weights); bias4: fp32 zeros [4*Cin].
+ * Variants 5 / 22 / 26 / 27 / 60 and the split-K ones (workspace as above, sized with ksize = 2, H = Ho, W = Wo,
+ * Cin = Cout, Cout = 4*Cin of this call); ESHAPE where the named kernel does not take the shape.
+ */
+int adayolo_conv_s2grad_fwd(const void* grad_out, int go_cstride, const void* weight4, const float* bias4, const void* residual,
+                            int res_cstride, void* grad_in, int gi_cstride, const void* pre, int pre_cstride, void* grad_pre,
+                            int gp_cstride, int B, int Ho, int Wo, int Cout, int Cin, int variant, void* workspace,
+                            size_t workspace_bytes, void* stream);
 
 /* adayolo_stem_fwd with the activation selectable (ADAYOLO_ACT_NONE keeps the pre-activation for training). */
 int adayolo_stem_fwd_act(const float* img, const float* weight, const float* bias, void* out, int out_cstride,

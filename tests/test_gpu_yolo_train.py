@@ -397,3 +397,66 @@ def test_conv_dsilu_fwd_equals_conv_then_silu_bwd(variant):
                                     k, 1, 50, None, 0, st) == -1
     assert L.adayolo_conv_dsilu_fwd(_p(x), cin, _p(w), _p(zb), None, 0, None, 0, None, 0, _p(gp), cout + 16, B, H, W, cin, cout,
                                     k, 1, 5, None, 0, st) == -1
+
+
+@pytest.mark.parametrize("variant", [5, 27, 60, 104])
+def test_stride2_data_gradient_without_zero_insertion(variant):
+    """adayolo_conv_s2grad_fwd (2x2 conv over the output grid, depth-to-space stores) against fp32 autograd of the stride-2
+    conv, with a residual, with the fused SiLU' (grad_in stored and not), on channel slices; ragged pixel counts."""
+    from adaptiveisp_amd.yolo import _lib
+    L = _lib.load()
+    st = _lib.stream_ptr()
+    served = 0
+    for (B, Ho, Wo, cin, cout, use_res) in [(8, 16, 16, 512, 1024, True), (2, 24, 40, 64, 128, False), (3, 9, 11, 128, 256, True),
+                                           (8, 32, 32, 256, 512, False), (1, 5, 7, 32, 64, True)]:
+        H, W = 2 * Ho, 2 * Wo
+        ws, nws = None, 0
+        if variant >= 100:
+            nws = int(L.adayolo_conv_splitk_workspace_bytes(B, Ho, Wo, cout, 4 * cin, 2, 1, variant))
+            if nws == 0:
+                continue
+            ws = torch.zeros(nws, dtype=torch.uint8, device=DEV)
+        g = torch.Generator().manual_seed(Ho * 7 + cin + variant)
+        w = (torch.randn(cout, 3, 3, cin, generator=g) / (9 * cin) ** 0.5).to(torch.bfloat16).to(DEV)
+        gy = torch.randn(B, Ho, Wo, cout, generator=g).to(torch.bfloat16).to(DEV)
+        res = torch.randn(B, H, W, cin, generator=g).to(torch.bfloat16).to(DEV) if use_res else None
+        pre = (torch.randn(B, H, W, cin + 8, generator=g) * 2).to(torch.bfloat16).to(DEV)[..., 8:]
+        x = torch.zeros(B, cin, H, W, device=DEV, requires_grad=True)
+        F.conv2d(x, w.float().permute(0, 3, 1, 2), stride=2, padding=1).backward(gy.float().permute(0, 3, 1, 2))
+        ref = x.grad.permute(0, 2, 3, 1) + (res.float() if use_res else 0.0)
+        w4 = torch.zeros(4 * cin, 2, 2, cout, dtype=torch.bfloat16, device=DEV)
+        KH = {(0, 0): 1, (1, 0): 2, (1, 1): 0}
+        for (pa, dh), kh in KH.items():
+            for (pb, dw), kw in KH.items():
+                w4[(2 * pa + pb) * cin:(2 * pa + pb + 1) * cin, dh, dw] = w[:, kh, kw, :].t()
+        zb = torch.zeros(4 * cin, device=DEV)
+        nan = lambda c=cin: torch.full((B, H, W, c), float("nan"), dtype=torch.bfloat16, device=DEV)  # noqa: E731
+        wsp, rp = (_p(ws) if ws is not None else None), (_p(res) if use_res else None)
+        gx = nan()
+        rc = L.adayolo_conv_s2grad_fwd(_p(gy), cout, _p(w4), _p(zb), rp, cin if use_res else 0, _p(gx), cin, None, 0, None, 0,
+                                       B, Ho, Wo, cout, cin, variant, wsp, nws, st)
+        if rc == -2:
+            continue
+        assert rc == 0, (rc, variant)
+        torch.cuda.synchronize()
+        assert torch.isfinite(gx.float()).all(), "unwritten (NaN) gradient pixels"
+        scale = max(1.0, ref.abs().max().item())
+        d = (gx.float() - ref).abs()
+        assert d.max().item() <= 2e-2 * scale and d.mean().item() <= 2e-3 * scale, (variant, B, Ho, Wo, cin, cout, d.max().item())
+        gp_ref = nan()
+        assert L.adayolo_silu_bwd(_p(gx), cin, _p(pre), cin + 8, _p(gp_ref), cin, None, 0, 0, B * H * W, cin, st) == 0
+        for store in (True, False):
+            gx2, wide = nan(), nan(cin + 16)
+            gp = wide[..., 8:8 + cin]
+            rc = L.adayolo_conv_s2grad_fwd(_p(gy), cout, _p(w4), _p(zb), rp, cin if use_res else 0, _p(gx2) if store else None,
+                                           cin if store else 0, _p(pre), cin + 8, _p(gp), cin + 16, B, Ho, Wo, cout, cin, variant, wsp, nws, st)
+            assert rc == 0, (rc, variant)
+            torch.cuda.synchronize()
+            assert torch.equal(gp.contiguous().view(torch.int16), gp_ref.view(torch.int16)), (variant, store)
+            if store:
+                assert torch.equal(gx2.view(torch.int16), gx.view(torch.int16))
+            assert torch.isnan(wide[..., :8].float()).all() and torch.isnan(wide[..., 8 + cin:].float()).all()
+        served += 1
+    assert served >= 2, (variant, served)
+    assert L.adayolo_conv_s2grad_fwd(_p(gy), cout, _p(w4), _p(zb), None, 0, None, 0, None, 0, None, 0, B, Ho, Wo, cout, cin, 5, None, 0, st) == -1
+    assert L.adayolo_conv_s2grad_fwd(_p(gy), cout, _p(w4), _p(zb), None, 0, _p(gx), cin, None, 0, None, 0, B, Ho, Wo, cout, cin, 50, None, 0, st) == -1
