@@ -34,8 +34,13 @@ class Trainer:
         self.replay, self.batch_size, self.save_dir = replay, int(batch_size), save_dir
         self.use_truncated, self.max_bri, self.rank, self.world = use_truncated, max_bri, rank, world
         self.max_iter_step = max(1, int(epochs * 1000 // (self.batch_size * world)))
-        self.agent_optimizer = torch.optim.Adam(agent.parameters(), lr=lr)
-        self.value_optimizer = torch.optim.Adam(value.parameters(), lr=lr * float(cfg.value_lr_mul))   # train.py:208-209
+        # torch.optim.Adam as in train.py:208-209. On a GPU its single-kernel form (`fused=True`: the same update rule in one
+        # launch per optimizer instead of ~10 tensor-list launches; state_dict layout unchanged): the iteration is bound by
+        # the HOST's enqueue work once the detector runs split-K — 11.5-13.0 -> 10.9-11.2 ms interleaved on one
+        # box. ADAISP_FUSED_ADAM=0: the default (foreach) form
+        kw = dict(fused=True) if (os.environ.get("ADAISP_FUSED_ADAM", "1") == "1" and next(agent.parameters()).is_cuda) else {}
+        self.agent_optimizer = torch.optim.Adam(agent.parameters(), lr=lr, **kw)
+        self.value_optimizer = torch.optim.Adam(value.parameters(), lr=lr * float(cfg.value_lr_mul), **kw)   # train.py:208-209
         lf = lr_lambda(self.max_iter_step)
         self.agent_scheduler = torch.optim.lr_scheduler.LambdaLR(self.agent_optimizer, lr_lambda=lf)
         self.value_scheduler = torch.optim.lr_scheduler.LambdaLR(self.value_optimizer, lr_lambda=lf)
