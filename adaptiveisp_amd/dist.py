@@ -60,9 +60,12 @@ class GradBucket:
     isp/filters.py:161-162) keep .grad = None as in the reference, so Adam creates no state for them."""
 
     def __init__(self, *modules):
-        self.params = [p for m in modules for p in m.parameters() if p.requires_grad]
+        self.modules = list(modules)
+        self.per_module = [[p for p in m.parameters() if p.requires_grad] for m in modules]   # (walked once, not per iteration)
+        self.params = [p for ps in self.per_module for p in ps]
         self.numel = sum(p.numel() for p in self.params)
         self.flat = None
+        self.views = None
 
     @staticmethod
     def _active():
@@ -74,16 +77,18 @@ class GradBucket:
         dev = self.params[0].device
         if self.flat is None or self.flat.device != dev:
             self.flat = torch.zeros(self.numel + len(self.params), dtype=torch.float32, device=dev)
+            self.views, off = [], 0
+            for p in self.params:                                # one view of the bucket per parameter, made once
+                self.views.append(self.flat[off:off + p.numel()].view_as(p))
+                off += p.numel()
         present = torch.tensor([0.0 if p.grad is None else 1.0 for p in self.params], dtype=torch.float32)
         self.flat[self.numel:].copy_(present)
-        off = 0
-        for p in self.params:
-            n = p.numel()
-            if p.grad is None:
-                self.flat[off:off + n].zero_()
-            else:
-                self.flat[off:off + n].copy_(p.grad.reshape(-1))
-            off += n
+        have = [(v, p.grad) for v, p in zip(self.views, self.params) if p.grad is not None]
+        absent = [v for v, p in zip(self.views, self.params) if p.grad is None]
+        if have:                                                 # two multi-tensor launches instead of one copy per parameter
+            torch._foreach_copy_([v for v, _ in have], [g for _, g in have])
+        if absent:
+            torch._foreach_zero_(absent)
         work = dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, async_op=async_op)
         if not async_op:
             self.flat[:self.numel].div_(dist.get_world_size())
@@ -98,16 +103,15 @@ class GradBucket:
             work.wait()
             self.flat[:self.numel].div_(dist.get_world_size())
         anywhere = self.flat[self.numel:].cpu() > 0      # one small D2H per iteration: which parameters have a gradient on ANY rank
-        off = 0
-        for p, have in zip(self.params, anywhere.tolist()):
-            n = p.numel()
+        dst, src = [], []
+        for p, v, have in zip(self.params, self.views, anywhere.tolist()):
             if have:
-                g = self.flat[off:off + n].view_as(p)
                 if p.grad is None:
-                    p.grad = g.clone()
-                else:
-                    p.grad.copy_(g)
-            off += n
+                    p.grad = torch.empty_like(p)
+                dst.append(p.grad)
+                src.append(v)
+        if dst:
+            torch._foreach_copy_(dst, src)
 
 
 def synced_step(models, optimizers, buckets, max_grad_norm=1e-5):
@@ -116,8 +120,9 @@ def synced_step(models, optimizers, buckets, max_grad_norm=1e-5):
     works = [b.all_reduce_mean(async_op=GradBucket._active()) for b in buckets]
     for b, w in zip(buckets, works):
         b.finish(w)
+    cached = {id(m): ps for b in buckets for m, ps in zip(getattr(b, "modules", ()), getattr(b, "per_module", ()))}
     for m in models:
-        torch.nn.utils.clip_grad_norm_(m.parameters(), max_grad_norm)
+        torch.nn.utils.clip_grad_norm_(cached.get(id(m)) or list(m.parameters()), max_grad_norm)
     for o in optimizers:
         o.step()
         o.zero_grad(set_to_none=True)       # (the reference's default too: the next backward writes the gradients instead of adding to zeros)

@@ -52,8 +52,10 @@ class Trainer:
 
     def step(self):
         it = self.iter
-        self.agent.train()
-        self.value.train()
+        if not self.agent.training:                          # (Module.train() walks ~130 modules: only when the mode changes)
+            self.agent.train()
+        if not self.value.training:
+            self.value.train()
         progress = float(it) / self.max_iter_step
         feed = self.replay.get_feed_dict_and_states(self.batch_size)
         labels = [torch.as_tensor(lb) for lb in feed["label"]]
