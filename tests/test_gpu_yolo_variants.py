@@ -371,3 +371,40 @@ def test_splitk_conv(case):
     assert L.adayolo_conv_splitk_fwd(*args, v, ctypes.c_void_p(small.data_ptr()), small.numel(), _lib.stream_ptr()) == -1   # EINVAL: workspace too small
     assert L.adayolo_conv_splitk_fwd(*args, v, None, 0, _lib.stream_ptr()) == -1
     assert L.adayolo_conv_splitk_fwd(*args, 60, ctypes.c_void_p(ws.data_ptr()), ws.numel(), _lib.stream_ptr()) == -1        # not a split variant
+
+
+def test_splitk_conv_repeated_launches_are_bit_stable():
+    """Race screen for the split-K reduce (partial tiles cross XCDs at device scope, last-arriver ticket): 300 launches each
+    of two training-step shapes on ONE workspace, other work interleaved on a second stream, every result bit-identical to
+    the first and the tickets zero at the end."""
+    from adaptiveisp_amd.yolo import _lib
+    L = _lib.load()
+    other = torch.cuda.Stream()
+    junk = torch.empty(64 << 20, dtype=torch.uint8, device=DEV)
+    for (B, H, W, cin, cout, k, s, v) in [(8, 16, 16, 1024, 512, 3, 1, 106), (8, 32, 32, 512, 256, 3, 1, 104)]:
+        nws = _splitk_bytes(v, B, H, W, cin, cout, k, s)
+        assert nws > 0
+        ws = torch.zeros(nws, dtype=torch.uint8, device=DEV)
+        g = torch.Generator(device="cpu").manual_seed(cin + v)
+        x = torch.randn(B, H, W, cin, generator=g).to(torch.bfloat16).to(DEV)
+        w = (torch.randn(cout, k, k, cin, generator=g) / (k * k * cin) ** 0.5).to(torch.bfloat16).to(DEV)
+        b = torch.randn(cout, generator=g).to(DEV)
+        outs = [torch.empty(B, H, W, cout, dtype=torch.bfloat16, device=DEV) for _ in range(2)]
+        first = None
+        for it in range(300):
+            out = outs[it & 1]
+            if it % 7 == 0:
+                with torch.cuda.stream(other):
+                    junk.add_(1)                       # traffic through the L2s / Infinity Cache beside the launch
+            rc = L.adayolo_conv_splitk_fwd(ctypes.c_void_p(x.data_ptr()), cin, ctypes.c_void_p(w.data_ptr()), ctypes.c_void_p(b.data_ptr()),
+                                           None, 0, ctypes.c_void_p(out.data_ptr()), cout, None, 0, B, H, W, cin, cout, k, s, 1, v,
+                                           ctypes.c_void_p(ws.data_ptr()), ws.numel(), _lib.stream_ptr())
+            assert rc == 0
+            if first is None:
+                torch.cuda.synchronize()
+                first = out.clone()
+            elif it % 10 == 9:
+                torch.cuda.synchronize()
+                assert torch.equal(first.view(torch.int16), out.view(torch.int16)), f"launch {it} differs"
+        torch.cuda.synchronize()
+        assert int(ws[:1024].view(torch.int32).abs().sum()) == 0          # the ticket block (<= 256 tiles)
