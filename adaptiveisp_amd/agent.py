@@ -40,6 +40,35 @@ class FeatureExtractor(_Trunk):
         super().__init__(shape=shape, mid_channels=mid_channels, output_dim=output_dim, dropout_prob=dropout_prob)
 
 
+class _LazyFilterDebug:
+    """The reference's per-filter debug list [{'filter_parameters': p[0], 'mask': mask[0]}, ...] as a sequence whose
+    entries are made on first access (same values, same shapes)."""
+
+    def __init__(self, filters, table):
+        self._filters, self._table, self._items = list(filters), table, None
+        self._masks = [f.mask for f in filters]
+
+    def _build(self):
+        if self._items is None:
+            items = []
+            for j, flt in enumerate(self._filters):
+                p0 = self._table[0, j, :flt.get_num_filter_parameters()]
+                if hasattr(flt, "curve_steps"):                    # curve filters keep the reference's [steps,ch,1,1] view
+                    p0 = p0.reshape(flt.curve_steps, -1, 1, 1)
+                items.append({'filter_parameters': p0, 'mask': self._masks[j][0]})
+            self._items = items
+        return self._items
+
+    def __len__(self):
+        return len(self._filters)
+
+    def __getitem__(self, i):
+        return self._build()[i]
+
+    def __iter__(self):
+        return iter(self._build())
+
+
 class Agent(nn.Module):
     def __init__(self, cfg, shape=(16, 64, 64), device='cuda'):
         super().__init__()
@@ -178,20 +207,14 @@ class Agent(nn.Module):
         packed, op_ids, selected, surrogate, penalty, new_states, pdf, table = res[:8]
         masks = res[8] if len(res) > 8 else None            # fc_mask outputs: eval only (unused while masking is off)
 
-        filter_debug_info = []
+        if self._ones_mask is None or self._ones_mask.device != x.device:       # Filter.get_mask with masking off: ones(1,1,1,1),
+            self._ones_mask = torch.ones((1, 1, 1, 1), dtype=torch.float32, device=x.device)   # one shared tensor, not a fill per filter
         for j, flt in enumerate(self.filters):
-            n = flt.get_num_filter_parameters()
-            p0 = table[0, j, :n]
-            if hasattr(flt, "curve_steps"):                    # curve filters keep the reference's [steps,ch,1,1] view
-                p0 = p0.reshape(flt.curve_steps, -1, 1, 1)
             flt.mask_parameters = masks[j] if masks is not None else None
-            if flt.use_masking():
-                flt.mask = flt.get_mask(x, flt.mask_parameters)
-            else:                                              # Filter.get_mask with masking off: ones(1,1,1,1) — one shared
-                if self._ones_mask is None or self._ones_mask.device != x.device:      # tensor instead of a fill launch per filter
-                    self._ones_mask = torch.ones((1, 1, 1, 1), dtype=torch.float32, device=x.device)
-                flt.mask = self._ones_mask
-            filter_debug_info.append({'filter_parameters': p0, 'mask': flt.mask[0]})
+            flt.mask = flt.get_mask(x, flt.mask_parameters) if flt.use_masking() else self._ones_mask
+        # debug_info['filter_debug_info'] (agent.py:138-146: per filter the first image's parameters and mask) is built when
+        # somebody reads it — ~50 view ops per call that the training loop never looks at
+        filter_debug_info = _LazyFilterDebug(self.filters, table)
 
         # pixels: only the selected filter runs
         x = self._apply_isp(x, packed, op_ids)
