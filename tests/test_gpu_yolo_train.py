@@ -460,3 +460,47 @@ def test_stride2_data_gradient_without_zero_insertion(variant):
     assert served >= 2, (variant, served)
     assert L.adayolo_conv_s2grad_fwd(_p(gy), cout, _p(w4), _p(zb), None, 0, None, 0, None, 0, None, 0, B, Ho, Wo, cout, cin, 5, None, 0, st) == -1
     assert L.adayolo_conv_s2grad_fwd(_p(gy), cout, _p(w4), _p(zb), None, 0, _p(gx), cin, None, 0, None, 0, B, Ho, Wo, cout, cin, 50, None, 0, st) == -1
+
+
+def test_stride2_gradient_forms_agree_through_the_whole_backward():
+    """The detector backward at the config-4 per-rank shape with the stride-2 layers back-propagated (a) by zero insertion +
+    3x3 conv, (b) by adayolo_conv_s2grad_fwd: the same forward (bit for bit), image gradients that differ only by bf16
+    rounding of differently ordered sums (relative L2 distance, cosine), five zero-insert launches gone."""
+    import os
+    from _synth import synth_yolo_state_dict, test_image
+    from adaptiveisp_amd.yolo import YoloTrainEngine, yolov3
+    cache = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "adaptiveisp_amd", "yolo", "tuning", "mi355x.json")
+    det = yolov3()
+    det.load_state_dict(synth_yolo_state_dict(det, seed=2))
+    det = det.to(DEV).train()
+    for p in det.parameters():
+        p.requires_grad_(False)
+    B, H, W = 8, 512, 512
+    x = torch.from_numpy(test_image(B, H, W, seed=7, special=False)).to(DEV)
+    res = {}
+    for flag in ("0", "1"):
+        os.environ["ADAYOLO_TRAIN_S2GRAD"] = flag
+        try:
+            eng = YoloTrainEngine(det, B, H, W, device=DEV)
+            eng.autotune(cache=cache, write=False)
+            xr = x.clone().requires_grad_(True)
+            raws = eng(xr)
+            R = [torch.randn(r.shape, generator=torch.Generator().manual_seed(3 + i)).to(DEV) for i, r in enumerate(raws)]
+            sum((r * w).sum() for r, w in zip(raws, R)).backward()
+            torch.cuda.synchronize()
+            nz = sum(1 for e in eng._backward_plan() if e[0] == "zins")
+            res[flag] = ([r.detach().clone() for r in raws], xr.grad.clone(), nz)
+            del eng
+        finally:
+            os.environ.pop("ADAYOLO_TRAIN_S2GRAD", None)
+    assert res["0"][2] == 5 and res["1"][2] == 0
+    for a, b in zip(res["0"][0], res["1"][0]):
+        assert torch.equal(a, b)
+    ga, gb = res["0"][1], res["1"][1]
+    rel = ((ga - gb).norm() / ga.norm()).item()
+    cos = F.cosine_similarity(ga.reshape(1, -1), gb.reshape(1, -1)).item()
+    import _margins
+    _margins.NOTES.append(f"detector image gradient, zero-insert form vs 2x2 depth-to-space form at 8x512x512: rel {rel:.5f} cos {cos:.7f}")
+    # each form is ~1.25 % from fp32 autograd (test_backward_to_image_vs_fp32_autograd) with its own bf16 roundings: measured
+    # 0.9 % apart, cosine 0.99996
+    assert rel < 2e-2 and cos > 0.9998, (rel, cos)
