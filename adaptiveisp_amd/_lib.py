@@ -9,7 +9,8 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libadaisp.so")
+# ADAISP_LIB: another BUILD of the same library (tools/build_variant.py); never a fallback
+LIB_PATH = os.environ.get("ADAISP_LIB") or os.path.join(_HERE, "csrc", "libadaisp.so")
 
 OP_ZERO, OP_EXPOSURE, OP_GAMMA, OP_CCM, OP_SHARPEN, OP_NLM, OP_TONE = -1, 0, 1, 2, 3, 4, 5
 OP_CONTRAST, OP_SATPLUS, OP_WNB, OP_WB, OP_USM, OP_SHARPEN_V2, OP_COLOR = 6, 7, 8, 9, 10, 11, 12

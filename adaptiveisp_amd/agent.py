@@ -146,10 +146,22 @@ class Agent(nn.Module):
         return _lib.forward(x, plan["op_ids"], plan["packed"], clip=True, no_usm=no_usm, out=out, pooled=pooled_next,
                             host_op=plan.get("host_op"))
 
+    @staticmethod
+    def _version_of(t):
+        """The tensor's version counter, or None when it has none: inference tensors (`torch.inference_mode()`, the mode
+        the reference's eval entry runs in, val_adaptiveisp.py:104) do not track versions, so nothing could tell a later
+        in-place write — such a tensor is never cached."""
+        if torch.is_inference(t):
+            return None
+        try:
+            return t._version
+        except RuntimeError:
+            return None
+
     def _cached_pool(self, x):
         """The pooling of x if x IS the tensor the previous eval step returned, unmodified since."""
         c = self._pool_cache
-        if c is not None and c[0]() is x and x._version == c[1]:
+        if c is not None and c[1] is not None and c[0]() is x and self._version_of(x) == c[1]:
             return c[2]
         return None
 
@@ -160,7 +172,8 @@ class Agent(nn.Module):
         # :293-304, the bench) never runs a separate pooling pass after the first step
         pooled_next = torch.empty((x.shape[0], 3, 64, 64), dtype=torch.float32, device=x.device)
         x_out = self.apply_step(x, o, out=out, pooled_next=pooled_next)
-        self._pool_cache = (weakref.ref(x_out), x_out._version, pooled_next)      # (_lib bumps the version of every tensor a kernel writes)
+        ver = self._version_of(x_out)                 # (_lib bumps the version of every tensor a kernel writes)
+        self._pool_cache = (weakref.ref(x_out), ver, pooled_next) if ver is not None else None
         hr_out = self.apply_step(high_res, o) if high_res is not None else None
         mask = self._ones_mask                      # Filter.get_mask with masking off (isp/filters.py:161-173): ones(1,1,1,1)
         if mask is None or mask.device != x.device:
@@ -294,7 +307,9 @@ class Agent(nn.Module):
         out = torch.where(c["is_sig"], torch.sigmoid(x), out)               # NLM, S+, BW
         out = torch.where(c["is_tanh"], torch.tanh(x), out)                 # contrast
         lum = 1e-5 + 0.27 * out[..., 0] + 0.67 * out[..., 1] + 0.06 * out[..., 2]               # isp/filters.py:204-206
-        norm = torch.where(c["is_wb"], 1.0 / lum, torch.ones_like(lum))
+        # masked BEFORE the reciprocal: the other filters' "lum" can land on exactly 0 (negative outputs), and the unselected
+        # branch of a where() still back-propagates 0 * inf = NaN into that filter's heads
+        norm = 1.0 / torch.where(c["is_wb"], lum, torch.ones_like(lum))
         return out * (norm[..., None] * c["valid"])
 
     def policy_heads(self, x_down, noise, states, entropy_coef, train=True, forced_id=None, with_masks=False):

@@ -123,6 +123,12 @@ __global__ __launch_bounds__(512) void k_conv_pp(const ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float* bias_s = reinterpret_cast<float*>(smem + (kEpi > 2 * kBuf ? kEpi : 2 * kBuf));
     PP_STAMP(0);
+#ifdef PP_DEPHASE            // measurement build: every other workgroup of an XCD starts PP_DEPHASE cycles late
+    if ((blockIdx.x >> 3) & 1) {
+        const unsigned long long t0 = __builtin_readcyclecounter();
+        while (__builtin_readcyclecounter() - t0 < (unsigned long long)(PP_DEPHASE)) __builtin_amdgcn_s_sleep(16);
+    }
+#endif
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);

@@ -5,7 +5,8 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-LIB_PATH = os.path.join(_HERE, "csrc", "libadayolo.so")
+# ADAYOLO_LIB: another BUILD of the same library (measurement builds of tools/build_variant.py); never a fallback
+LIB_PATH = os.environ.get("ADAYOLO_LIB") or os.path.join(_HERE, "csrc", "libadayolo.so")
 ABI_VERSION = 5
 ACT_NONE, ACT_SILU = 0, 1
 EXPORTS = ("adayolo_conv_fwd", "adayolo_conv_fwd_variant", "adayolo_conv_fused1x1_fwd", "adayolo_conv_keep_fwd", "adayolo_conv_splitk_fwd", "adayolo_conv_dsilu_fwd", "adayolo_conv_s2grad_fwd", "adayolo_conv_splitk_workspace_bytes", "adayolo_stem_fwd", "adayolo_upsample2x", "adayolo_detect_decode", "adayolo_nms", "adayolo_nms_workspace_bytes", "adayolo_stem_fwd_act", "adayolo_stem_down_fwd", "adayolo_letterbox_pack", "adayolo_silu_fwd", "adayolo_silu_bwd",

@@ -335,3 +335,33 @@ def test_eval_loop_reuses_the_pooling_of_the_filter_launch(golden):
         (y, _, _, _), _, _ = ag((T(g["x"]).to(dev), z, T(g["s0"]).to(dev)), 0.5)
         _lib.process(_lib.OP_EXPOSURE, T(g["x"]).to(dev), torch.ones(y.shape[0], 1, device=dev), out=y)   # raw-pointer write
         assert ag._cached_pool(y) is None
+
+
+def test_eval_loop_under_inference_mode(golden):
+    """The reference's eval entry runs under `torch.inference_mode()` (val_adaptiveisp.py:104 `@smart_inference_mode()`):
+    inference tensors have no version counter, so the pooled-plane cache must stand aside — same selections, states and
+    pixels as the `no_grad` loop, every step pooled by a launch of its own."""
+    g = golden("agent")
+    ag, cfg, dev = _agent()
+    z = T(g["z"]).to(dev)
+
+    def loop(ctx):
+        trace = []
+        with ctx():
+            x, st = T(g["x"]).to(dev), T(g["s0"]).to(dev)
+            zz = z.clone()
+            for k in range(4):
+                (x, st, sur, pen), dbg, _ = ag((x, zz, st), 0.5)
+                trace.append((x.clone(), st.clone(), dbg["selected_filter"].clone(), dbg["pdf"].clone(), pen.clone()))
+                if ctx is torch.inference_mode:
+                    assert torch.is_inference(x) and ag._cached_pool(x) is None
+        return trace
+
+    a, b = loop(torch.inference_mode), loop(torch.no_grad)
+    for ta, tb in zip(a, b):
+        assert all(torch.equal(u.clone(), v) for u, v in zip(ta, tb))
+    # a normal tensor handed in while inference mode is on still has its version: the cache keeps working for it
+    with torch.no_grad():
+        (x, st, _, _), _, _ = ag((T(g["x"]).to(dev), z, T(g["s0"]).to(dev)), 0.5)
+    with torch.inference_mode():
+        assert ag._cached_pool(x) is not None

@@ -192,3 +192,41 @@ def test_batched_heads_match_the_per_filter_heads():
     assert torch.equal(a[2], b[2]) and torch.equal(a[5], b[5])                   # selections, states
     torch.testing.assert_close(a[0], b[0], rtol=2e-5, atol=2e-6)                 # packed parameters of the selected filters
     torch.testing.assert_close(a[4], b[4], rtol=1e-5, atol=1e-6)
+
+
+def test_batched_heads_survive_a_zero_luminance_in_an_unselected_filter():
+    """`lum = 1e-5 + 0.27 o0 + 0.67 o1 + 0.06 o2` can be exactly 0 for a filter that is NOT white balance (its
+    outputs may be negative); the reciprocal must be masked BEFORE it is formed or `where` back-propagates 0 * inf = NaN
+    into that filter's heads. Forced here by making the contrast head output the exact root."""
+    import torch
+    from _engine import cpu_agent
+    from adaptiveisp_amd.config import cfg
+    ag = cpu_agent(cfg, seed=0).train()
+    B = 3
+    feats = torch.randn(B, cfg.feature_extractor_dims)
+    j = [f.get_short_name() for f in ag.filters].index("Ct")
+    with torch.no_grad():                                   # contrast: out = tanh(x); x = bias only -> lum == 0 exactly
+        ag.filters[j].fc_filter.weight.zero_()
+        ag.filters[j].fc_filter.bias.fill_(float(torch.atanh(torch.tensor(-1e-5 / 0.27))))
+    c = ag._head_consts(feats.device)
+    out = ag._heads_batched(feats)
+    assert torch.isfinite(out).all()
+    out.sum().backward()
+    for flt in ag.filters:
+        for p in (flt.fc1.weight, flt.fc_filter.weight, flt.fc_filter.bias):
+            assert torch.isfinite(p.grad).all(), flt.get_short_name()
+
+
+def test_pool_cache_stands_aside_for_inference_tensors():
+    """`Tensor._version` raises on inference tensors (`torch.inference_mode()`, val_adaptiveisp.py:104)."""
+    import torch
+    from adaptiveisp_amd.agent import Agent
+    with torch.inference_mode():
+        t = torch.zeros(2, 3)
+        assert Agent._version_of(t) is None
+    u = torch.zeros(2, 3)
+    v0 = Agent._version_of(u)
+    u.add_(1)
+    assert Agent._version_of(u) == v0 + 1
+    with torch.inference_mode():
+        assert Agent._version_of(u) == v0 + 1
