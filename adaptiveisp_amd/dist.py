@@ -74,6 +74,7 @@ class GradBucket:
     def all_reduce_mean(self, async_op=False):
         if not self._active():
             return None                       # single process: the gradients stay where autograd put them
+        self._check_pending()
         dev = self.params[0].device
         if self.flat is None or self.flat.device != dev:
             self.flat = torch.zeros(self.numel + len(self.params), dtype=torch.float32, device=dev)
@@ -81,8 +82,13 @@ class GradBucket:
             for p in self.params:                                # one view of the bucket per parameter, made once
                 self.views.append(self.flat[off:off + p.numel()].view_as(p))
                 off += p.numel()
-        present = torch.tensor([0.0 if p.grad is None else 1.0 for p in self.params], dtype=torch.float32)
-        self.flat[self.numel:].copy_(present)
+            # the presence mask is built in ONE persistent host buffer (pinned when the bucket lives on a GPU: the copy is
+            # then asynchronous; a fresh pageable tensor per iteration made it a blocking one)
+            self._present_host = torch.zeros(len(self.params), dtype=torch.float32, pin_memory=dev.type == "cuda")
+        ph = self._present_host
+        for i, p in enumerate(self.params):
+            ph[i] = 0.0 if p.grad is None else 1.0
+        self.flat[self.numel:].copy_(ph, non_blocking=True)
         have = [(v, p.grad) for v, p in zip(self.views, self.params) if p.grad is not None]
         absent = [v for v, p in zip(self.views, self.params) if p.grad is None]
         if have:                                                 # two multi-tensor launches instead of one copy per parameter
@@ -94,6 +100,33 @@ class GradBucket:
             self.flat[:self.numel].div_(dist.get_world_size())
         return work
 
+    # ---- which parameters received a gradient on ANY rank ------------------------------------------------------------
+    # Reading the reduced mask is a device-to-host copy that waits for the whole backward AND the all-reduce: done every
+    # iteration it serialises the host behind the GPU (the next iteration's ~10 ms of enqueue work cannot start), for the one
+    # configuration data parallelism exists for. It is needed only when THIS rank lacks a gradient for a parameter that may
+    # have one elsewhere. So: the set of parameters without a gradient on any rank is learned by a (blocking) read the first
+    # time this rank lacks one, and afterwards a rank whose missing gradients all lie in that set reads nothing. That the
+    # set is still right is verified on the device — (mask of the set) > 0 anywhere -> a pinned flag behind an event, read
+    # one iteration later, when it has long landed: a parameter of the set that receives a gradient on another rank raises
+    # loudly (the replicas have diverged by one update) instead of drifting. ADAISP_DP_FETCH_MASK=1: read every iteration.
+    def _check_pending(self):
+        pend, self._pending = getattr(self, "_pending", None), None
+        if pend is not None:
+            flag, event = pend
+            if event is not None:
+                event.synchronize()
+            if bool(flag[0]):
+                raise RuntimeError("GradBucket: a parameter that had no gradient on any rank received one on another rank in the "
+                                   "previous iteration; this rank skipped its update (replicas diverged by one step). Set "
+                                   "ADAISP_DP_FETCH_MASK=1 to read the presence mask every iteration.")
+
+    def _fetch_anywhere(self):
+        self.mask_fetches = getattr(self, "mask_fetches", 0) + 1
+        anywhere = (self.flat[self.numel:].cpu() > 0).tolist()
+        self._never = frozenset(i for i, a in enumerate(anywhere) if not a)
+        self._never_idx = None
+        return anywhere
+
     def finish(self, work=None):
         """Complete an async all-reduce (if any) and scatter the averaged bucket back into .grad (materialising .grad
         where another rank had a gradient and this one did not)."""
@@ -102,14 +135,32 @@ class GradBucket:
         if work is not None:
             work.wait()
             self.flat[:self.numel].div_(dist.get_world_size())
-        anywhere = self.flat[self.numel:].cpu() > 0      # one small D2H per iteration: which parameters have a gradient on ANY rank
+        local_absent = [i for i, p in enumerate(self.params) if p.grad is None]
+        never = getattr(self, "_never", None)
+        if not local_absent:
+            anywhere = None                                      # every gradient exists here: nothing to learn from the mask
+        elif os.environ.get("ADAISP_DP_FETCH_MASK") == "1" or never is None or not never.issuperset(local_absent):
+            anywhere = self._fetch_anywhere()
+        else:
+            anywhere = None                                      # all of them are known to be absent everywhere: verify, do not wait
+            if getattr(self, "_never_idx", None) is None:
+                self._never_idx = torch.tensor(sorted(never), dtype=torch.int64, device=self.flat.device) + self.numel
+                self._flag_host = torch.zeros(1, dtype=torch.bool, pin_memory=self.flat.device.type == "cuda")
+            bad = (self.flat.index_select(0, self._never_idx) > 0).any().reshape(1)
+            self._flag_host.copy_(bad, non_blocking=True)
+            event = None
+            if self.flat.is_cuda:
+                event = torch.cuda.Event()
+                event.record()
+            self._pending = (self._flag_host, event)
         dst, src = [], []
-        for p, v, have in zip(self.params, self.views, anywhere.tolist()):
-            if have:
-                if p.grad is None:
-                    p.grad = torch.empty_like(p)
-                dst.append(p.grad)
-                src.append(v)
+        for i, (p, v) in enumerate(zip(self.params, self.views)):
+            if p.grad is None:
+                if anywhere is None or not anywhere[i]:
+                    continue
+                p.grad = torch.empty_like(p)
+            dst.append(p.grad)
+            src.append(v)
         if dst:
             torch._foreach_copy_(dst, src)
 

@@ -250,15 +250,49 @@ def main(argv=None):
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
     timed = max(0, n - a.warmup)
+    # the collective alone: the iteration's ONE flattened gradient bucket all-reduced 5 times back to back, bracketed by a
+    # pair of events on the stream it is issued from (host clock without a device) — what the xGMI ring costs per iteration
+    bucket = (tr.buckets[0] if hasattr(tr, "buckets") else tr.bucket)
+    bucket_bytes = 4 * (bucket.numel + len(bucket.params))
+    ar_ms = None
+    if world > 1 and bucket.flat is not None:
+        reps = 5
+        torch.distributed.all_reduce(bucket.flat)                    # warm the communicator
+        fence()
+        if bucket.flat.is_cuda:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                torch.distributed.all_reduce(bucket.flat)
+            e1.record()
+            torch.cuda.synchronize()
+            ar_ms = e0.elapsed_time(e1) / reps
+        else:
+            t1 = time.perf_counter()
+            for _ in range(reps):
+                torch.distributed.all_reduce(bucket.flat)
+            ar_ms = (time.perf_counter() - t1) / reps * 1e3
     if rank == 0:
         last = tr.history[-1] if tr.history else {}
+        ms_it = dt / max(timed, 1) * 1e3
+        # the same one-line shape as bench.py (metric / value / unit / n_gpus / steps / warmup / ms_per_step / scaling / config),
+        # so that the first multi-GPU lease yields a config-4 scaling point from one command
         print(json.dumps({"metric": "RL training images/sec", "value": round(world * a.batch * timed / dt, 2) if timed else None,
-                          "n_gpus": world, "iters": timed, "ms_per_iter": round(dt / max(timed, 1) * 1e3, 2),
+                          "unit": "images/sec", "n_gpus": world, "steps": timed, "warmup": min(a.warmup, n),
+                          "ms_per_step": round(ms_it, 2), "iterations_per_sec": round(1e3 / ms_it, 2) if timed else None,
+                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                          "dtype": "bf16 detector / fp32 ISP + heads", "data": "synthetic" + (" (DRY REHEARSAL: no device)" if dry else ""),
+                          "iters": timed, "ms_per_iter": round(ms_it, 2),
                           "per_gpu_batch": a.batch, "global_batch": a.batch * world, "image": f"{a.size}x{a.size}",
+                          "config": {"workload": f"RL iteration (agent + value + replay + frozen YOLOv3 reward, train.py:234-351) "
+                                                 f"batch {a.batch} x {a.size}x{a.size} per GPU", "per_gpu_batch": a.batch,
+                                     "global_batch": a.batch * world, "parallelism": f"dp{world}"},
                           # what the N > 1 semantics are: BatchNorm statistics of the agent / value CNNs per rank (False) or
                           # over the global batch (True = the reference's single-GPU batch-64 behaviour); gradients of both
                           # models travel in ONE flattened all-reduce per iteration
-                          "sync_bn": bool(a.sync_bn), "grad_buckets": 1,
+                          "sync_bn": bool(a.sync_bn), "grad_buckets": 1, "grad_bucket_bytes": bucket_bytes,
+                          "all_reduce_ms": round(ar_ms, 3) if ar_ms is not None else None,
+                          "mask_fetches": getattr(bucket, "mask_fetches", 0),
                           "parallelism": f"dp{world}" + (" (DRY REHEARSAL: no device)" if dry else ""),
                           "last": last}), flush=True)
     if world > 1:

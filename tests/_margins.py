@@ -68,8 +68,36 @@ def close(label, got, ref, rtol, atol=0.0, err_msg=""):
                           f"max abs {float(d.max()):.3g} {err_msg}")
 
 
+def close_scaled(label, got, ref, frac, floor=1.0, err_msg=""):
+    """max |got - ref| <= frac * max(floor, max |ref|): the detector's rule (bf16 kernels against an fp32 reference: the error
+    is a fraction of the tensor's scale, not of each element). Recorded like `close` on the scale-normalised tensors, so the
+    measured share of the bound lands in the same table."""
+    g, r = _np(got), _np(ref)
+    scale = max(float(floor), float(np.abs(r[np.isfinite(r)]).max()) if r.size else 0.0)
+    close(label, g / scale, r / scale, rtol=0.0, atol=float(frac), err_msg=err_msg)
+
+
+VECTORS = {}
+
+
+def vector_close(label, got, ref, max_rel, min_cos):
+    """Whole-tensor agreement of a bf16 result with its fp32 reference: relative L2 distance and cosine (what a gradient
+    through 75 bf16 layers can be held to; element-wise bounds say nothing there). Largest rel / smallest cosine per label are
+    written below the table."""
+    g, r = _np(got).ravel(), _np(ref).ravel()
+    assert g.shape == r.shape and np.isfinite(g).all(), label
+    nr = float(np.linalg.norm(r))
+    rel = float(np.linalg.norm(g - r)) / max(nr, 1e-30)
+    cos = float(g @ r) / max(float(np.linalg.norm(g)) * nr, 1e-30)
+    rec = VECTORS.setdefault(label, {"n": 0, "rel": 0.0, "cos": 1.0, "max_rel": max_rel, "min_cos": min_cos})
+    rec["n"] += 1
+    rec["rel"], rec["cos"] = max(rec["rel"], rel), min(rec["cos"], cos)
+    assert rel <= max_rel and cos >= min_cos, f"{label}: rel L2 {rel:.5f} (bound {max_rel}), cosine {cos:.6f} (bound {min_cos})"
+    return rel, cos
+
+
 def dump(path):
-    if not RECORDS and not NOTES:
+    if not RECORDS and not NOTES and not VECTORS:
         return
     lines = ["# label | assertions | max abs err | max rel err (|ref| >= 1e-3) | r4 | need_atol | share of asserted tolerance used "
              "| asserted rtol | asserted atol | cap rtol | cap atol"]
@@ -77,6 +105,8 @@ def dump(path):
         r = RECORDS[k]
         lines.append(f"{k} | {r['n']} | {r['max_abs']:.3e} | {r['max_rel']:.3e} | {r['r4']:.3e} | {r['need_atol']:.3e} | "
                      f"{r['used']:.3f} | {r['rtol']:g} | {r['atol']:g} | {r['cap_r']:g} | {r['cap_a']:g}")
+    lines += [f"# vector {k} | assertions {v['n']} | rel L2 {v['rel']:.5f} (bound {v['max_rel']}) | cosine {v['cos']:.7f} "
+              f"(bound {v['min_cos']})" for k, v in sorted(VECTORS.items())]
     lines += ["# " + n for n in NOTES]
     with open(path, "w") as f:
         f.write("\n".join(lines) + "\n")

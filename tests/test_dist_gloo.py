@@ -89,6 +89,74 @@ def test_two_rank_gradient_all_reduce():
     assert got == [(0, 1223841), (1, 1223841)]
 
 
+def _mask_worker(rank, world, port, out):
+    """World 4, unequal presence masks: parameter k of a 6-layer stack has a gradient on rank r iff bit r of PATTERN[k]."""
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    os.environ.pop("ADAISP_DP_FETCH_MASK", None)
+    import torch.distributed as dist
+    from adaptiveisp_amd import dist as adist
+    torch.set_num_threads(1)
+    adist.init_from_env("gloo")
+    net = torch.nn.ModuleList([torch.nn.Linear(3, 2, bias=False) for _ in range(6)])
+    with torch.no_grad():
+        for l in net:
+            l.weight.fill_(1.0)
+    PATTERN = [0b1111, 0b0001, 0b1010, 0b0000, 0b0110, 0b0000]      # two parameters never get a gradient anywhere
+    bucket = adist.GradBucket(net)
+    opt = torch.optim.SGD(net.parameters(), lr=1.0)
+    for it in range(4):
+        for k, l in enumerate(net):
+            l.weight.grad = torch.full_like(l.weight, float(rank + 1)) if (PATTERN[k] >> rank) & 1 else None
+        adist.synced_step([net], [opt], [bucket], max_grad_norm=1e9)
+    for k, l in enumerate(net):
+        ranks = [r for r in range(world) if (PATTERN[k] >> r) & 1]
+        step = sum(r + 1 for r in ranks) / world                   # mean over ALL ranks of the gradients that exist
+        torch.testing.assert_close(l.weight.detach(), torch.full_like(l.weight, 1.0 - 4 * step))
+    # the reduced mask was read ONCE (first iteration: the set of never-used parameters is learned); ranks that lack a
+    # gradient only inside that set — or lack none — do not read it again. Rank 0 lacks parameter 2 (present on ranks 1, 3)
+    # every iteration, so it reads every iteration.
+    lacks_live = any(PATTERN[k] and not (PATTERN[k] >> rank) & 1 for k in range(6))
+    fetches = getattr(bucket, "mask_fetches", 0)
+    assert fetches == (4 if lacks_live else 1), (rank, fetches)
+    # a rank whose missing gradients all lie in the learned never-set skips the read; when such a parameter then DOES get a
+    # gradient elsewhere, the device-side check raises on the next iteration instead of letting the replicas drift
+    net2 = torch.nn.ModuleList([torch.nn.Linear(2, 2, bias=False) for _ in range(2)])
+    b2 = adist.GradBucket(net2)
+    opt2 = torch.optim.SGD(net2.parameters(), lr=0.1)
+
+    def run(second_on_rank0):
+        net2[0].weight.grad = torch.ones_like(net2[0].weight)
+        net2[1].weight.grad = torch.ones_like(net2[1].weight) if (second_on_rank0 and rank == 0) else None
+        adist.synced_step([net2], [opt2], [b2], max_grad_norm=1e9)
+
+    run(False); run(False)
+    assert getattr(b2, "mask_fetches", 0) == 1
+    run(True)                                           # rank 0 alone produces a gradient for the "never" parameter
+    raised = False
+    try:
+        b2._check_pending()                             # what the next iteration's all_reduce_mean() starts with
+    except RuntimeError as e:
+        raised = "ADAISP_DP_FETCH_MASK" in str(e)
+    assert raised == (rank != 0), (rank, raised)        # every rank that skipped the update says so
+    out.put((rank, fetches))
+    dist.destroy_process_group()
+
+
+def test_four_ranks_unequal_presence_masks():
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_mask_worker, args=(r, 4, port, out)) for r in range(4)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(180)
+        assert p.exitcode == 0
+    got = sorted(out.get(timeout=5) for _ in range(4))
+    assert [g[0] for g in got] == [0, 1, 2, 3]
+
+
 def test_single_process_is_a_no_op():
     from adaptiveisp_amd import dist as adist
     lin = torch.nn.Linear(4, 2)
@@ -257,3 +325,8 @@ def test_train_gpus_n_launches_n_ranks():
                          {"ADAISP_DP_REHEARSAL": "dry"})
     assert line["n_gpus"] == 2 and line["global_batch"] == 8 and line["per_gpu_batch"] == 4
     assert line["sync_bn"] is False and line["grad_buckets"] == 1 and line["iters"] == 2
+    # the same one-line shape as bench.py, plus the collective's own figures
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "config"):
+        assert k in line, k
+    assert line["steps"] == 2 and line["scaling"] == "weak" and line["config"]["parallelism"] == "dp2"
+    assert line["grad_bucket_bytes"] == 4 * (8 * 8 + 8 + 2) and line["all_reduce_ms"] > 0

@@ -504,3 +504,46 @@ def test_stride2_gradient_forms_agree_through_the_whole_backward():
     # each form is ~1.25 % from fp32 autograd (test_backward_to_image_vs_fp32_autograd) with its own bf16 roundings: measured
     # 0.9 % apart, cosine 0.99996
     assert rel < 2e-2 and cos > 0.9998, (rel, cos)
+
+
+def test_config4_shape_tuned_engine_vs_fp32_autograd():
+    """the training engine at BASELINE config 4's per-rank shape (8 x 512 x 512) with the TUNED table — the
+    split-K (S = 2..6), stride-2-gradient and SiLU'-in-epilogue variants the autotuner picks only at this shape are all active
+    — against fp32 autograd of the module tree THROUGH THE WHOLE NETWORK: raw head maps of the training forward and the image
+    gradient of every image (relative L2 / cosine per image, recorded in the parity-margins file). train.py:262-271,341-342."""
+    import os
+    import _margins
+    from _synth import synth_yolo_state_dict, test_image
+    from adaptiveisp_amd.yolo import YoloTrainEngine, yolov3
+    cache = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "adaptiveisp_amd", "yolo", "tuning", "mi355x.json")
+    det = yolov3()
+    det.load_state_dict(synth_yolo_state_dict(det, seed=2))
+    det = det.to(DEV).train()
+    for m in det.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.eval()
+    for p in det.parameters():
+        p.requires_grad_(False)
+    B, H, W = 8, 512, 512
+    eng = YoloTrainEngine(det, B, H, W, device=DEV)
+    tuned = eng.autotune(cache=cache, write=False)
+    bwd = eng._backward_plan()
+    kinds = {e[0] for e in bwd}
+    assert any(v >= 100 for v in tuned.values()), "config-4 shape: the table routes no layer to split-K"
+    assert "zins" not in kinds, "config-4 shape: a stride-2 layer still goes through zero insertion"
+    x = torch.from_numpy(test_image(B, H, W, seed=23, special=False)).to(DEV)
+    g = torch.Generator().manual_seed(9)
+    xr = x.clone().requires_grad_(True)
+    raws_ref = det(xr)                                    # fp32 module tree (512 is a multiple of 32: no letterbox rows)
+    R = [torch.randn(r.shape, generator=g).to(DEV) for r in raws_ref]
+    sum((r * w).sum() for r, w in zip(raws_ref, R)).backward()
+    xh = x.clone().requires_grad_(True)
+    raws = eng(xh)
+    for a, b in zip(raws, raws_ref):
+        _margins.close_scaled("yolo.train_engine_raw_maps_8x512x512", a, b.detach(), 5e-2)
+    sum((r * w).sum() for r, w in zip(raws, R)).backward()
+    torch.cuda.synchronize()
+    assert torch.isfinite(xh.grad).all()
+    for i in range(B):                                    # every image of the batch on its own: a wrong tile of one image cannot hide
+        _margins.vector_close("yolo.train_engine_image_grad_8x512x512", xh.grad[i], xr.grad[i], max_rel=0.025, min_cos=0.9995)
+    _margins.vector_close("yolo.train_engine_image_grad_8x512x512.batch", xh.grad, xr.grad, max_rel=0.025, min_cos=0.9995)
