@@ -863,14 +863,22 @@ def main():
                                         ("beside the ISP episode of the next batch on a second stream (the headline's arrangement)"
                                          if pipelined else "single stream") + "; *_clean = detector alone")
         line["roofline"]["other_kernels"] = [roof(r) for r in d["kernels"][1:4]]
-        # live (pipelined) figure vs the committed rocprofv3 summary of the same command: more than 25 % apart -> say so loudly
-        off = []
+        # live figures vs the committed rocprofv3 summary of the same command. rocprofv3 times a dispatch from its first
+        # workgroup's start to its last one's end; an event pair on the stream also contains the time a launch WAITS for CUs —
+        # in the two-stream arrangement the detector's first small launches queue behind NLM's workgroups (3 x 48.5 KB of LDS
+        # per CU leave no room for a conv workgroup), so their pipelined figure is wait + run while `clean` is run only. A
+        # kernel is a violation when NEITHER live figure is within 25 % of the profile; `queued` lists the kernels whose
+        # pipelined figure is > 1.5 x the clean one (contention, not kernel time)
+        off, queued = [], []
         for r in [line["roofline"]] + line["roofline"]["other_kernels"]:
             ref = r.get("rocprof_avg_launch_ms")
-            if ref and abs(r["avg_launch_ms"] - ref) > 0.25 * ref:
-                off.append({"kernel": r["kernel"], "live_ms": r["avg_launch_ms"], "rocprof_ms": ref, "source": r["rocprof_source"]})
-        line["consistency"] = {"ok": not off, "rule": "live pipelined avg launch vs committed rocprofv3 avg, within 25 %",
-                               "violations": off}
+            if r["avg_launch_ms"] > 1.5 * r["avg_launch_ms_clean"]:
+                queued.append({"kernel": r["kernel"], "pipelined_ms": r["avg_launch_ms"], "clean_ms": r["avg_launch_ms_clean"]})
+            if ref and min(abs(r["avg_launch_ms"] - ref), abs(r["avg_launch_ms_clean"] - ref)) > 0.25 * ref:
+                off.append({"kernel": r["kernel"], "pipelined_ms": r["avg_launch_ms"], "clean_ms": r["avg_launch_ms_clean"],
+                            "rocprof_ms": ref, "source": r["rocprof_source"]})
+        line["consistency"] = {"ok": not off, "rule": "a live avg launch (pipelined or clean) within 25 % of the committed rocprofv3 avg",
+                               "violations": off, "queued_behind_isp": queued}
         if off:
             print(f"[bench] CONSISTENCY: live per-kernel timings differ from the committed rocprofv3 summary by > 25 %: {off}",
                   file=sys.stderr)

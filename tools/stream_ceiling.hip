@@ -1,0 +1,130 @@
+// Streaming ceiling of THIS pool's MI355X for the ISP kernels' traffic pattern: our own float4 copy
+// kernels on rotating buffer sets larger than the 256 MB Infinity Cache, next to hipMemcpyAsync (the vendor's copy).
+// Build: hipcc --offload-arch=gfx950 -O3 -o build/stream_ceiling tools/stream_ceiling.hip ; run on the GPU box.
+// Every figure: bytes read + bytes written per launch / average launch time over `reps` launches bracketed by one event pair.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); exit(1); } } while (0)
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+template <int UNROLL, int LDNT, int STNT>
+__global__ __launch_bounds__(256) void k_copy(const f4* __restrict__ in, f4* __restrict__ out, long n4) {
+    const long stride = (long)gridDim.x * 256;
+    long i = (long)blockIdx.x * 256 + threadIdx.x;
+    for (; i + (UNROLL - 1) * stride < n4; i += UNROLL * stride) {
+        f4 v[UNROLL];
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) v[u] = LDNT ? __builtin_nontemporal_load(in + i + u * stride) : in[i + u * stride];
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) {
+            v[u] *= 1.0001f;
+            if (STNT) __builtin_nontemporal_store(v[u], out + i + u * stride); else out[i + u * stride] = v[u];
+        }
+    }
+    for (; i < n4; i += stride) out[i] = in[i] * 1.0001f;
+}
+
+// contiguous chunk per workgroup (each workgroup streams one contiguous range front to back, UNROLL x 4 KB in flight)
+template <int UNROLL, int STNT>
+__global__ __launch_bounds__(256) void k_copy_chunk(const f4* __restrict__ in, f4* __restrict__ out, long n4, long per_wg) {
+    const long lo = (long)blockIdx.x * per_wg, hi = lo + per_wg < n4 ? lo + per_wg : n4;
+    for (long i = lo + threadIdx.x; i < hi; i += UNROLL * 256) {
+        f4 v[UNROLL];
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) if (i + u * 256 < hi) v[u] = in[i + u * 256];
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) if (i + u * 256 < hi) {
+            v[u] *= 1.0001f;
+            if (STNT) __builtin_nontemporal_store(v[u], out + i + u * 256); else out[i + u * 256] = v[u];
+        }
+    }
+}
+
+// the fused-pooling walk: one WAVE = a strip of <= 256 px x `rows` image rows of the three planes of one image; R rows in flight
+template <int R, int STNT>
+__global__ __launch_bounds__(64) void k_walk(const float* __restrict__ in, float* __restrict__ out, int H, int W, int rows, int strip_px) {
+    const int strips = (W + strip_px - 1) / strip_px;
+    const int sx = blockIdx.x % strips, ry = blockIdx.x / strips, b = blockIdx.y;
+    const long plane = (long)H * W;
+    const float* ip = in + (long)b * 3 * plane;
+    float* op = out + (long)b * 3 * plane;
+    const int x = sx * strip_px + 4 * threadIdx.x;
+    const bool act = 4 * threadIdx.x < strip_px && x < W;
+    const int y0 = ry * rows, y1 = y0 + rows < H ? y0 + rows : H;
+    f4 acc = {0, 0, 0, 0};
+    for (int y = y0; y < y1; y += R) {
+        f4 v[R][3];
+#pragma unroll
+        for (int u = 0; u < R; ++u)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const int yy = y + u < y1 ? y + u : y1 - 1;
+                v[u][c] = *reinterpret_cast<const f4*>(ip + c * plane + (long)yy * W + (act ? x : 0));
+            }
+#pragma unroll
+        for (int u = 0; u < R; ++u)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) if (act && y + u < y1) {
+                v[u][c] *= 1.0001f;
+                acc += v[u][c];
+                f4* d = reinterpret_cast<f4*>(op + c * plane + (long)(y + u) * W + x);
+                if (STNT) __builtin_nontemporal_store(v[u][c], d); else *d = v[u][c];
+            }
+    }
+    if (acc.x == 123.456f) out[0] = acc.y;
+}
+
+static std::vector<float*> ins, outs;
+static hipEvent_t e0, e1;
+
+template <class F>
+static double timed(F f, int reps, int nsets) {
+    for (int k = 0; k < nsets; ++k) f(ins[k], outs[k]);
+    CHECK(hipDeviceSynchronize());
+    CHECK(hipEventRecord(e0));
+    for (int i = 0; i < reps; ++i) f(ins[i % nsets], outs[i % nsets]);
+    CHECK(hipEventRecord(e1));
+    CHECK(hipEventSynchronize(e1));
+    float ms;
+    CHECK(hipEventElapsedTime(&ms, e0, e1));
+    return ms / reps;
+}
+
+int main(int argc, char** argv) {
+    const int B = 8, H = 720, W = 1280;
+    const long n = (long)B * 3 * H * W, bytes = n * 4;
+    const int maxsets = 6;                                      // 6 x (88.5 + 88.5) MB = 1.06 GB
+    for (int k = 0; k < maxsets; ++k) {
+        float *a, *b;
+        CHECK(hipMalloc(&a, bytes)); CHECK(hipMalloc(&b, bytes));
+        CHECK(hipMemset(a, 0x3c, bytes)); CHECK(hipMemset(b, 0, bytes));
+        ins.push_back(a); outs.push_back(b);
+    }
+    CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+    const double gb = 2.0 * bytes / 1e9;
+    printf("# config 2 tensor: %d x 3 x %d x %d fp32 = %.1f MB read + %.1f MB written per launch; TB/s = (read + written) / time\n", B, H, W, bytes / 1e6, bytes / 1e6);
+    for (int nsets : {1, 3, 6}) {
+        const int reps = 30;
+        printf("## rotating over %d buffer pair(s) = %.0f MB touched per cycle (Infinity Cache: 256 MB)\n", nsets, nsets * 2.0 * bytes / 1e6);
+        double ms = timed([&](float* a, float* b) { CHECK(hipMemcpyAsync(b, a, bytes, hipMemcpyDeviceToDevice, 0)); }, reps, nsets);
+        printf("hipMemcpyAsync D2D                                   %7.1f us  %5.2f TB/s\n", ms * 1e3, gb / ms);
+#define RUN_COPY(U, L, S, G) { double m = timed([&](float* a, float* b) { hipLaunchKernelGGL((k_copy<U, L, S>), dim3(G), dim3(256), 0, 0, (const f4*)a, (f4*)b, n / 4); }, reps, nsets); \
+        printf("k_copy grid-stride unroll %d ld %-5s st %-5s grid %6d  %7.1f us  %5.2f TB/s\n", U, L ? "nt" : "plain", S ? "nt" : "plain", G, m * 1e3, gb / m); }
+        for (int g : {2048, 4096, 8192, 16384}) { RUN_COPY(2, 0, 0, g) RUN_COPY(2, 0, 1, g) RUN_COPY(2, 1, 1, g) }
+        for (int g : {1024, 2048, 4096, 8192}) { RUN_COPY(4, 0, 1, g) RUN_COPY(8, 0, 1, g) }
+        RUN_COPY(1, 0, 1, 21600) RUN_COPY(1, 0, 0, 21600) RUN_COPY(4, 1, 1, 2048) RUN_COPY(4, 1, 1, 4096)
+#define RUN_CHUNK(U, S, G) { long per = ((n / 4 + G - 1) / G + 255) / 256 * 256; double m = timed([&](float* a, float* b) { hipLaunchKernelGGL((k_copy_chunk<U, S>), dim3(G), dim3(256), 0, 0, (const f4*)a, (f4*)b, n / 4, per); }, reps, nsets); \
+        printf("k_copy_chunk contiguous per wg unroll %d st %-5s grid %5d  %7.1f us  %5.2f TB/s\n", U, S ? "nt" : "plain", G, m * 1e3, gb / m); }
+        for (int g : {512, 1024, 2048, 4096}) { RUN_CHUNK(4, 1, g) RUN_CHUNK(8, 1, g) }
+#define RUN_WALK(R, S, ROWS, SP) { int strips = (W + SP - 1) / SP, rg = (H + ROWS - 1) / ROWS; double m = timed([&](float* a, float* b) { hipLaunchKernelGGL((k_walk<R, S>), dim3(strips * rg, B), dim3(64), 0, 0, a, b, H, W, ROWS, SP); }, reps, nsets); \
+        printf("k_walk wave = %3d px x %3d rows, %d rows in flight st %-5s (%5d waves)  %7.1f us  %5.2f TB/s\n", SP, ROWS, R, S ? "nt" : "plain", strips * rg * B, m * 1e3, gb / m); }
+        RUN_WALK(4, 0, 12, 220) RUN_WALK(4, 1, 12, 220) RUN_WALK(2, 1, 12, 220) RUN_WALK(1, 1, 12, 220) RUN_WALK(4, 1, 12, 256) RUN_WALK(2, 1, 12, 256)
+        RUN_WALK(4, 1, 45, 256) RUN_WALK(2, 1, 45, 256) RUN_WALK(1, 1, 45, 256) RUN_WALK(2, 1, 24, 256) RUN_WALK(2, 1, 6, 256) RUN_WALK(2, 1, 45, 128) RUN_WALK(4, 1, 45, 128)
+        RUN_WALK(2, 1, 90, 256) RUN_WALK(4, 1, 90, 256) RUN_WALK(2, 0, 45, 256)
+    }
+    return 0;
+}
