@@ -8,6 +8,10 @@
 // Reference: isp/sharpen.py:105-142 (adjust_sharpness), :145-182 (sharpness), :63-102 (unsharp_mask).
 #include "isp_internal.h"
 
+#ifndef ISP_CONV_NT_LD
+#define ISP_CONV_NT_LD 0
+#endif
+
 namespace adaisp {
 namespace {
 
@@ -179,7 +183,11 @@ __device__ __forceinline__ void issue_row(const float* __restrict__ src, int y, 
     r.c = make_float4(0.f, 0.f, 0.f, 0.f);
     r.e0 = 0.f; r.e1 = 0.f;
     if (active && row_ok) {
+#if ISP_CONV_NT_LD
+        r.c = ld4_nt(reinterpret_cast<const float4*>(rowp + gx));
+#else
         r.c = *reinterpret_cast<const float4*>(rowp + gx);
+#endif
         if (edge_l) {
             if (MODE == kUSM) { r.e0 = rowp[reflect(gx - 2, W)]; r.e1 = rowp[reflect(gx - 1, W)]; }
             else if (gx > 0) r.e1 = rowp[gx - 1];
@@ -212,12 +220,14 @@ __device__ __forceinline__ void finish_row(const RawRow& r, bool active, bool ed
 
 // The walk itself. The wave's lanes cover pixels gx = x_first + 4 * lane < x_read_end of plane `src`; output rows
 // [y_begin, y_end) are computed, rows < y_store_end and pixels < x_store_end are stored (the fused-pooling cut computes
-// the row / quad it shares with the next pool window without storing it). `colsum` accumulates the lane's four output
+// the row / quad it shares with the next pool window without storing it; a walk over TWO pool windows passes the first
+// window's end, the second one's begin and `colsum2` — a row inside both adds to both). `colsum` accumulates the lane's four output
 // columns over the computed rows, ascending y from its initial value (the pooled planes' column sums).
 template <int R, int MODE, int NG>
 __device__ void conv_rows_core(const float* __restrict__ src, float* __restrict__ dst, const float* __restrict__ p, int H,
                                int W, int x_first, int x_read_end, int x_store_end, int y_begin, int y_end,
-                               int y_store_end, float (&colsum)[4]) {
+                               int y_store_end, float (&colsum)[4], int y_first_end = 1 << 30, int y_second_begin = 1 << 30,
+                               float* colsum2 = nullptr) {
     constexpr int G = 2 * R + 1, GS = G * NG;        // ring period, rows per pipeline group
     const int lane = threadIdx.x & 63;
     const int gx = x_first + 4 * lane;
@@ -296,8 +306,11 @@ __device__ void conv_rows_core(const float* __restrict__ src, float* __restrict_
             }
             if (y < y_end) {
 #pragma unroll
-                for (int k = 0; k < 4; ++k) colsum[k] += o[k];
-                if (store_x && y < y_store_end) *reinterpret_cast<float4*>(dst + (long)y * W + gx) = make_float4(o[0], o[1], o[2], o[3]);
+                for (int k = 0; k < 4; ++k) {
+                    if (y < y_first_end) colsum[k] += o[k];
+                    if (y >= y_second_begin) colsum2[k] += o[k];
+                }
+                if (store_x && y < y_store_end) st4(reinterpret_cast<float4*>(dst + (long)y * W + gx), make_float4(o[0], o[1], o[2], o[3]));
             }
         }
 #pragma unroll
@@ -337,40 +350,54 @@ __global__ __launch_bounds__(kThreads) void k_conv_rows(const float* __restrict_
     else conv_rows<1, kSharpness, NG>(img + off, out + off, p, H, W, c, strip, band, rs);
 }
 
-// The same walk cut along the pool windows, with the next step's 64x64 pooling fused (isp_internal.h: PoolGeom): a wave =
-// one strip of pool columns x one pool row x one plane; workgroup = the strips of (pool row, plane).
-template <int R>
-__global__ __launch_bounds__(1024) void k_conv_rows_pool(const float* __restrict__ img, float* __restrict__ out,
-                                                         float* __restrict__ pooled, const int32_t* __restrict__ ids,
-                                                         int uniform_op, const float* __restrict__ params, int pstride,
-                                                         int H, int W, int cps) {
-    extern __shared__ __attribute__((aligned(16))) float colsum_lds[];   // [waves][256]
+// The same walk cut along the pool windows, with the next step's 64x64 pooling fused: workgroup = (pool row, plane) over
+// the whole width, wave w = the 256-pixel strip [256 w, 256 w + 256) — line-aligned like the pointwise family's cut
+// (isp_pointwise.hip; round 3 cut along the pool columns: 220-px strips whose edge lines two waves fetched) — or, beyond
+// 2048 px, strips w, w + 8, ... The lane's four output columns are summed down the window's rows (ascending y from 0.0f),
+// go to LDS ([W] floats) and thread ox adds its pool cell's columns in ascending x: k_pool64's order, bit-identical.
+// NW = pool windows per wave: with two, the 2R halo rows and the pipeline's head are paid once per ~22 rows instead of once
+// per ~11 (reads 1.13 x the plane instead of 1.24 x at 720 rows): 8x720x1280 sharpen 46.1 -> 44.3 us, USM 62.3 -> 54.3; at
+// 2160 rows a window is already 34 rows tall and two per wave leave too few, too long waves (4x2160x3840: 164 -> 201 us), so
+// the launcher takes two only while a window is shorter than 16 rows (tools/isp_step_ab.py, profiles/round4_isp_step_ab.txt).
+constexpr int kPoolWaves = 8;
+template <int R, int NW>
+__global__ __launch_bounds__(64 * kPoolWaves) void k_conv_rows_pool(const float* __restrict__ img, float* __restrict__ out,
+                                                                    float* __restrict__ pooled, const int32_t* __restrict__ ids,
+                                                                    int uniform_op, const float* __restrict__ params, int pstride,
+                                                                    int H, int W) {
+    extern __shared__ __attribute__((aligned(16))) float colsum_lds[];   // [NW][256 x strips]
     const int b = blockIdx.z;
     const int op = ids ? ids[b] : uniform_op;
     if (R == 1 && op != ADAISP_OP_SHARPEN && op != ADAISP_OP_SHARPEN_V2) return;
     if (R == 2 && op != ADAISP_OP_USM) return;
-    const int oy = blockIdx.x, c = blockIdx.y;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int oy = blockIdx.x * NW, c = blockIdx.y;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nwaves = (int)blockDim.x >> 6;
+    const int strips = (W + 255) >> 8, Wp = strips << 8;
     const long plane = (long)H * W;
     const float* src = img + ((long)b * 3 + c) * plane;
     float* dst = out + ((long)b * 3 + c) * plane;
     const float* p = params + (long)b * pstride;
-    const int ys = win_lo(oy, H), ye = win_hi(oy, H), y_own_end = oy == 63 ? H : win_lo(oy + 1, H);
-    const int x_lo = strip_x_lo(wave, cps, W), x_end = strip_x_end(wave, cps, W), x_own_end = strip_x_lo(wave + 1, cps, W);
-    float acc[4] = {0.f, 0.f, 0.f, 0.f};
-    if (R == 2) conv_rows_core<2, kUSM, 1>(src, dst, p, H, W, x_lo, x_end, x_own_end, ys, ye, y_own_end, acc);
-    else if (op == ADAISP_OP_SHARPEN) conv_rows_core<1, kAdjust, 1>(src, dst, p, H, W, x_lo, x_end, x_own_end, ys, ye, y_own_end, acc);
-    else conv_rows_core<1, kSharpness, 1>(src, dst, p, H, W, x_lo, x_end, x_own_end, ys, ye, y_own_end, acc);
-    float* cs = colsum_lds + wave * 256;
-    *reinterpret_cast<float4*>(cs + 4 * lane) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    const int oy_last = min(oy + NW - 1, 63);
+    const int ys = win_lo(oy, H), ye = win_hi(oy_last, H), y_own_end = oy_last == 63 ? H : win_lo(oy_last + 1, H);
+    const int y_first_end = win_hi(oy, H), y_second_begin = NW > 1 && oy + 1 <= 63 ? win_lo(oy + 1, H) : (1 << 30);
+    for (int sw = wave; sw < strips; sw += nwaves) {
+        const int x_lo = 256 * sw, x_end = min(W, x_lo + 256);
+        float acc[4] = {0.f, 0.f, 0.f, 0.f}, acc2[4] = {0.f, 0.f, 0.f, 0.f};
+        if (R == 2) conv_rows_core<2, kUSM, 1>(src, dst, p, H, W, x_lo, x_end, x_end, ys, ye, y_own_end, acc, y_first_end, y_second_begin, acc2);
+        else if (op == ADAISP_OP_SHARPEN) conv_rows_core<1, kAdjust, 1>(src, dst, p, H, W, x_lo, x_end, x_end, ys, ye, y_own_end, acc, y_first_end, y_second_begin, acc2);
+        else conv_rows_core<1, kSharpness, 1>(src, dst, p, H, W, x_lo, x_end, x_end, ys, ye, y_own_end, acc, y_first_end, y_second_begin, acc2);
+        *reinterpret_cast<float4*>(colsum_lds + x_lo + 4 * lane) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+        if (NW > 1) *reinterpret_cast<float4*>(colsum_lds + Wp + x_lo + 4 * lane) = make_float4(acc2[0], acc2[1], acc2[2], acc2[3]);
+    }
     __syncthreads();
-    const int c0 = strip_cell0(wave, cps), ncell = strip_cell0(wave + 1, cps) - c0;
-    if (lane < ncell) {
-        const int ox = c0 + lane;
+    for (int i = threadIdx.x; i < 64 * NW; i += blockDim.x) {
+        const int ox = i & 63, w = i >> 6, oyw = oy + w;
+        if (oyw > 63) break;
         const int xs = win_lo(ox, W), xe = win_hi(ox, W);
+        const float* col = colsum_lds + w * Wp;
         float a = 0.f;
-        for (int xx = xs; xx < xe; ++xx) a += cs[xx - x_lo];
-        pooled[(((long)b * 3 + c) * 64 + oy) * 64 + ox] = a / (float)(ye - ys) / (float)(xe - xs);
+        for (int xx = xs; xx < xe; ++xx) a += col[xx];
+        pooled[(((long)b * 3 + c) * 64 + oyw) * 64 + ox] = a / (float)(win_hi(oyw, H) - win_lo(oyw, H)) / (float)(xe - xs);
     }
 }
 
@@ -396,14 +423,16 @@ __global__ __launch_bounds__(kThreads) void k_conv(const float* __restrict__ img
 hipError_t launch_conv_pool(const Batch& a, float* pooled, const PoolGeom& g, hipStream_t s) {
     const bool want3 = a.ids ? true : (a.uniform_op == ADAISP_OP_SHARPEN || a.uniform_op == ADAISP_OP_SHARPEN_V2);
     const bool want5 = a.ids ? !(a.flags & ADAISP_NO_USM) : (a.uniform_op == ADAISP_OP_USM);
-    const dim3 grid(64, 3, a.B), block(64 * g.strips);
-    const size_t smem = (size_t)g.strips * 256 * sizeof(float);
-    if (want3)
-        hipLaunchKernelGGL(k_conv_rows_pool<1>, grid, block, smem, s, a.img, a.out, pooled, a.ids, a.uniform_op, a.params,
-                           a.pstride, a.H, a.W, g.cps);
-    if (want5)
-        hipLaunchKernelGGL(k_conv_rows_pool<2>, grid, block, smem, s, a.img, a.out, pooled, a.ids, a.uniform_op, a.params,
-                           a.pstride, a.H, a.W, g.cps);
+    (void)g;
+    const int strips = (a.W + 255) / 256;
+    const int nw = a.H < 16 * 64 ? 2 : 1;
+    const dim3 grid((64 + nw - 1) / nw, 3, a.B), block(64 * (strips < kPoolWaves ? strips : kPoolWaves));
+    const size_t smem = (size_t)nw * strips * 256 * sizeof(float);
+#define CONV_POOL_LAUNCH(R, NW) hipLaunchKernelGGL((k_conv_rows_pool<R, NW>), grid, block, smem, s, a.img, a.out, pooled, a.ids, \
+                                                   a.uniform_op, a.params, a.pstride, a.H, a.W)
+    if (want3) { if (nw == 2) CONV_POOL_LAUNCH(1, 2); else CONV_POOL_LAUNCH(1, 1); }
+    if (want5) { if (nw == 2) CONV_POOL_LAUNCH(2, 2); else CONV_POOL_LAUNCH(2, 1); }
+#undef CONV_POOL_LAUNCH
     return hipGetLastError();
 }
 

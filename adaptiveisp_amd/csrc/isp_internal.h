@@ -53,7 +53,8 @@ __host__ __device__ inline int strip_x_end(int s, int cps, int W) {             
 }
 inline PoolGeom pool_geom(int H, int W, const void* img, const void* out) {
     PoolGeom g{0, 0, false};
-    if (H < 64 || W < 64 || (W & 3) || (reinterpret_cast<uintptr_t>(img) & 15) || (reinterpret_cast<uintptr_t>(out) & 15))
+    // W <= 8192: the pointwise family keeps a whole row's column sums in LDS (3 x W floats, isp_pointwise.hip)
+    if (H < 64 || W < 64 || W > 8192 || (W & 3) || (reinterpret_cast<uintptr_t>(img) & 15) || (reinterpret_cast<uintptr_t>(out) & 15))
         return g;
     for (int strips = 1; strips <= 16; ++strips) {
         const int cps = (64 + strips - 1) / strips;
@@ -97,5 +98,36 @@ struct Clip {
 };
 
 __device__ __forceinline__ float clamp01(float v) { return fminf(fmaxf(v, 0.0f), 1.0f); }
+
+// Streaming access policy (tools/stream_ceiling.hip, profiles/round4_stream_ceiling.txt): on tensors that do not stay in the
+// 256 MB Infinity Cache a grid-stride float4 copy moves 6.2 TB/s with non-temporal loads AND stores, 5.6 with plain loads +
+// non-temporal stores, 5.2-5.4 with plain / plain (the vendor's copy: 5.1-5.2). Every pixel of the pointwise filters is read
+// once and written once: ld4 / st4. The stencil filters re-read halo rows that a neighbouring wave fetched moments ago (L2
+// hits with plain loads): they use st4 and plain loads (ISP_CONV_NT_LD measures the other choice).
+#ifndef ISP_NT_LD
+#define ISP_NT_LD 1
+#endif
+#ifndef ISP_NT_ST
+#define ISP_NT_ST 1
+#endif
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 ld4_nt(const float4* p) {
+    const f32x4_t v = __builtin_nontemporal_load(reinterpret_cast<const f32x4_t*>(p));
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ float4 ld4(const float4* p) {
+#if ISP_NT_LD
+    return ld4_nt(p);
+#else
+    return *p;
+#endif
+}
+__device__ __forceinline__ void st4(float4* p, const float4& v) {
+#if ISP_NT_ST
+    __builtin_nontemporal_store(f32x4_t{v.x, v.y, v.z, v.w}, reinterpret_cast<f32x4_t*>(p));
+#else
+    *p = v;
+#endif
+}
 
 }  // namespace adaisp

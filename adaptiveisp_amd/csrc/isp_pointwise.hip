@@ -77,40 +77,76 @@ struct OpCCM {  // isp/filters.py:703-708,666-672   rows normalised by their sum
     }
 };
 
-// 8-segment piecewise-linear curve: acc += clamp(v - i/8, 0, 1/8) * p_i in segment order, then * 8/sum.
-__device__ __forceinline__ float curve8(float v, const float* c, float scale) {
-    float acc = v * 0.0f;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) acc += fminf(fmaxf(v - 0.125f * (float)i, 0.0f), 0.125f) * c[i];
-    return acc * scale;
+// 8-segment piecewise-linear curve (isp/filters.py:293-303,337-347): acc = v * 0; acc += clamp(v - i/8, 0, 1/8) * p_i for
+// i = 0..7 in order; result acc * 8 / sum(p). For v in segment j the terms i < j are exactly p_i / 8 (a power-of-two scaling),
+// the terms i > j are +0 and leave the running sum unchanged, so the reference's eight-term fp32 sum equals
+//     P_j + clamp(v - j/8, 0, 1/8) * p_j,      P_j = ((p_0/8 + p_1/8) + ...) + p_{j-1}/8  in the same order  (P_0 = +0)
+// bit for bit; `+ v * 0.0f` keeps the reference's NaN for a non-finite v (inf * 0) and changes nothing else. (P_j, p_j, j/8)
+// is an 8-entry table per curve in LDS, one ds_read_b128 per value: ~10 VALU instead of ~34 per curve evaluation — the
+// fused-pooling walk has too few waves to hide the difference (T 39 -> see profiles/round4_isp_step_ab.txt).
+struct CurveTable {
+    const float4* t;        // [8] in LDS: {P_j, p_j, j/8, -}
+    float scale;
+    __device__ __forceinline__ float eval(float v) const {
+        int j = __float2int_rd(v * 8.0f);
+        j = min(max(j, 0), 7);
+        const float4 e = t[j];
+        const float tj = fminf(fmaxf(v - e.z, 0.0f), 0.125f) * e.y;
+        return ((e.x + tj) + v * 0.0f) * scale;
+    }
+};
+// entry j of the table of the curve whose eight parameters are c[0..7] (stride `cs` floats)
+__device__ __forceinline__ float4 curve_entry(const float* c, int cs, int j) {
+    float P = 0.0f;
+    for (int i = 0; i < j; ++i) P = (i == 0) ? 0.125f * c[0] : P + 0.125f * c[i * cs];
+    return make_float4(P, c[j * cs], 0.125f * (float)j, 0.0f);
 }
 
 struct OpTone {  // isp/filters.py:337-347
-    float c[8], scale;
-    __device__ void init(const float* p) {
+    static constexpr int kCurves = 1;
+    CurveTable tab;
+    __device__ void init(const float* p, float4* lds) {
+        if (threadIdx.x < 8) lds[threadIdx.x] = curve_entry(p, 1, threadIdx.x);
         float s = 0.0f;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) { c[i] = p[i]; s += p[i]; }
-        scale = 8.0f / (s + 1e-30f);
+        for (int i = 0; i < 8; ++i) s += p[i];
+        tab.t = lds;
+        tab.scale = 8.0f / (s + 1e-30f);
     }
     __device__ __forceinline__ void apply(float& r, float& g, float& b) const {
-        r = curve8(r, c, scale); g = curve8(g, c, scale); b = curve8(b, c, scale);
+        r = tab.eval(r); g = tab.eval(g); b = tab.eval(b);
     }
 };
 
 struct OpColor {  // isp/filters.py:293-303   per-channel curves, params laid out [step][channel]
-    float c[3][8], scale[3];
-    __device__ void init(const float* p) {
+    static constexpr int kCurves = 3;
+    CurveTable tab[3];
+    __device__ void init(const float* p, float4* lds) {
+        if (threadIdx.x < 24) lds[threadIdx.x] = curve_entry(p + (threadIdx.x >> 3), 3, threadIdx.x & 7);
 #pragma unroll
         for (int ch = 0; ch < 3; ++ch) {
             float s = 0.0f;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) { c[ch][i] = p[3 * i + ch]; s += p[3 * i + ch]; }
-            scale[ch] = 8.0f / (s + 1e-30f);
+            for (int i = 0; i < 8; ++i) s += p[3 * i + ch];
+            tab[ch].t = lds + 8 * ch;
+            tab[ch].scale = 8.0f / (s + 1e-30f);
         }
     }
     __device__ __forceinline__ void apply(float& r, float& g, float& b) const {
-        r = curve8(r, c[0], scale[0]); g = curve8(g, c[1], scale[1]); b = curve8(b, c[2], scale[2]);
+        r = tab[0].eval(r); g = tab[1].eval(g); b = tab[2].eval(b);
+    }
+};
+
+// ops with a table in LDS build it cooperatively (the op is block-uniform: every thread of the workgroup is here) and meet
+// at one barrier; the others only read their parameters
+template <class OP, class = void> struct OpSetup {
+    static __device__ __forceinline__ void run(OP& op, const float* p) { op.init(p); }
+};
+template <class OP> struct OpSetup<OP, decltype((void)OP::kCurves)> {
+    static __device__ __forceinline__ void run(OP& op, const float* p) {
+        __shared__ float4 curve_lds[8 * OP::kCurves];
+        op.init(p, curve_lds);
+        __syncthreads();
     }
 };
 
@@ -208,7 +244,7 @@ template <class OP>
 __device__ void stream_vec(const float* __restrict__ in, float* __restrict__ out, const float* __restrict__ p,
                            long plane, const Clip clip) {
     OP op;
-    op.init(p);
+    OpSetup<OP>::run(op, p);
     const long n4 = plane >> 2;
     const float4* __restrict__ ir = reinterpret_cast<const float4*>(in);
     const float4* __restrict__ ig = reinterpret_cast<const float4*>(in + plane);
@@ -219,17 +255,17 @@ __device__ void stream_vec(const float* __restrict__ in, float* __restrict__ out
     const long stride = (long)gridDim.x * kThreads;
     long i = (long)blockIdx.x * kThreads + threadIdx.x;
     for (; i + stride < n4; i += 2 * stride) {
-        float4 r0 = ir[i], g0 = ig[i], b0 = ib[i];
-        float4 r1 = ir[i + stride], g1 = ig[i + stride], b1 = ib[i + stride];
+        float4 r0 = ld4(ir + i), g0 = ld4(ig + i), b0 = ld4(ib + i);
+        float4 r1 = ld4(ir + i + stride), g1 = ld4(ig + i + stride), b1 = ld4(ib + i + stride);
         apply4(op, r0, g0, b0, clip);
         apply4(op, r1, g1, b1, clip);
-        orr[i] = r0; og[i] = g0; ob[i] = b0;
-        orr[i + stride] = r1; og[i + stride] = g1; ob[i + stride] = b1;
+        st4(orr + i, r0); st4(og + i, g0); st4(ob + i, b0);
+        st4(orr + i + stride, r1); st4(og + i + stride, g1); st4(ob + i + stride, b1);
     }
     for (; i < n4; i += stride) {
-        float4 r0 = ir[i], g0 = ig[i], b0 = ib[i];
+        float4 r0 = ld4(ir + i), g0 = ld4(ig + i), b0 = ld4(ib + i);
         apply4(op, r0, g0, b0, clip);
-        orr[i] = r0; og[i] = g0; ob[i] = b0;
+        st4(orr + i, r0); st4(og + i, g0); st4(ob + i, b0);
     }
 }
 
@@ -237,7 +273,7 @@ template <class OP>
 __device__ void stream_scalar(const float* __restrict__ in, float* __restrict__ out, const float* __restrict__ p,
                               long plane, const Clip clip) {
     OP op;
-    op.init(p);
+    OpSetup<OP>::run(op, p);
     const long stride = (long)gridDim.x * kThreads;
     for (long i = (long)blockIdx.x * kThreads + threadIdx.x; i < plane; i += stride) {
         float r = in[i], g = in[i + plane], b = in[i + 2 * plane];
@@ -281,27 +317,42 @@ __global__ __launch_bounds__(kThreads) void k_pointwise(const float* __restrict_
 }
 
 // ---- the same ops with the next step's 64x64 pooling fused (agent.py:97 applied to this step's output) ---------
-// One wave = one strip of pool columns x one pool row (isp_internal.h: PoolGeom); the lane owns a pixel quad and walks
-// the window's rows, four rows (12 x 16-B loads) in flight; the three planes' column sums stay in registers.
+// Workgroup = one pool row `oy` (image rows win_lo(oy,H) .. win_hi(oy,H)) over the WHOLE width; wave w owns the 256-pixel
+// strip [256 w, 256 w + 256) — 1 KB per plane row, aligned to the 128-byte line whenever the row pitch is, so that no line
+// is fetched by two waves (round 3 cut the strips along the pool columns: 220 px = 6.9 lines, the edge lines were read
+// twice and the strips' non-temporal loads would have fetched them twice from HBM). A lane owns a pixel quad and walks the
+// window's rows, ISP_POOL_ROWS rows (x 3 planes x 16 B) in flight; the three planes' column sums stay in registers, go to
+// LDS ([3][W] floats), and after one barrier thread (c, ox) adds its pool cell's columns in ascending x — the order of
+// k_pool64 (column sums down the rows from 0.0f, then the x-window from 0.0f, / kh / kw): bit-identical results. A row that
+// belongs to two windows is read (and computed) by both owners and written by the first.
+#ifndef ISP_POOL_ROWS
+#define ISP_POOL_ROWS 3
+#endif
+#ifndef ISP_POOL_PIPE
+#define ISP_POOL_PIPE 0
+#endif
 template <class OP>
-__device__ __forceinline__ void stream_pool(const float* __restrict__ in, float* __restrict__ out,
-                                            const float* __restrict__ p, int H, int W, int ys, int ye, int y_own_end,
-                                            int x, bool active, bool own_x, const Clip clip, float4 (&acc)[3]) {
-    OP op;
-    op.init(p);
+__device__ __forceinline__ void stream_pool(const OP& op, const float* __restrict__ in, float* __restrict__ out,
+                                            int H, int W, int ys, int ye, int y_own_end,
+                                            int x, bool active, const Clip clip, float4 (&acc)[3]) {
+    constexpr int R = ISP_POOL_ROWS;
     const long plane = (long)H * W;
-    const int xs = active ? x : 0;                      // inactive lanes read a valid quad and drop it
-    for (int y0 = ys; y0 < ye; y0 += 4) {
-        float4 r[4], g[4], b[4];
+    const int xs = active ? x : 0;                      // inactive lanes (beyond a ragged right edge) read a valid quad and drop it
+    // the loads of the NEXT group of R rows are issued before the current group is computed and stored (two register sets,
+    // the loop body written out for both): a wave always has R x 3 x 16 B in flight behind its arithmetic — the workgroup is
+    // only `W / 256` waves, 2-3 per SIMD at 720p, too few to hide a whole load -> compute -> store round trip in each other
+    auto load = [&](float4 (&r)[R], float4 (&g)[R], float4 (&b)[R], int y0) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < R; ++u) {
             const long o = (long)min(y0 + u, ye - 1) * W + xs;
-            r[u] = *reinterpret_cast<const float4*>(in + o);
-            g[u] = *reinterpret_cast<const float4*>(in + plane + o);
-            b[u] = *reinterpret_cast<const float4*>(in + 2 * plane + o);
+            r[u] = ld4(reinterpret_cast<const float4*>(in + o));
+            g[u] = ld4(reinterpret_cast<const float4*>(in + plane + o));
+            b[u] = ld4(reinterpret_cast<const float4*>(in + 2 * plane + o));
         }
+    };
+    auto work = [&](float4 (&r)[R], float4 (&g)[R], float4 (&b)[R], int y0) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < R; ++u) {
             const int y = y0 + u;
             if (y < ye) {
                 apply4(op, r[u], g[u], b[u], clip);
@@ -309,28 +360,75 @@ __device__ __forceinline__ void stream_pool(const float* __restrict__ in, float*
                     acc[0].x += r[u].x; acc[0].y += r[u].y; acc[0].z += r[u].z; acc[0].w += r[u].w;
                     acc[1].x += g[u].x; acc[1].y += g[u].y; acc[1].z += g[u].z; acc[1].w += g[u].w;
                     acc[2].x += b[u].x; acc[2].y += b[u].y; acc[2].z += b[u].z; acc[2].w += b[u].w;
-                    if (own_x && y < y_own_end) {
+                    if (y < y_own_end) {
                         const long o = (long)y * W + x;
-                        *reinterpret_cast<float4*>(out + o) = r[u];
-                        *reinterpret_cast<float4*>(out + plane + o) = g[u];
-                        *reinterpret_cast<float4*>(out + 2 * plane + o) = b[u];
+                        st4(reinterpret_cast<float4*>(out + o), r[u]);
+                        st4(reinterpret_cast<float4*>(out + plane + o), g[u]);
+                        st4(reinterpret_cast<float4*>(out + 2 * plane + o), b[u]);
                     }
                 }
             }
         }
+    };
+#if ISP_POOL_PIPE
+    float4 ra[R], ga[R], ba[R], rb[R], gb[R], bb[R];
+    load(ra, ga, ba, ys);
+    for (int y0 = ys; y0 < ye; y0 += 2 * R) {
+        if (y0 + R < ye) load(rb, gb, bb, y0 + R);
+        work(ra, ga, ba, y0);
+        if (y0 + R < ye) {
+            if (y0 + 2 * R < ye) load(ra, ga, ba, y0 + 2 * R);
+            work(rb, gb, bb, y0 + R);
+        }
+    }
+#else
+    float4 r[R], g[R], b[R];
+    for (int y0 = ys; y0 < ye; y0 += R) {
+        load(r, g, b, y0);
+        work(r, g, b, y0);
+    }
+#endif
+}
+
+// At most 8 waves per workgroup; rows wider than 2048 px give a wave a second 256-px strip (wave, wave + 8, ...).
+// OPSEL >= 0: the op is a compile-time constant (the host knows it: adaisp_forward_uniform) — no switch, and the register
+// allocation is that op's, not the largest branch's; OPSEL = kOpRuntime: the op is read from the device-side ids.
+constexpr int kPoolWaves = 8;
+constexpr int kOpRuntime = -2;
+#ifndef ISP_POOL_WPE
+#define ISP_POOL_WPE 4          // waves per SIMD the register allocation must allow (4 -> 128 registers per lane)
+#endif
+
+template <class OP>
+__device__ __forceinline__ void pool_strips(const float* __restrict__ in, float* __restrict__ o, const float* __restrict__ p,
+                                            float* __restrict__ colsum, int H, int W, int ys, int ye, int y_own_end,
+                                            const Clip clip) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nwaves = (int)blockDim.x >> 6;
+    const int strips = (W + 255) >> 8, Wp = strips << 8;
+    OP op;
+    OpSetup<OP>::run(op, p);
+    for (int sw = wave; sw < strips; sw += nwaves) {
+        const int x = 256 * sw + 4 * lane;
+        float4 acc[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) acc[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+        stream_pool<OP>(op, in, o, H, W, ys, ye, y_own_end, x, x < W, clip, acc);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) *reinterpret_cast<float4*>(colsum + c * Wp + x) = acc[c];
     }
 }
 
-__global__ __launch_bounds__(1024) void k_pointwise_pool(const float* __restrict__ img, float* __restrict__ out,
-                                                         float* __restrict__ pooled, const int32_t* __restrict__ ids,
-                                                         int uniform_op, const float* __restrict__ params, int pstride,
-                                                         int H, int W, int cps, unsigned flags) {
-    extern __shared__ __attribute__((aligned(16))) float colsum[];      // [waves][3][256]
+template <int OPSEL>
+__global__ __launch_bounds__(64 * kPoolWaves, ISP_POOL_WPE)
+void k_pointwise_pool(const float* __restrict__ img, float* __restrict__ out, float* __restrict__ pooled,
+                      const int32_t* __restrict__ ids, int uniform_op, const float* __restrict__ params, int pstride,
+                      int H, int W, unsigned flags) {
+    extern __shared__ __attribute__((aligned(16))) float colsum[];      // [3][Wp], Wp = 256 x strips
     const int oy = blockIdx.x, b = blockIdx.y;
-    int op = ids ? ids[b] : uniform_op;
+    int op = OPSEL != kOpRuntime ? OPSEL : (ids ? ids[b] : uniform_op);
     if (op_is_conv(op) || op == ADAISP_OP_NLM) return;                   // block-uniform: the whole workgroup leaves
     if (!op_is_pointwise(op)) op = ADAISP_OP_ZERO;                       // unknown id (device data): the zero image, like -1
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int Wp = ((W + 255) >> 8) << 8;
     const long plane = (long)H * W;
     const float* in = img + (long)b * 3 * plane;
     float* o = out + (long)b * 3 * plane;
@@ -338,35 +436,21 @@ __global__ __launch_bounds__(1024) void k_pointwise_pool(const float* __restrict
     const Clip clip((flags & ADAISP_CLIP01) != 0);
     const int ys = win_lo(oy, H), ye = win_hi(oy, H);
     const int y_own_end = oy == 63 ? H : win_lo(oy + 1, H);
-    const int x_lo = strip_x_lo(wave, cps, W), x_end = strip_x_end(wave, cps, W);
-    const int x = x_lo + 4 * lane;
-    const bool active = x < x_end, own_x = x < strip_x_lo(wave + 1, cps, W);
-    float4 acc[3];
-#pragma unroll
-    for (int c = 0; c < 3; ++c) acc[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+#define POOL_CASE(ID, OP) case ID: if (OPSEL == kOpRuntime || OPSEL == ID) pool_strips<OP>(in, o, p, colsum, H, W, ys, ye, y_own_end, clip); break;
     switch (op) {
-        case ADAISP_OP_ZERO:     stream_pool<OpZero>(in, o, p, H, W, ys, ye, y_own_end, x, active, own_x, clip, acc); break;
-        case ADAISP_OP_EXPOSURE: stream_pool<OpExposure>(in, o, p, H, W, ys, ye, y_own_end, x, active, own_x, clip, acc); break;
-        case ADAISP_OP_GAMMA:    stream_pool<OpGamma>(in, o, p, H, W, ys, ye, y_own_end, x, active, own_x, clip, acc); break;
-        case ADAISP_OP_WB:       stream_pool<OpWB>(in, o, p, H, W, ys, ye, y_own_end, x, active, own_x, clip, acc); break;
-        case ADAISP_OP_CCM:      stream_pool<OpCCM>(in, o, p, H, W, ys, ye, y_own_end, x, active, own_x, clip, acc); break;
-        case ADAISP_OP_TONE:     stream_pool<OpTone>(in, o, p, H, W, ys, ye, y_own_end, x, active, own_x, clip, acc); break;
-        case ADAISP_OP_COLOR:    stream_pool<OpColor>(in, o, p, H, W, ys, ye, y_own_end, x, active, own_x, clip, acc); break;
-        case ADAISP_OP_CONTRAST: stream_pool<OpContrast>(in, o, p, H, W, ys, ye, y_own_end, x, active, own_x, clip, acc); break;
-        case ADAISP_OP_WNB:      stream_pool<OpWNB>(in, o, p, H, W, ys, ye, y_own_end, x, active, own_x, clip, acc); break;
-        case ADAISP_OP_SATPLUS:  stream_pool<OpSatPlus>(in, o, p, H, W, ys, ye, y_own_end, x, active, own_x, clip, acc); break;
+        POOL_CASE(ADAISP_OP_ZERO, OpZero) POOL_CASE(ADAISP_OP_EXPOSURE, OpExposure) POOL_CASE(ADAISP_OP_GAMMA, OpGamma)
+        POOL_CASE(ADAISP_OP_WB, OpWB) POOL_CASE(ADAISP_OP_CCM, OpCCM) POOL_CASE(ADAISP_OP_TONE, OpTone)
+        POOL_CASE(ADAISP_OP_COLOR, OpColor) POOL_CASE(ADAISP_OP_CONTRAST, OpContrast) POOL_CASE(ADAISP_OP_WNB, OpWNB)
+        POOL_CASE(ADAISP_OP_SATPLUS, OpSatPlus)
         default: break;
     }
-    float* cs = colsum + wave * 3 * 256;
-#pragma unroll
-    for (int c = 0; c < 3; ++c) *reinterpret_cast<float4*>(cs + c * 256 + 4 * lane) = acc[c];
+#undef POOL_CASE
     __syncthreads();
-    const int c0 = strip_cell0(wave, cps), ncell = strip_cell0(wave + 1, cps) - c0;
     const float kh = (float)(ye - ys);
-    for (int i = lane; i < 3 * ncell; i += 64) {
-        const int c = i / ncell, ox = c0 + (i - c * ncell);
+    for (int i = threadIdx.x; i < 3 * 64; i += blockDim.x) {
+        const int c = i >> 6, ox = i & 63;
         const int xs = win_lo(ox, W), xe = win_hi(ox, W);
-        const float* col = cs + c * 256 - x_lo;
+        const float* col = colsum + c * Wp;
         float a = 0.f;
         for (int xx = xs; xx < xe; ++xx) a += col[xx];
         pooled[(((long)b * 3 + c) * 64 + oy) * 64 + ox] = a / kh / (float)(xe - xs);
@@ -376,8 +460,27 @@ __global__ __launch_bounds__(1024) void k_pointwise_pool(const float* __restrict
 }  // namespace
 
 hipError_t launch_pointwise_pool(const Batch& a, float* pooled, const PoolGeom& g, hipStream_t s) {
-    hipLaunchKernelGGL(k_pointwise_pool, dim3(64, (unsigned)a.B), dim3(64 * g.strips), (size_t)g.strips * 3 * 256 * sizeof(float),
-                       s, a.img, a.out, pooled, a.ids, a.uniform_op, a.params, a.pstride, a.H, a.W, g.cps, a.flags);
+    (void)g;                                                            // (the stencil family's cut; this one's is W / 256)
+    const int strips = (a.W + 255) / 256;
+    const int waves = strips < kPoolWaves ? strips : kPoolWaves;
+    const dim3 grid(64, (unsigned)a.B), block(64 * waves);
+    const size_t smem = (size_t)strips * 3 * 256 * sizeof(float);
+#define POOL_LAUNCH(SEL) hipLaunchKernelGGL(k_pointwise_pool<SEL>, grid, block, smem, s, a.img, a.out, pooled, a.ids, a.uniform_op, \
+                                            a.params, a.pstride, a.H, a.W, a.flags)
+    if (a.ids) POOL_LAUNCH(kOpRuntime);
+    else switch (a.uniform_op) {
+        case ADAISP_OP_EXPOSURE: POOL_LAUNCH(ADAISP_OP_EXPOSURE); break;
+        case ADAISP_OP_GAMMA:    POOL_LAUNCH(ADAISP_OP_GAMMA); break;
+        case ADAISP_OP_WB:       POOL_LAUNCH(ADAISP_OP_WB); break;
+        case ADAISP_OP_CCM:      POOL_LAUNCH(ADAISP_OP_CCM); break;
+        case ADAISP_OP_TONE:     POOL_LAUNCH(ADAISP_OP_TONE); break;
+        case ADAISP_OP_COLOR:    POOL_LAUNCH(ADAISP_OP_COLOR); break;
+        case ADAISP_OP_CONTRAST: POOL_LAUNCH(ADAISP_OP_CONTRAST); break;
+        case ADAISP_OP_WNB:      POOL_LAUNCH(ADAISP_OP_WNB); break;
+        case ADAISP_OP_SATPLUS:  POOL_LAUNCH(ADAISP_OP_SATPLUS); break;
+        default:                 POOL_LAUNCH(kOpRuntime); break;         // ZERO and everything the kernel maps to it
+    }
+#undef POOL_LAUNCH
     return hipGetLastError();
 }
 

@@ -8,6 +8,10 @@
 // sums go to LDS, then 64 lanes reduce their column windows. Deterministic (no atomics).
 #include "isp_internal.h"
 
+#ifndef ISP_POOL_NT_LD
+#define ISP_POOL_NT_LD 0
+#endif
+
 namespace adaisp {
 namespace {
 
@@ -43,7 +47,11 @@ __global__ __launch_bounds__(kThreads) void k_pool64(const float* __restrict__ i
             if (x + 3 < W) {
 #pragma unroll 4
                 for (int y = ys; y < ye; ++y) {
+#if ISP_POOL_NT_LD
+                    const float4 v = ld4_nt(reinterpret_cast<const float4*>(src + (long)y * W));
+#else
                     const float4 v = *reinterpret_cast<const float4*>(src + (long)y * W);
+#endif
                     acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
                 }
             }

@@ -239,60 +239,62 @@ def build_pipeline(step, engine, x0, cut=None, gate=None, detector_eager=False):
     return prime, run
 
 
-def time_isp_kernels(x0, sched, iters=12):
+def time_isp_kernels(x0, sched, iters=24):
     """Per-op ISP kernel time (HIP events on the launch stream), algorithmic 24 B/px. Two figures per op:
-      ms / GBps / frac_hbm   on a ROTATING set of 3 input / output buffer pairs (6 x 88.5 MB = 531 MB at config 2, more
-                             than the 256 MB Infinity Cache): every launch reads lines that have left the cache — HBM rate;
+      ms / GBps / frac_hbm   on a ROTATING set of NSETS input / output buffer pairs (12 x 88.5 MB = 1.06 GB at config 2, four
+                             times the 256 MB Infinity Cache; rounds 1-3 rotated over 531 MB, which still flattered plain
+                             loads by 10-25 %: tools/stream_ceiling.hip): every launch reads lines that have left the cache;
       warm_ms / warm_GBps    the same launch repeated on ONE pair (what rounds 1-2 reported): part of its traffic is
                              Infinity-Cache resident when the tensors fit."""
     from adaptiveisp_amd import _lib
     B, _, H, W = x0.shape
     npar = {0: 1, 1: 1, 2: 9, 3: 1, 4: 1, 5: 8, 6: 1, 7: 1, 8: 1, 9: 3}
-    ins = [x0] + [x0.clone() for _ in range(2)]
-    outs = [torch.empty_like(x0) for _ in range(3)]
-    res = {}
+    NSETS = max(3, min(6, int(1.1e9 // (2 * x0.numel() * 4)) + 1))      # >= 1 GB per cycle where the tensors allow it
+    ins = [x0] + [x0.clone() for _ in range(NSETS - 1)]
+    outs = [torch.empty_like(x0) for _ in range(NSETS)]
+    res = {"rotation_MB": round(NSETS * 2 * x0.numel() * 4 / 1e6)}
 
     def timed(op, p, n, rotate):
-        for k in range(3):
+        for k in range(NSETS):
             _lib.process(op, ins[k], p, clip=True, out=outs[k])
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for i in range(n):
-            k = i % 3 if rotate else 0
+            k = i % NSETS if rotate else 0
             _lib.process(op, ins[k], p, clip=True, out=outs[k])
         e1.record()
         torch.cuda.synchronize()
         return e0.elapsed_time(e1) / n
 
-    pools = [torch.empty((B, 3, 64, 64), dtype=torch.float32, device=x0.device) for _ in range(3)]
+    pools = [torch.empty((B, 3, 64, 64), dtype=torch.float32, device=x0.device) for _ in range(NSETS)]
 
     def timed_step(op, p, n):
         """The RL step's form of the launch: host-known op + the next step's 64x64 pooling out of the same launch."""
-        for k in range(3):
+        for k in range(NSETS):
             _lib.forward(ins[k], None, p, clip=True, out=outs[k], pooled=pools[k], host_op=op)
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for i in range(n):
-            _lib.forward(ins[i % 3], None, p, clip=True, out=outs[i % 3], pooled=pools[i % 3], host_op=op)
+            _lib.forward(ins[i % NSETS], None, p, clip=True, out=outs[i % NSETS], pooled=pools[i % NSETS], host_op=op)
         e1.record()
         torch.cuda.synchronize()
         return e0.elapsed_time(e1) / n
 
-    for k in range(3):
+    for k in range(NSETS):
         _lib.pool64(ins[k])
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for i in range(iters):
-        _lib.pool64(ins[i % 3])
+        _lib.pool64(ins[i % NSETS])
     e1.record()
     torch.cuda.synchronize()
     res["pool64"] = {"ms": round(e0.elapsed_time(e1) / iters, 4), "bytes_per_px": 12}
     for op in sorted(set(sched)):
         p = torch.rand(B, npar[op], device=x0.device) * 0.8 + 0.6
-        n = 3 if op == 4 else iters
+        n = 6 if op == 4 else iters
         ms, warm = timed(op, p, n, True), timed(op, p, n, False)
         gbs = 24.0 * B * H * W / (ms * 1e-3) / 1e9
         res[NAMES[op]] = {"ms": round(ms, 4), "GBps": round(gbs, 1), "frac_hbm": round(gbs / HBM_PEAK_GBS, 3),
