@@ -21,6 +21,9 @@
 // No barriers inside the 121-shift loop. Compute-bound on the fp32 VALU (≈3.3 kflop/px + 242
 // transcendentals per px), not on HBM (24 B/px).
 #include "isp_internal.h"
+#ifndef NLM_ABL
+#define NLM_ABL 0             // measurement builds of k_nlm_fwd: 1 no transcendentals, 2 no row sums, 3 no colour sums, 4 exp2 only
+#endif
 
 namespace adaisp {
 namespace {
@@ -509,6 +512,11 @@ __global__ __launch_bounds__(kThreads) void k_nlm_fwd(const float* __restrict__ 
                 c[2 * i + 1] = cc.y;
             }
             float D[2 * RQ], t1[2 * RQ], t2[2 * RQ], P[2 * RQ];
+#if NLM_ABL == 2          // measurement build: no 5-lane row sums
+#pragma unroll
+            for (int i = 0; i < 2 * RQ; ++i) D[i] = c[i];
+            if (false)
+#endif
             // t1 = c[i+1] + c[i], P = c[i-1] + c[i], t2 = t1[i+1] + c[i], D = P[i-1] + t2 (see above); one block per RQ
             if constexpr (RQ == 4) {
                 asm("s_nop 1\n\t"
@@ -586,9 +594,20 @@ __global__ __launch_bounds__(kThreads) void k_nlm_fwd(const float* __restrict__ 
 #pragma unroll
             for (int i = 0; i < RQ; ++i) {
                 // D >= 0 (a sum of squares): no clamp before the square root
+#if NLM_ABL == 1          // measurement build: no transcendentals
+                const v2f wgt = v2f{D[2 * i], D[2 * i + 1]} * nc + 1.0f;
+#elif NLM_ABL == 4        // measurement build: exp2 only
+                const v2f ex = v2f{D[2 * i], D[2 * i + 1]} * nc;
+                const v2f wgt = v2f{__builtin_amdgcn_exp2f(ex.x), __builtin_amdgcn_exp2f(ex.y)};
+#else
                 const v2f dist = v2f{__builtin_amdgcn_sqrtf(D[2 * i]), __builtin_amdgcn_sqrtf(D[2 * i + 1])};
                 const v2f ex = dist * nc;
                 const v2f wgt = v2f{__builtin_amdgcn_exp2f(ex.x), __builtin_amdgcn_exp2f(ex.y)};
+#endif
+#if NLM_ABL == 3          // measurement build: no colour accumulation (weights summed only)
+                den2[i] += wgt;
+                continue;
+#endif
                 // (R,G) x (w,w): left to the compiler, which broadcasts the LOW half through op_sel_hi and moves a
                 // high half down first. A hand-written high-half broadcast (op_sel:[0,1,0]) on v_pk_fma_f32 passed every
                 // stand-alone test and gave run-to-run different sums beside the detector's workgroups
