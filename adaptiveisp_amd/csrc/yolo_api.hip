@@ -128,6 +128,18 @@ int adayolo_conv_fused1x1_fwd(const void* in, int in_cstride, const void* weight
     return launch_conv_pp(a, static_cast<hipStream_t>(stream), 50) == hipSuccess ? ADAYOLO_OK : ADAYOLO_ELAUNCH;
 }
 
+int adayolo_bottleneck256_fwd(const void* x, int x_cstride, const void* weight1, const float* bias1, const void* weight2,
+                              const float* bias2, void* out, int out_cstride, int B, int H, int W, void* stream) {
+    if (!x || !weight1 || !bias1 || !weight2 || !bias2 || !out || x == out) return ADAYOLO_EINVAL;
+    if (B <= 0 || H <= 0 || W <= 0) return ADAYOLO_EINVAL;
+    if (x_cstride % 8 || out_cstride % 8 || x_cstride < 256 || out_cstride < 256) return ADAYOLO_ESHAPE;
+    if ((long)B * H * W * (x_cstride > out_cstride ? x_cstride : out_cstride) > 0x7fffffffffL ||
+        (long)B * ((H + 15) / 16) * ((W + 15) / 16) > 0x7fffffffL)
+        return ADAYOLO_ESHAPE;
+    return launch_bottleneck256(x, x_cstride, weight1, bias1, weight2, bias2, out, out_cstride, B, H, W,
+                                static_cast<hipStream_t>(stream)) == hipSuccess ? ADAYOLO_OK : ADAYOLO_ELAUNCH;
+}
+
 int adayolo_conv_keep_fwd(const void* in, int in_cstride, const void* weight, const float* bias, const void* residual,
                           int res_cstride, void* out, int out_cstride, void* pre, int pre_cstride, int B, int H, int W, int Cin,
                           int Cout, int ksize, int stride, int act, int variant, void* stream) {

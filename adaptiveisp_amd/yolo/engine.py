@@ -360,6 +360,8 @@ class YoloEngine:
         own. Runs after the variants are known (autotune); ADAYOLO_FUSE_1X1=0 keeps the layers separate. Returns the
         number of fused pairs."""
         self.fused_pairs = getattr(self, "fused_pairs", 0)
+        if self._pair_fusion:
+            self.fuse_bottlenecks()
         if not self._pair_fusion or os.environ.get("ADAYOLO_FUSE_1X1", "1") != "1":
             return 0
         out, i, n, P = [], 0, 0, self.plan
@@ -385,6 +387,47 @@ class YoloEngine:
         self.plan = out
         self.fused_pairs += n
         return n
+
+    def fuse_bottlenecks(self):
+        """A whole Bottleneck of the C = 256 stage — cv1 (1x1 256 -> 128 + SiLU) and cv2 (3x3 128 -> 256 + SiLU, + the block's
+        input) — as ONE launch with the hidden tensor in LDS (adayolo_bottleneck256_fwd, csrc/yolo_bneck.hip), wherever the plan
+        holds exactly that pair. Off by default (ADAYOLO_BNECK=1 turns it on): measured equal to the [3x3 | next 1x1] pairs
+        it replaces. Returns the number of fused blocks."""
+        self.fused_blocks = getattr(self, "fused_blocks", 0)
+        if os.environ.get("ADAYOLO_BNECK", "0") != "1":
+            return 0
+        out, i, n, P = [], 0, 0, self.plan
+        first_free = 3 if self._head_next is not None else 2
+        while i < len(P):
+            kind, fn, a = P[i]
+            if i >= first_free and kind == "conv" and i + 1 < len(P) and P[i + 1][0] == "conv":
+                b = P[i + 1][2]
+                if ((a[11], a[12], a[13], a[14], a[15]) == (256, 128, 1, 1, _lib.ACT_SILU) and a[4] is None and
+                        (b[11], b[12], b[13], b[14], b[15]) == (128, 256, 3, 1, _lib.ACT_SILU) and b[4] is not None and
+                        b[4].value == a[0].value and b[5] == a[1] and b[0].value == a[6].value and b[1] == a[7] and a[7] == 128 and
+                        (b[8], b[9], b[10]) == (a[8], a[9], a[10]) and b[6].value != a[0].value):
+                    out.append(("bneck", self.L.adayolo_bottleneck256_fwd,
+                                [a[0], a[1], a[2], a[3], b[2], b[3], b[6], b[7], a[8], a[9], a[10]]))
+                    i, n = i + 2, n + 1
+                    continue
+            out.append(P[i])
+            i += 1
+        self.plan = out
+        self.fused_blocks += n
+        return n
+
+    # `hook(i)`, when set, is called after the i-th launch of a forward (0 = the stem / fused head) on the launch stream: a
+    # caller that software-pipelines OTHER work between the detector's layers (bench.py: the next batch's ISP filters) puts
+    # it there instead of on a second stream whose workgroups would time-slice the CUs with the conv kernels'.
+    hook = None
+
+    def num_launches(self):
+        """Launches one forward issues (the hook's index range)."""
+        if self._stem is None:
+            return len(self.plan)
+        if self.fuse_head:
+            return 1 + len(self.plan) - (3 if self._head_next is not None else 2)
+        return len(self.plan)
 
     def forward(self, img):
         """img: planar fp32 [B,3,H,W] in [0,1] on the engine's device -> pred fp32 [B, N, 85] (eval decode)."""
@@ -412,10 +455,15 @@ class YoloEngine:
                                                   ctypes.c_void_p(n["dst"].ptr) if n else None, n["dst"].cs if n else 0, st)
                 if rc != 0:
                     _lib.check(rc, "adayolo stem_down")
-                for kind, fn, args in self.plan[(3 if n else 2):]:
+                hook = self.hook
+                if hook is not None:
+                    hook(0)
+                for li, (kind, fn, args) in enumerate(self.plan[(3 if n else 2):]):
                     rc = fn(*args, st)
                     if rc != 0:
                         _lib.check(rc, f"adayolo {kind}")
+                    if hook is not None:
+                        hook(li + 1)
                 return self.pred
             nc = self.head_chunks if (len(self.plan) > 1 and self.plan[0][0] == "stem" and self.plan[1][0] == "conv") else 1
             Bc = self.B // nc

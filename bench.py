@@ -34,7 +34,7 @@ TUNE_CACHE = os.path.join(ROOT, "adaptiveisp_amd", "yolo", "tuning", "mi355x.jso
 CONV_KERNEL_NAMES = {2: "dma::k_conv_igemm_dma<128,128,2,2,2>", 5: "dma2::k_conv_igemm_dma32<128,128,2,2,2,0,64,1>",
                      22: "dma2::k_conv_igemm_dma32<128,64,4,1,4,0,32,1>", 26: "dma2::k_conv_igemm_dma32<128,256,2,4,3,0,32,4>",
                      27: "dma2::k_conv_igemm_dma32<256,128,4,2,3,0,32,4>", 40: "smallk::k_conv3x3_small<...>",
-                     50: "pp::k_conv_pp<0, false>", 58: "pp::k_conv_pp<0, true>", 60: "pp128::k_conv_pp128<0>", 80: "pq::k_conv_pq<0, 4>", 85: "pq::k_conv_pq<0, 2>", 90: "ws::k_conv_ws<...>"}
+                     50: "pp::k_conv_pp<0, false>", 58: "pp::k_conv_pp<0, true>", 59: "bnk::k_bneck<0>", 60: "pp128::k_conv_pp128<0>", 80: "pq::k_conv_pq<0, 4>", 85: "pq::k_conv_pq<0, 2>", 90: "ws::k_conv_ws<...>"}
 
 
 def parse():
@@ -49,6 +49,10 @@ def parse():
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
     ap.add_argument("--no-pipeline", action="store_true", help="one stream: the detector of a batch starts only after "
                     "its own ISP episode (no overlap of consecutive batches)")
+    ap.add_argument("--pipeline", default="streams", choices=["interleaved", "streams"], help="how consecutive batches "
+                    "overlap: `streams` = the whole ISP episode of the next batch on a second stream (build_pipeline); `interleaved` "
+                    "= its filters between the detector's layers on one stream, only its policy launches on a second "
+                    "(build_interleaved; measured 0.12-0.15 ms per step SLOWER, tools/pipeline_points_ab.py)")
     ap.add_argument("--retune", action="store_true", help="re-measure the per-layer conv variants instead of loading "
                     "adaptiveisp_amd/yolo/tuning/*.json")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -239,6 +243,89 @@ def build_pipeline(step, engine, x0, cut=None, gate=None, detector_eager=False):
     return prime, run
 
 
+def build_interleaved(step, engine, x0, points=None, eager=False, side_priority=0):
+    """The same software pipeline over consecutive batches — one replay = the ISP episode of batch i+1 and the detector
+    forward of batch i — with the FILTER launches of the episode placed BETWEEN the detector's layers on the detector's own
+    stream (YoloEngine.hook) and only the policy launches (six small latency-bound kernels per RL step) on a second stream.
+    The idea: two streams share CUs by time-slicing whole workgroups, so every conv launch that overlaps an NLM or pointwise
+    launch loses its CUs for that long (the fused pair: 115 us beside the ISP stream, 93 us alone); in series the conv kernels
+    run at their clean time while the policy's latency chain stays hidden. MEASURED (round 4, tools/pipeline_points_ab.py, one
+    process, 8x720x1280): the conv kernels do run at their clean time, but the step is 4.45-4.55 ms against 4.33 for the
+    two-stream arrangement — the policy's six dependent small launches get CUs only at the conv launches' tails, so the
+    filter that waits for them stalls the detector's stream, and the two-stream form overlaps some of NLM's VALU work with
+    the conv kernels' memory phases. Not the default; kept as `--pipeline interleaved`. `points[k]` = detector launch index after which filter k is issued (default:
+    spread over the first ~60 % of the forward so the chain pol -> filter -> pol ... always has a policy's worth of layers
+    between two filters). Every replay still does one whole ISP pass and one whole detector pass. eager=True: the same
+    schedule launched without a graph (the per-kernel event-pair timing uses it)."""
+    sched = step.sched
+    n = len(sched)
+    L = engine.num_launches()
+    if points is None:
+        first, last = max(2, L // 12), max(n + 2, int(L * 0.62))
+        points = [first + (last - first) * k // max(1, n - 1) for k in range(n)]
+    if len(points) != n or any(b <= a for a, b in zip(points, points[1:])) or points[-1] >= L:
+        raise ValueError(f"points {points}: need {n} increasing detector launch indices < {L}")
+    at = {pt: k for k, pt in enumerate(points)}
+    xbuf = [torch.empty_like(x0), torch.empty_like(x0)]
+    side, hp = torch.cuda.Stream(priority=side_priority), torch.cuda.Stream()
+
+    def body(p):
+        cur = torch.cuda.current_stream()
+        carry = [None]
+
+        def half(h, out=None):
+            carry[0] = step.isp_chain(out=out, start=h, stop=h + 1, carry=carry[0], with_carry=True)
+
+        def hook(i):
+            k = at.get(i)
+            if k is None:
+                return
+            cur.wait_stream(side)                          # policy of RL step k has produced op ids / parameters
+            half(2 * k + 1, out=xbuf[p] if k == n - 1 else None)      # filter k (+ the pooling of its result), in series
+            if k + 1 < n:
+                side.wait_stream(cur)
+                with torch.cuda.stream(side):
+                    half(2 * k + 2)                        # policy of step k + 1 beside the next layers
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            half(0)                                        # first input's pooling + policy of step 0
+        done = [0]
+        engine.hook = lambda i: (hook(i), done.__setitem__(0, done[0] + (i in at)))
+        try:
+            with torch.no_grad():
+                engine(xbuf[1 - p])                        # detector of the batch the previous replay retouched
+        finally:
+            engine.hook = None
+        cur.wait_stream(side)
+        if done[0] != n:
+            raise RuntimeError(f"interleaved pipeline: only {done[0]} of {n} filters were placed (this engine's forward "
+                               "does not call the layer hook)")
+
+    graphs = []
+    if not eager:
+        for p in range(2):
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=hp):
+                body(p)
+            graphs.append(g)
+    state = {"i": 0}
+
+    def prime():
+        step.isp_chain(out=xbuf[1])
+        state["i"] = 0
+
+    def run():
+        p = state["i"] & 1
+        if eager:
+            body(p)
+        else:
+            graphs[p].replay()
+        state["i"] += 1
+
+    run.xbuf, run.state, run.points = xbuf, state, points
+    return prime, run
+
+
 def time_isp_kernels(x0, sched, iters=24):
     """Per-op ISP kernel time (HIP events on the launch stream), algorithmic 24 B/px. Two figures per op:
       ms / GBps / frac_hbm   on a ROTATING set of NSETS input / output buffer pairs (12 x 88.5 MB = 1.06 GB at config 2, four
@@ -323,6 +410,9 @@ def time_conv_kernels(engine, x, reps=20, runner=None):
 
     def entry(kind, args):
         """(variant, flops) of a conv launch of the plan; (None, 0) for everything else."""
+        if kind == "bneck":             # a whole Bottleneck of the C = 256 stage: 1x1 256 -> 128 and 3x3 128 -> 256
+            B, H, W = args[8:11]
+            return 59, 2.0 * B * H * W * (256 * 128 + 9 * 128 * 256)
         if kind not in ("conv", "conv2"):
             return None, 0.0
         B, H, W, cin, cout, k, s = args[8:15]
@@ -652,7 +742,7 @@ def extra_config5(dev, steps=6):
     det_ms = e0.elapsed_time(e1) / 3
     return {"workload": "config 5: batch 4 x 3840x2160, schedule [NLM, Shr] + YOLOv3 forward @3840x2176 bf16",
             "images_per_sec": round(4 / dt, 1), "ms_per_step": round(dt * 1e3, 2), "steps": steps,
-            "launch_mode": "pipelined" if pipelined else ("graph" if graphed else "eager"),
+            "launch_mode": (pipelined if pipelined == "interleaved" else "pipelined") if pipelined else ("graph" if graphed else "eager"),
             "nlm_ms": k["NLM"]["ms"], "nlm_frac_valu": k["NLM"].get("frac_valu"), "sharpen_ms": k["Shr"]["ms"],
             "sharpen_frac_hbm": k["Shr"]["frac_hbm"], "sharpen_with_pool_ms": k["Shr"]["with_pool_ms"],
             "detector_ms": round(det_ms, 3), "detector_tflops": round(engine.flops / (det_ms * 1e-3) / 1e12, 1)}
@@ -696,16 +786,18 @@ def prepare_gpu_run(a, dev):
             run, graphed = graph.replay, True
             single_run = graph.replay
             if not a.no_pipeline:
-                try:
-                    prime, prun = build_pipeline(step, engine, x0)
-                    prime()
-                    prun(); prun()
-                    torch.cuda.synchronize()
-                    run, pipelined = prun, True
-                except Exception as e:
-                    print(f"[bench] two-stream pipeline unavailable ({type(e).__name__}: {e}); single-stream graph",
-                          file=sys.stderr)
-                    torch.cuda.synchronize()
+                modes = ["interleaved", "streams"] if getattr(a, "pipeline", "streams") == "interleaved" else ["streams"]
+                for mode in modes:
+                    try:
+                        prime, prun = (build_interleaved if mode == "interleaved" else build_pipeline)(step, engine, x0)
+                        prime()
+                        prun(); prun()
+                        torch.cuda.synchronize()
+                        run, pipelined = prun, mode
+                        break
+                    except Exception as e:
+                        print(f"[bench] {mode} pipeline unavailable ({type(e).__name__}: {e})", file=sys.stderr)
+                        torch.cuda.synchronize()
         except Exception as e:          # stays on the HIP kernels either way; only the launch mechanism differs
             print(f"[bench] hipGraph capture unavailable ({type(e).__name__}: {e}); launching eagerly", file=sys.stderr)
             torch.cuda.synchronize()
@@ -785,13 +877,16 @@ def main():
         "metric": f"ISP+YOLO forward images/sec @{a.width}x{a.height} bs{a.batch}", "value": round(value, 2), "unit": "images/sec",
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-        "launch_mode": "pipelined" if pipelined else ("graph" if graphed else "eager"),
+        "launch_mode": (pipelined if pipelined == "interleaved" else "pipelined") if pipelined else ("graph" if graphed else "eager"),
         "config": {"workload": f"batch {a.batch} x {a.width}x{a.height} " + ("uint16 RGGB Bayer plane -> demosaic -> " if a.raw else "") +
                                f"fp32 RGB, {len(sched)}-step ISP schedule "
                                f"{[NAMES[k] for k in sched]} (teacher-forced, policy/heads evaluated every step) + YOLOv3 "
                                f"forward @{a.width}x{Hp} bf16 (random-init weights)",
                    "per_gpu_batch": a.batch, "global_batch": a.batch * world, "parallelism": f"replicas x{world}",
-                   "launch": ("hipGraph replay, 2-stage pipeline: one ISP episode's worth of steps (batch i+1 from its NLM "
+                   "launch": ("hipGraph replay, 2-stage pipeline: the ISP episode of batch i+1 inside the detector forward of batch i — "
+                              "its filter launches between the detector's layers on one stream, its policy launches on a second "
+                              "(every step = one full ISP pass + one full detector pass)") if pipelined == "interleaved" else
+                             ("hipGraph replay, 2-stage pipeline: one ISP episode's worth of steps (batch i+1 from its NLM "
                               "step on, then the first steps of batch i+2) beside the detector of batch i "
                               "(two streams; every step = one full ISP pass + one full detector pass)") if pipelined
                    else ("hipGraph replay" if graphed else "eager")},
@@ -813,7 +908,7 @@ def main():
         # issues: adaisp_forward's per-family launches + the selective pooling launch) instead of the host-known op
         step.mode["device_ids"] = True
         try:
-            dprime, drun = build_pipeline(step, engine, x0)
+            dprime, drun = (build_interleaved if pipelined == "interleaved" else build_pipeline)(step, engine, x0)
             dprime()
             for _ in range(max(a.warmup, 2)):
                 drun()
@@ -834,7 +929,8 @@ def main():
     if rank == 0 and not a.no_detail:
         runner = None
         if pipelined:
-            mprime, runner = build_pipeline(step, engine, x0, detector_eager=True)
+            mprime, runner = (build_interleaved(step, engine, x0, eager=True) if pipelined == "interleaved" else
+                              build_pipeline(step, engine, x0, detector_eager=True))
             mprime()
             runner(); runner()
             torch.cuda.synchronize()
@@ -862,7 +958,9 @@ def main():
 
         line["roofline"] = roof(d["kernels"][0])        # dominant = largest total time
         line["roofline"]["measured"] = (f"HIP event pair around every launch, in the network, {d['reps']} forwards; avg_launch_ms = " +
-                                        ("beside the ISP episode of the next batch on a second stream (the headline's arrangement)"
+                                        ("in the headline's arrangement (next batch's ISP filters between the layers, its policy on a "
+                                         "second stream)" if pipelined == "interleaved" else
+                                         "beside the ISP episode of the next batch on a second stream (the headline's arrangement)"
                                          if pipelined else "single stream") + "; *_clean = detector alone")
         line["roofline"]["other_kernels"] = [roof(r) for r in d["kernels"][1:4]]
         # live figures vs the committed rocprofv3 summary of the same command. rocprofv3 times a dispatch from its first

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define ADAYOLO_ABI_VERSION 5
+#define ADAYOLO_ABI_VERSION 6
 
 #define ADAYOLO_ACT_NONE 0
 #define ADAYOLO_ACT_SILU 1
@@ -67,6 +67,23 @@ int adayolo_conv_fused1x1_fwd(const void* in, int in_cstride,
                               int ksize, int stride, int act,
                               const void* weight2, const float* bias2,
                               void* out2, int out2_cstride, int Cout2, void* stream);
+
+/*
+ * A whole Bottleneck block of the C = 256 stage in one launch (yolov3/models/common.py:110-120, `x + cv2(cv1(x))` with
+ * cv1 = Conv(256 -> 128, k1) + SiLU and cv2 = Conv(128 -> 256, k3, s1) + SiLU, BatchNorm folded into both):
+ *     out = x + SiLU(bias2 + W2 (3x3) * SiLU(bias1 + W1 (1x1) * x))
+ * The hidden tensor never leaves the CU: a workgroup computes it on the 18 x 18 patch its 16 x 16 output tile needs,
+ * bf16-rounded exactly as the stand-alone 1x1 layer would store it, into LDS; the 3x3's activation operand is read from
+ * there (only its weights stream), and the shortcut re-reads the x tile the same workgroup fetched a moment earlier.
+ * x / out: NHWC bf16 [B,H,W,256] with channel strides; weight1 bf16 [128][256], weight2 bf16 [256][3][3][128], biases fp32.
+ * `out` must not overlap `x` (tiles read their neighbours' x while others write). ADAYOLO_ESHAPE for strides that are not
+ * multiples of 8 or < 256. Same result as adayolo_conv_fwd (k1) followed by adayolo_conv_fwd (k3, residual = x).
+ */
+int adayolo_bottleneck256_fwd(const void* x, int x_cstride,
+                              const void* weight1, const float* bias1,
+                              const void* weight2, const float* bias2,
+                              void* out, int out_cstride,
+                              int B, int H, int W, void* stream);
 
 /*
  * Same as adayolo_conv_fwd with an explicit kernel (what YoloEngine.autotune picks per layer; results agree to the

@@ -31,6 +31,31 @@ def test_pipelined_replay_equals_sequential_step(cut, gate):
     assert torch.isfinite(ref).all() and ref.shape[0] == 2
 
 
+@pytest.mark.parametrize("points", [None, [1, 2, 3, 4, 5], [0, 10, 20, 30, 60], [60, 61, 62, 63, 64]])
+def test_interleaved_replay_equals_sequential_step(points):
+    """bench.py's default arrangement (round 4): the next batch's ISP filters are issued BETWEEN the detector's layers on the
+    detector's stream (YoloEngine.hook), its policy launches on a second stream. Same predictions as the sequential step for
+    every placement of the five filters, as a graph replay and launched eagerly."""
+    sys.path.insert(0, ROOT)
+    import bench
+    a = argparse.Namespace(batch=2, height=96, width=128, schedule="mixed", retune=False)
+    bench.TUNE_CACHE = None
+    step, engine, agent, x0, sched = bench.build_workload(a, torch.device("cuda:0"))
+    ref = step().clone()
+    torch.cuda.synchronize()
+    assert engine.num_launches() > 64
+    for eager in (False, True):
+        prime, run = bench.build_interleaved(step, engine, x0, points=points, eager=eager)
+        prime()
+        for _ in range(4):
+            run()
+            torch.cuda.synchronize()
+            assert torch.equal(engine.pred, ref)
+        assert engine.hook is None
+    with pytest.raises(ValueError):
+        bench.build_interleaved(step, engine, x0, points=[5, 4, 3, 2, 1])
+
+
 def test_full_size_chain_is_bit_reproducible_beside_the_detector():
     """Regression: with the detector's big-LDS workgroups running on a second stream, an earlier LDS + barrier form of
     the policy's fc1 kernel produced run-to-run different sums (tools/chain_stress5.py). The ISP episode must come out
@@ -67,10 +92,11 @@ def test_raw_bayer_start_pipelined_equals_sequential():
     assert torch.isfinite(first).all() and 0.0 <= float(first.min()) and float(first.max()) <= 1.0
     x0.fill_(float("nan"))                                     # the next step must rebuild it from the Bayer plane
     assert torch.equal(step(), ref) and torch.equal(x0, first)
-    prime, run = bench.build_pipeline(step, engine, x0)
-    prime()
-    for _ in range(4):
-        x0.fill_(float("nan"))
-        run()
-        torch.cuda.synchronize()
-        assert torch.equal(engine.pred, ref)
+    for build in (bench.build_pipeline, bench.build_interleaved):
+        prime, run = build(step, engine, x0)
+        prime()
+        for _ in range(4):
+            x0.fill_(float("nan"))
+            run()
+            torch.cuda.synchronize()
+            assert torch.equal(engine.pred, ref)

@@ -407,3 +407,69 @@ def test_splitk_conv_repeated_launches_are_bit_stable():
                 assert torch.equal(first.view(torch.int16), out.view(torch.int16)), f"launch {it} differs"
         torch.cuda.synchronize()
         assert int(ws[:1024].view(torch.int32).abs().sum()) == 0          # the ticket block (<= 256 tiles)
+
+
+@pytest.mark.parametrize("shape", [(1, 16, 16), (1, 5, 7), (2, 23, 37), (1, 40, 33), (8, 92, 160)])
+def test_bottleneck256_kernel(shape):
+    """adayolo_bottleneck256_fwd (csrc/yolo_bneck.hip: a whole Bottleneck of the C = 256 stage in one launch, hidden tensor in
+    LDS) against fp32 `x + cv2(cv1(x))` on the same bf16 operands with the hidden tensor rounded to bf16 as the stand-alone
+    layers store it (yolov3/models/common.py:110-120), and against those two layers launched separately: ragged tiles, image
+    borders (the 3x3 pads the HIDDEN tensor with zeros, not x), NaN-prefilled output, run-to-run bit identity."""
+    from adaptiveisp_amd.yolo import _lib
+    L = _lib.load()
+    B, H, W = shape
+    g = torch.Generator(device="cpu").manual_seed(H * 7 + W)
+    x = torch.randn(B, H, W, 256, generator=g).to(torch.bfloat16).to(DEV)
+    w1 = (torch.randn(128, 1, 1, 256, generator=g) / 16).to(torch.bfloat16).to(DEV)
+    b1 = (torch.randn(128, generator=g) * 0.5).to(DEV)
+    w2 = (torch.randn(256, 3, 3, 128, generator=g) / (9 * 128) ** 0.5).to(torch.bfloat16).to(DEV)
+    b2 = (torch.randn(256, generator=g) * 0.5).to(DEV)
+    P = lambda t: ctypes.c_void_p(t.data_ptr())                                # noqa: E731
+    st = _lib.stream_ptr()
+    outs = []
+    for _ in range(3):
+        out = torch.full((B, H, W, 256), float("nan"), dtype=torch.bfloat16, device=DEV)
+        assert L.adayolo_bottleneck256_fwd(P(x), 256, P(w1), P(b1), P(w2), P(b2), P(out), 256, B, H, W, st) == 0
+        outs.append(out)
+    torch.cuda.synchronize()
+    out = outs[0]
+    assert torch.isfinite(out.float()).all(), "unwritten (NaN) outputs"
+    assert all(torch.equal(out.view(torch.int16), o.view(torch.int16)) for o in outs[1:]), "run-to-run difference"
+    xf = x.float().permute(0, 3, 1, 2)
+    h = F.silu(F.conv2d(xf, w1.float().permute(0, 3, 1, 2), b1)).to(torch.bfloat16).float()
+    ref = (F.silu(F.conv2d(h, w2.float().permute(0, 3, 1, 2), b2, padding=1)).to(torch.bfloat16).float() + xf).permute(0, 2, 3, 1)
+    close_scaled("yolo.bottleneck256_vs_fp32", out.float(), ref, 2e-2)
+    # the two stand-alone layers (1x1 on the 128-px two-workgroup kernel, 3x3 + residual on the 256 x 256 kernel)
+    hid = torch.empty(B, H, W, 128, dtype=torch.bfloat16, device=DEV)
+    two = torch.empty_like(out)
+    assert L.adayolo_conv_fwd_variant(P(x), 256, P(w1), P(b1), None, 0, P(hid), 128, B, H, W, 256, 128, 1, 1, 1, 85, st) == 0
+    assert L.adayolo_conv_fwd_variant(P(hid), 128, P(w2), P(b2), P(x), 256, P(two), 256, B, H, W, 128, 256, 3, 1, 1, 50, st) == 0
+    torch.cuda.synchronize()
+    close_scaled("yolo.bottleneck256_vs_two_layers", out.float(), two.float(), 2.0 ** -6)     # bf16 roundings of differently ordered sums
+    # argument checks of the C-ABI
+    assert L.adayolo_bottleneck256_fwd(P(x), 256, P(w1), P(b1), P(w2), P(b2), P(x), 256, B, H, W, st) == -1      # in place
+    assert L.adayolo_bottleneck256_fwd(P(x), 250, P(w1), P(b1), P(w2), P(b2), P(out), 256, B, H, W, st) == -2
+
+
+def test_engine_with_bottleneck_launches_matches_the_default_plan():
+    """ADAYOLO_BNECK=1: the eight blocks of the C = 256 stage as one launch each. Same predictions as the default plan
+    (pairs [3x3 | next 1x1]) up to bf16 rounding, at the BASELINE shape."""
+    from _synth import synth_yolo_state_dict, test_image
+    from adaptiveisp_amd.yolo import YoloEngine, yolov3
+    m = yolov3().eval()
+    m.load_state_dict(synth_yolo_state_dict(m))
+    B, H, W = 8, 720, 1280
+    x = torch.from_numpy(test_image(B, H, W, seed=5, special=False)).to(DEV)
+    base = YoloEngine(m, B, H, W, device=DEV)
+    base.autotune(cache=TUNE, write=False)
+    ref = base(x).clone()
+    os.environ["ADAYOLO_BNECK"] = "1"
+    try:
+        eng = YoloEngine(m, B, H, W, device=DEV)
+        eng.autotune(cache=TUNE, write=False)
+    finally:
+        os.environ.pop("ADAYOLO_BNECK", None)
+    assert eng.fused_blocks == 8 and sum(1 for e in eng.plan if e[0] == "bneck") == 8
+    out = eng(x)
+    torch.cuda.synchronize()
+    close("yolo.engine_bneck_vs_default_plan", out, ref, rtol=2e-2, atol=2e-2)
