@@ -140,7 +140,7 @@ __global__ __launch_bounds__(512) void k_conv_pp128(const ConvArgs a) {
                 const int wo = rem - ho * a.Wo;
                 const int hi0 = ho * a.stride - a.pad, wi0 = wo * a.stride - a.pad;
                 unsigned vw = 0;                               // tap validity is separable: rows x columns
-                // ks is 1 or 3 (checked at the ABI): three straight-line taps, no loop
+                // ks <= 3 (1 or 3 at the ABI; 2 for the stride-2 data gradient): three straight-line taps, no loop
 #pragma unroll
                 for (int kw = 0; kw < 3; ++kw) vw |= (unsigned)(kw < a.ks && wi0 + kw >= 0 && wi0 + kw < a.W) << kw;
 #pragma unroll

@@ -416,6 +416,30 @@ class YoloEngine:
         self.fused_blocks += n
         return n
 
+    # ONE set of activation buffers and ONE split-K workspace (tickets + fp32 partial tiles) serve every pass of an engine —
+    # the inference plan, the training forward, the backward and their hipGraphs — so two passes must never overlap. A pass that
+    # starts on another stream than the previous one therefore waits for it (one event per pass); inside a graph capture the
+    # capture's own dependencies do that. (rl.py runs the input batch's forward on a side stream and the retouched batch's on
+    # the current one: its explicit wait_stream is now belt and braces.)
+    def _pass_begin(self):
+        if torch.cuda.is_current_stream_capturing():
+            return
+        last = getattr(self, "_last_pass", None)
+        if last is not None:
+            cur = torch.cuda.current_stream(self.dev)
+            if last[0] != cur:
+                cur.wait_event(last[1])
+
+    def _pass_end(self):
+        if torch.cuda.is_current_stream_capturing():
+            return
+        cur = torch.cuda.current_stream(self.dev)
+        ev = getattr(self, "_pass_event", None)
+        if ev is None:
+            ev = self._pass_event = torch.cuda.Event()
+        ev.record(cur)
+        self._last_pass = (cur, ev)
+
     # `hook(i)`, when set, is called after the i-th launch of a forward (0 = the stem / fused head) on the launch stream: a
     # caller that software-pipelines OTHER work between the detector's layers (bench.py: the next batch's ISP filters) puts
     # it there instead of on a second stream whose workgroups would time-slice the CUs with the conv kernels'.
@@ -436,59 +460,67 @@ class YoloEngine:
                              f"{tuple(img.shape)} on {img.device}")
         img = img.contiguous()
         with torch.cuda.device(self.dev):
-            st = _lib.stream_ptr()
-            if self._stem is None:                               # generic first conv: pack launch takes the image pointer
-                for kind, fn, args in self.plan:
-                    rc = fn(ctypes.c_void_p(img.data_ptr()), *args[1:], st) if kind == "pack" else fn(*args, st)
-                    if rc != 0:
-                        _lib.check(rc, f"adayolo {kind}")
-                return self.pred
-            w, b, out = self._stem
-            if self.fuse_head:
-                d, n = self._head_down, self._head_next
-                rc = self.L.adayolo_stem_down_fwd(ctypes.c_void_p(img.data_ptr()), ctypes.c_void_p(w.data_ptr()),
-                                                  ctypes.c_void_p(b.data_ptr()), ctypes.c_void_p(d["w"].data_ptr()),
-                                                  ctypes.c_void_p(d["b"].data_ptr()), ctypes.c_void_p(d["dst"].ptr), d["dst"].cs,
-                                                  self.B, self.H, self.W, self.Hp, self.pad_top, LETTERBOX_VALUE,
-                                                  ctypes.c_void_p(n["w"].data_ptr()) if n else None,
-                                                  ctypes.c_void_p(n["b"].data_ptr()) if n else None,
-                                                  ctypes.c_void_p(n["dst"].ptr) if n else None, n["dst"].cs if n else 0, st)
+            self._pass_begin()
+            try:
+                return self._forward_launches(img)
+            finally:
+                self._pass_end()
+
+    def _forward_launches(self, img):
+        """The launch sequence of one forward on the current stream (see forward)."""
+        st = _lib.stream_ptr()
+        if self._stem is None:                               # generic first conv: pack launch takes the image pointer
+            for kind, fn, args in self.plan:
+                rc = fn(ctypes.c_void_p(img.data_ptr()), *args[1:], st) if kind == "pack" else fn(*args, st)
                 if rc != 0:
-                    _lib.check(rc, "adayolo stem_down")
-                hook = self.hook
-                if hook is not None:
-                    hook(0)
-                for li, (kind, fn, args) in enumerate(self.plan[(3 if n else 2):]):
-                    rc = fn(*args, st)
-                    if rc != 0:
-                        _lib.check(rc, f"adayolo {kind}")
-                    if hook is not None:
-                        hook(li + 1)
-                return self.pred
-            nc = self.head_chunks if (len(self.plan) > 1 and self.plan[0][0] == "stem" and self.plan[1][0] == "conv") else 1
-            Bc = self.B // nc
-            for c in range(nc):                                   # [stem, first conv] per batch chunk
-                rc = self.L.adayolo_stem_fwd(ctypes.c_void_p(img.data_ptr() + c * Bc * 3 * self.H * self.W * 4),
-                                             ctypes.c_void_p(w.data_ptr()), ctypes.c_void_p(b.data_ptr()),
-                                             ctypes.c_void_p(out.ptr + c * Bc * self.Hp * self.W * out.cs * 2), out.cs,
-                                             Bc, self.H, self.W, self.Hp, self.pad_top, LETTERBOX_VALUE, 32, st)
-                if rc != 0:
-                    _lib.check(rc, "adayolo stem")
-                if nc > 1:
-                    _, fn, args = self.plan[1]
-                    a = list(args)
-                    H, W, s = a[9], a[10], a[14]
-                    Ho, Wo = (H - 1) // s + 1, (W - 1) // s + 1
-                    a[0] = ctypes.c_void_p(a[0].value + c * Bc * H * W * a[1] * 2)
-                    a[6] = ctypes.c_void_p(a[6].value + c * Bc * Ho * Wo * a[7] * 2)
-                    a[8] = Bc
-                    rc = fn(*a, st)
-                    if rc != 0:
-                        _lib.check(rc, "adayolo conv")
-            for kind, fn, args in self.plan[(2 if nc > 1 else 1):]:
+                    _lib.check(rc, f"adayolo {kind}")
+            return self.pred
+        w, b, out = self._stem
+        if self.fuse_head:
+            d, n = self._head_down, self._head_next
+            rc = self.L.adayolo_stem_down_fwd(ctypes.c_void_p(img.data_ptr()), ctypes.c_void_p(w.data_ptr()),
+                                              ctypes.c_void_p(b.data_ptr()), ctypes.c_void_p(d["w"].data_ptr()),
+                                              ctypes.c_void_p(d["b"].data_ptr()), ctypes.c_void_p(d["dst"].ptr), d["dst"].cs,
+                                              self.B, self.H, self.W, self.Hp, self.pad_top, LETTERBOX_VALUE,
+                                              ctypes.c_void_p(n["w"].data_ptr()) if n else None,
+                                              ctypes.c_void_p(n["b"].data_ptr()) if n else None,
+                                              ctypes.c_void_p(n["dst"].ptr) if n else None, n["dst"].cs if n else 0, st)
+            if rc != 0:
+                _lib.check(rc, "adayolo stem_down")
+            hook = self.hook
+            if hook is not None:
+                hook(0)
+            for li, (kind, fn, args) in enumerate(self.plan[(3 if n else 2):]):
                 rc = fn(*args, st)
                 if rc != 0:
                     _lib.check(rc, f"adayolo {kind}")
+                if hook is not None:
+                    hook(li + 1)
+            return self.pred
+        nc = self.head_chunks if (len(self.plan) > 1 and self.plan[0][0] == "stem" and self.plan[1][0] == "conv") else 1
+        Bc = self.B // nc
+        for c in range(nc):                                   # [stem, first conv] per batch chunk
+            rc = self.L.adayolo_stem_fwd(ctypes.c_void_p(img.data_ptr() + c * Bc * 3 * self.H * self.W * 4),
+                                         ctypes.c_void_p(w.data_ptr()), ctypes.c_void_p(b.data_ptr()),
+                                         ctypes.c_void_p(out.ptr + c * Bc * self.Hp * self.W * out.cs * 2), out.cs,
+                                         Bc, self.H, self.W, self.Hp, self.pad_top, LETTERBOX_VALUE, 32, st)
+            if rc != 0:
+                _lib.check(rc, "adayolo stem")
+            if nc > 1:
+                _, fn, args = self.plan[1]
+                a = list(args)
+                H, W, s = a[9], a[10], a[14]
+                Ho, Wo = (H - 1) // s + 1, (W - 1) // s + 1
+                a[0] = ctypes.c_void_p(a[0].value + c * Bc * H * W * a[1] * 2)
+                a[6] = ctypes.c_void_p(a[6].value + c * Bc * Ho * Wo * a[7] * 2)
+                a[8] = Bc
+                rc = fn(*a, st)
+                if rc != 0:
+                    _lib.check(rc, "adayolo conv")
+        for kind, fn, args in self.plan[(2 if nc > 1 else 1):]:
+            rc = fn(*args, st)
+            if rc != 0:
+                _lib.check(rc, f"adayolo {kind}")
         return self.pred
 
     __call__ = forward

@@ -402,23 +402,31 @@ class YoloTrainEngine(YoloEngine):
         """The forward launch sequence: the raw head maps land in self.raw (bf16, the engine's buffers)."""
         st = self._graph("fwd")
         with torch.cuda.device(self.dev):
-            if st is None:
-                self._run(self._forward_plan(), img=img)
-            else:
-                st["img"].copy_(img)
-                st["fwd"].replay()
+            self._pass_begin()
+            try:
+                if st is None:
+                    self._run(self._forward_plan(), img=img)
+                else:
+                    st["img"].copy_(img)
+                    st["fwd"].replay()
+            finally:
+                self._pass_end()
         self._gen += 1
 
     def _backward_raw(self):
         """The backward launch sequence from the head-gradient buffers (self._graw) -> d loss / d img."""
         st = self._graph("bwd")
         with torch.cuda.device(self.dev):
-            if st is None:
-                grad_img = torch.empty((self.B, 3, self.H, self.W), dtype=torch.float32, device=self.dev)
-                self._run(self._backward_plan(), grad_img=grad_img)
-                return grad_img
-            st["bwd"].replay()
-            return st["grad_img"].clone()
+            self._pass_begin()
+            try:
+                if st is None:
+                    grad_img = torch.empty((self.B, 3, self.H, self.W), dtype=torch.float32, device=self.dev)
+                    self._run(self._backward_plan(), grad_img=grad_img)
+                    return grad_img
+                st["bwd"].replay()
+                return st["grad_img"].clone()
+            finally:
+                self._pass_end()
 
     def forward_train(self, img):
         """img planar fp32 [B,3,H,W] on the device -> the three raw head maps [B,na,ny,nx,no] fp32."""
