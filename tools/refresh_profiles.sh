@@ -8,11 +8,11 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out
 mkdir -p "$OUT"
 # 1) tune once (writes the cache into this checkout and a copy into gpurun_out so it can be committed), 2) official line
-python3 "$R/bench.py" --retune --no-cpu-baseline --no-detail > /dev/null 2>&1
+python3 "$R/bench.py" --retune --no-cpu-baseline --no-detail --no-extras > /dev/null 2>&1
 cp "$R/adaptiveisp_amd/yolo/tuning/mi355x.json" "$OUT/${TAG}_tuning_mi355x.json"
 python3 "$R/bench.py" > "$OUT/${TAG}_bench.json" 2> "$OUT/${TAG}_bench.err"
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/${TAG}_stats" -o bench -- python3 "$R/bench.py" --no-cpu-baseline > "$OUT/${TAG}_stats.log" 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/${TAG}_stats" -o bench -- python3 "$R/bench.py" --no-cpu-baseline --no-extras > "$OUT/${TAG}_stats.log" 2>&1
 cp "$OUT/${TAG}_stats/bench_kernel_stats.csv" "$OUT/${TAG}_rocprofv3_kernel_stats.csv"
 for C in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $C --kernel-trace --output-format csv -d "$OUT/${TAG}_pmc" -o $C -- python3 "$R/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-detail --no-graph > "$OUT/${TAG}_pmc_$C.log" 2>&1
