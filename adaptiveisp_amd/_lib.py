@@ -20,9 +20,9 @@ NLM_EXACT = 2      # NLM patch sums in the reference's running-sum order (slower
 NLM_SEP_V1 = 4     # the compiler-scheduled form of the separable kernel (cross-check / measurement)
 NO_USM = 8         # adaisp_forward: no image selects the unsharp mask (its empty launch is skipped)
 NLM_TILE32 = 16    # the 32-row tile of the default NLM kernel (cross-check / measurement)
-ABI_VERSION = 4
+ABI_VERSION = 5
 
-EXPORTS = ("adaisp_forward", "adaisp_forward_uniform", "adaisp_process", "adaisp_backward_params", "adaisp_pool64", "adaisp_pool64_backward", "adaisp_demosaic", "adaisp_num_params",
+EXPORTS = ("adaisp_forward", "adaisp_forward_uniform", "adaisp_process", "adaisp_backward_params", "adaisp_pool64", "adaisp_pool64_backward", "adaisp_demosaic", "adaisp_nlm_general", "adaisp_nlm_general_workspace_bytes", "adaisp_num_params",
            "adaisp_policy_conv", "adaisp_policy_fc1", "adaisp_policy_finish",
            "adaisp_strerror", "adaisp_abi_version")
 
@@ -53,6 +53,10 @@ def load():
     L.adaisp_pool64_backward.restype = ci
     L.adaisp_demosaic.argtypes = [vp, vp, ci, ci, ci, ci, ctypes.c_float, ctypes.c_float, vp]
     L.adaisp_demosaic.restype = ci
+    L.adaisp_nlm_general.argtypes = [vp, vp, vp, ci, vp, ctypes.c_size_t, ci, ci, ci, ci, ci, vp]
+    L.adaisp_nlm_general.restype = ci
+    L.adaisp_nlm_general_workspace_bytes.argtypes = [ci, ci, ci]
+    L.adaisp_nlm_general_workspace_bytes.restype = ctypes.c_size_t
     L.adaisp_num_params.argtypes = [ci]
     L.adaisp_strerror.argtypes = [ci]
     L.adaisp_strerror.restype = ctypes.c_char_p
@@ -147,6 +151,25 @@ def forward(img, op_ids, params, clip=True, pooled=None, out=None, nlm_exact=Fal
     _check(rc, "adaisp_forward")
     _wrote(out)
     _wrote(pooled)
+    return out
+
+
+def nlm_general(img, h, search_window_size, patch_size, out=None):
+    """adaisp_nlm_general: NonLocalMeansGray(search_window_size, patch_size).forward(img, h) for any odd sizes (the ISP's
+    11 / 5 goes through OP_NLM's tuned kernel). h: one value per image."""
+    L = load()
+    img = _dev_f32(img, "img")
+    B, H, W = _img_shape(img)
+    h = _dev_f32(h.reshape(B, -1), "h")
+    if out is None:
+        out = torch.empty_like(img)
+    nbytes = int(L.adaisp_nlm_general_workspace_bytes(B, H, W))
+    ws = torch.empty(nbytes // 4, dtype=torch.float32, device=img.device)
+    with torch.cuda.device(img.device):
+        rc = L.adaisp_nlm_general(img.data_ptr(), out.data_ptr(), h.data_ptr(), h.shape[1], ws.data_ptr(), nbytes, B, H, W,
+                                  int(search_window_size), int(patch_size), _stream())
+    _check(rc, "adaisp_nlm_general")
+    _wrote(out)
     return out
 
 

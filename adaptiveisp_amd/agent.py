@@ -158,9 +158,21 @@ class Agent(nn.Module):
         except RuntimeError:
             return None
 
+    # The one piece of state the eval path keeps between calls: the 64x64 planes of the image the previous step returned, reused
+    # when THAT tensor object comes back with an unchanged version counter (torch bumps it for its own in-place ops, _lib for
+    # every kernel of this package). A writer that goes AROUND both — another extension writing through the raw pointer —
+    # is invisible to it: such a caller sets `agent.reuse_pooled_planes = False` (every step then pools its input with a launch
+    # of its own, ~17 us at 8 x 720 x 1280) or calls `agent.forget_pooled_planes()` after writing.
+    reuse_pooled_planes = True
+
+    def forget_pooled_planes(self):
+        self._pool_cache = None
+
     def _cached_pool(self, x):
         """The pooling of x if x IS the tensor the previous eval step returned, unmodified since."""
         c = self._pool_cache
+        if not self.reuse_pooled_planes:
+            return None
         if c is not None and c[1] is not None and c[0]() is x and self._version_of(x) == c[1]:
             return c[2]
         return None

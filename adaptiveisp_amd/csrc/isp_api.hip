@@ -97,6 +97,21 @@ int adaisp_process(int op, const float* img, float* out, const float* params, in
     return e == hipSuccess ? ADAISP_OK : ADAISP_ELAUNCH;
 }
 
+size_t adaisp_nlm_general_workspace_bytes(int B, int H, int W) {
+    return (B > 0 && H > 0 && W > 0) ? (size_t)B * H * W * sizeof(float) : 0;
+}
+
+int adaisp_nlm_general(const float* img, float* out, const float* h, int h_stride, void* workspace, size_t workspace_bytes,
+                       int B, int H, int W, int search_window_size, int patch_size, void* stream) {
+    if (!img || !out || !h || !workspace || B <= 0 || H <= 0 || W <= 0 || h_stride <= 0) return ADAISP_EINVAL;
+    if (search_window_size < 1 || patch_size < 1 || !(search_window_size & 1) || !(patch_size & 1)) return ADAISP_EINVAL;
+    if (search_window_size > 63 || patch_size > 31 || B > 65535 || (H + 3) / 4 > 65535) return ADAISP_ESHAPE;
+    if (workspace_bytes < adaisp_nlm_general_workspace_bytes(B, H, W)) return ADAISP_EINVAL;
+    if (ranges_overlap(img, out, (long)B * 3 * H * W)) return ADAISP_EALIAS;
+    return launch_nlm_general(img, out, h, h_stride, static_cast<float*>(workspace), B, H, W, search_window_size, patch_size,
+                              static_cast<hipStream_t>(stream)) == hipSuccess ? ADAISP_OK : ADAISP_ELAUNCH;
+}
+
 namespace {
 
 // One RL step for a batch: ids on the device (`filter_id`) or one host-known op (`filter_id` == NULL). With `pooled` the

@@ -75,6 +75,8 @@ hipError_t launch_pool64_sel(const float* img, float* pooled, const int32_t* ids
                              unsigned flags, int B, int H, int W, hipStream_t s);
 hipError_t launch_conv(const Batch& a, hipStream_t s);     // 3x3 sharpen, 3x3 sharpness, 5x5 USM
 hipError_t launch_nlm(const Batch& a, hipStream_t s);
+hipError_t launch_nlm_general(const float* img, float* out, const float* h, int hstride, float* workspace, int B, int H, int W,
+                              int search, int patch, hipStream_t s);
 hipError_t launch_pool64(const float* img, float* pooled, int B, int H, int W, hipStream_t s);
 hipError_t launch_pool64_bwd(const float* grad_pooled, float* grad_img, int B, int H, int W, hipStream_t s);
 hipError_t launch_demosaic(const uint16_t* raw, float* out, int B, int H, int W, int pattern, float black, float white,

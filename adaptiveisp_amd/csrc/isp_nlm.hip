@@ -641,7 +641,63 @@ __global__ __launch_bounds__(kThreads) void k_nlm_fwd(const float* __restrict__ 
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// NonLocalMeansGray(search_window_size, patch_size) for ANY odd sizes (isp/denoise.py:93-119; the class default is
+// 21 / 7, the ISP's DenoiseFilter uses 11 / 5 and has the tuned kernels above). A plain gather form, one pixel per
+// lane: the clipped luminance comes from a plane computed once (k_nlm_luma, denoise.py:11-17), the patch distance is summed
+// in the reference's order (patch column outer, patch row inner, from 0), shifts are visited x outer / y inner, the
+// colours are the UNCLIPPED input (the class clips only inside rgb_to_luminance), the result is clamped to [0, 1].
+// O(search^2 * patch^2) cached loads per pixel: a correctness path for configurations the ISP does not use.
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kThreads) void k_nlm_luma(const float* __restrict__ img, float* __restrict__ y, long plane, long total) {
+    const long i = (long)blockIdx.x * kThreads + threadIdx.x;
+    if (i >= total) return;
+    const long b = i / plane, r = i - b * plane;
+    const float* in = img + b * 3 * plane + r;
+    const float rr = clamp01(in[0]), gg = clamp01(in[plane]), bb = clamp01(in[2 * plane]);
+    y[i] = (0.299f * rr + 0.587f * gg) + 0.114f * bb;
+}
+
+__global__ __launch_bounds__(kThreads) void k_nlm_general(const float* __restrict__ img, const float* __restrict__ ylum,
+                                                          float* __restrict__ out, const float* __restrict__ h, int hstride,
+                                                          int H, int W, int SRg, int PRg) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), yy = blockIdx.y * 4 + (threadIdx.x >> 6), b = blockIdx.z;
+    if (x >= W || yy >= H) return;
+    const long plane = (long)H * W;
+    const float* in = img + (long)b * 3 * plane;
+    const float* yl = ylum + (long)b * plane;
+    const float hh = fmaxf(h[(long)b * hstride], 0.0f) + 1e-8f;
+    float n0 = 0.f, n1 = 0.f, n2 = 0.f, den = 0.f;
+    for (int dx = -SRg; dx <= SRg; ++dx)
+        for (int dy = -SRg; dy <= SRg; ++dy) {
+            float D = 0.f;
+            for (int bx = -PRg; bx <= PRg; ++bx) {
+                const int jj = wrap(x - bx, W), js = wrap(x - bx - dx, W);
+                for (int by = -PRg; by <= PRg; ++by) {
+                    const int ii = wrap(yy - by, H), is = wrap(yy - by - dy, H);
+                    const float d = yl[(long)ii * W + jj] - yl[(long)is * W + js];
+                    D += d * d;
+                }
+            }
+            const float wgt = expf(-sqrtf(fmaxf(D, 0.0f)) / hh);
+            const long sidx = (long)wrap(yy - dy, H) * W + wrap(x - dx, W);
+            n0 += in[sidx] * wgt; n1 += in[sidx + plane] * wgt; n2 += in[sidx + 2 * plane] * wgt;
+            den += wgt;
+        }
+    float* o = out + (long)b * 3 * plane + (long)yy * W + x;
+    o[0] = clamp01(n0 / den); o[plane] = clamp01(n1 / den); o[2 * plane] = clamp01(n2 / den);
+}
+
 }  // namespace
+
+hipError_t launch_nlm_general(const float* img, float* out, const float* h, int hstride, float* workspace, int B, int H, int W,
+                              int search, int patch, hipStream_t s) {
+    const long plane = (long)H * W, total = plane * B;
+    hipLaunchKernelGGL(k_nlm_luma, dim3((unsigned)((total + kThreads - 1) / kThreads)), dim3(kThreads), 0, s, img, workspace, plane, total);
+    hipLaunchKernelGGL(k_nlm_general, dim3((W + 63) / 64, (H + 3) / 4, B), dim3(kThreads), 0, s, img, workspace, out, h, hstride, H, W,
+                       search / 2, patch / 2);
+    return hipGetLastError();
+}
 
 hipError_t launch_nlm(const Batch& a, hipStream_t s) {
     if (!(a.flags & ADAISP_NLM_EXACT)) {

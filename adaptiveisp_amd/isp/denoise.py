@@ -1,6 +1,7 @@
-"""Non-local-means denoise — mirror of the reference's isp/denoise.py entry points, backed by the
-single-launch HIP kernel (csrc/isp_nlm.hip). Only the configuration the reference's ISP uses is
-built: gray-weighted NLM with an 11x11 search window and a 5x5 patch (isp/filters.py:577)."""
+"""Non-local-means denoise — mirror of the reference's isp/denoise.py entry points, backed by the HIP kernels of
+csrc/isp_nlm.hip: the tuned single-launch kernel for the configuration the reference's ISP uses (gray-weighted NLM, 11x11
+search window, 5x5 patch: isp/filters.py:577) and a plain gather kernel for every other odd (search, patch) pair the class
+accepts (its own default is 21 / 7, isp/denoise.py:94)."""
 import torch
 import torch.nn as nn
 
@@ -22,10 +23,15 @@ class NonLocalMeansGray(nn.Module):
 
     def __init__(self, search_window_size=11, patch_size=5):
         super().__init__()
-        if (search_window_size, patch_size) != (11, 5):
-            raise NotImplementedError("the HIP NLM kernel is specialised for search 11 / patch 5, the only "
-                                      "configuration on the reference's ISP path (isp/filters.py:577)")
+        if search_window_size % 2 != 1 or patch_size % 2 != 1 or search_window_size < 1 or patch_size < 1:
+            raise ValueError("window size must be odd")                  # BoxFilter's assertion, isp/denoise.py:52
+        self.search_window_size, self.patch_size = int(search_window_size), int(patch_size)
         self.r = search_window_size // 2
 
     def forward(self, rgb, h):
-        return isp_apply(rgb, h.reshape(h.shape[0], -1), _lib.OP_NLM, clip=False)
+        if (self.search_window_size, self.patch_size) == (11, 5):
+            # the ISP's configuration: tuned kernel, differentiable in h (rgb in [0,1], as DenoiseFilter.process hands it over)
+            return isp_apply(rgb, h.reshape(h.shape[0], -1), _lib.OP_NLM, clip=False)
+        if torch.is_grad_enabled() and (h.requires_grad or rgb.requires_grad):
+            raise NotImplementedError("only the 11 / 5 configuration (the one on the training path) has a backward kernel")
+        return _lib.nlm_general(rgb, h.reshape(h.shape[0], -1), self.search_window_size, self.patch_size)

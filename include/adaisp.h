@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define ADAISP_ABI_VERSION 4
+#define ADAISP_ABI_VERSION 5
 
 /* Kernel op codes. 0..9 follow the reference's default filter order (config.py:19-22). */
 enum adaisp_op {
@@ -123,6 +123,19 @@ int adaisp_backward_params(const float* img, const float* grad_out,
 #define ADAISP_CFA_BGGR 3
 int adaisp_demosaic(const uint16_t* raw, float* out, int B, int H, int W, int pattern,
                     float black_level, float white_level, void* stream);
+
+/*
+ * NonLocalMeansGray(search_window_size, patch_size).forward(rgb, h) for ANY odd sizes — isp/denoise.py:93-119 (class default
+ * 21 / 7; the ISP's DenoiseFilter constructs 11 / 5, isp/filters.py:577, which ADAISP_OP_NLM serves with the tuned kernel).
+ * Luminance 0.299 R + 0.587 G + 0.114 B of the CLIPPED image (rgb_to_luminance :11-17), patch distance = box sum of squared
+ * differences under torch.roll's circular wrap, weight exp(-sqrt(relu(D)) / (relu(h) + 1e-8)), colours = the input as given,
+ * result clamped to [0, 1]. h: one value per image, `h_stride` floats apart. `workspace` (adaisp_nlm_general_workspace_bytes:
+ * one fp32 luminance plane per image) is caller-owned scratch. A plain gather kernel — O(search^2 patch^2) per pixel — for
+ * configurations the ISP path does not use. `out` must not overlap `img`.
+ */
+size_t adaisp_nlm_general_workspace_bytes(int B, int H, int W);
+int adaisp_nlm_general(const float* img, float* out, const float* h, int h_stride, void* workspace, size_t workspace_bytes,
+                       int B, int H, int W, int search_window_size, int patch_size, void* stream);
 
 /* AdaptiveAvgPool2d((64,64)) of a [B,3,H,W] image: agent.py:85,97, value.py:61,63. */
 int adaisp_pool64(const float* img, float* pooled, int B, int H, int W, void* stream);

@@ -45,6 +45,8 @@ def lib():
         L.oracle_demosaic.restype = ctypes.c_int
         L.oracle_nms.argtypes = [f32p, ctypes.c_int, ctypes.c_float, ctypes.c_int, i32p]
         L.oracle_nms.restype = ctypes.c_int
+        L.oracle_nlm_general.argtypes = [f32p, f32p, f32p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+        L.oracle_nlm_general.restype = ctypes.c_int
         L.oracle_num_params.argtypes = [ctypes.c_int]
         L.oracle_num_params.restype = ctypes.c_int
         _LIB = L
@@ -90,6 +92,17 @@ def select_and_update(pdf, u, states, train=False, forced=-1, test_steps=5.0):
     lib().oracle_select_and_update(_fp(pdf), _fp(u), _fp(states), B, F, 1 if train else 0, int(forced),
                                    float(test_steps), sel.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), _fp(ns))
     return sel, ns
+
+
+def nlm_general(img, h, search, patch):
+    """NonLocalMeansGray(search, patch).forward(img, h) (isp/denoise.py:93-119): img [B,3,H,W], h [B] -> [B,3,H,W]."""
+    img = _f32(img)
+    B, C, H, W = img.shape
+    h = _f32(h).reshape(B)
+    out = np.empty_like(img)
+    if lib().oracle_nlm_general(_fp(img), _fp(out), _fp(h), B, H, W, int(search), int(patch)) != 0:
+        raise ValueError("oracle_nlm_general: odd positive window sizes expected")
+    return out
 
 
 def nms(boxes, iou_thres, max_det=300):

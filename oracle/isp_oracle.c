@@ -210,14 +210,16 @@ static void conv_image(int op, const float* in, float* out, const float* p, int 
 
 static inline int wrapi(int v, int n) { v %= n; return v < 0 ? v + n : v; }
 
-/* NonLocalMeansGray(11, 5), isp/denoise.py:93-119; clip of DenoiseFilter.process isp/filters.py:584 */
-static void nlm_image(const float* in, float* out, float h, int H, int W) {
+/* NonLocalMeansGray(2 sr + 1, 2 pr + 1), isp/denoise.py:93-119. clip_rgb: the colours are clipped first (DenoiseFilter.process,
+ * isp/filters.py:584, hands the class a clipped image); without it they are the input as given and only the luminance is
+ * computed from the clipped image (rgb_to_luminance, denoise.py:11-17) — the class on its own. */
+static void nlm_image_sp(const float* in, float* out, float h, int H, int W, int sr, int pr, int clip_rgb) {
     const long plane = (long)H * W;
     float* rgb = (float*)malloc(sizeof(float) * 3 * plane);
     float* y = (float*)malloc(sizeof(float) * plane);
     for (long i = 0; i < plane; ++i) {
         const float r = clamp01f(in[i]), g = clamp01f(in[i + plane]), b = clamp01f(in[i + 2 * plane]);
-        rgb[i] = r; rgb[i + plane] = g; rgb[i + 2 * plane] = b;
+        rgb[i] = clip_rgb ? r : in[i]; rgb[i + plane] = clip_rgb ? g : in[i + plane]; rgb[i + 2 * plane] = clip_rgb ? b : in[i + 2 * plane];
         y[i] = (0.299f * r + 0.587f * g) + 0.114f * b;               /* denoise.py:17 */
     }
     const float hh = (h > 0.0f ? h : 0.0f) + 1e-8f;                  /* denoise.py:113 */
@@ -225,11 +227,11 @@ static void nlm_image(const float* in, float* out, float h, int H, int W) {
     for (int i = 0; i < H; ++i)
         for (int j = 0; j < W; ++j) {
             float num0 = 0.0f, num1 = 0.0f, num2 = 0.0f, den = 0.0f;
-            for (int dx = -5; dx <= 5; ++dx)                         /* x_shift outer, :104 */
-                for (int dy = -5; dy <= 5; ++dy) {                   /* y_shift inner, :105 */
+            for (int dx = -sr; dx <= sr; ++dx)                       /* x_shift outer, :104 */
+                for (int dy = -sr; dy <= sr; ++dy) {                 /* y_shift inner, :105 */
                     float D = 0.0f;
-                    for (int bx = -2; bx <= 2; ++bx)                 /* BoxFilter: x outer, y inner, :60-63 */
-                        for (int by = -2; by <= 2; ++by) {
+                    for (int bx = -pr; bx <= pr; ++bx)               /* BoxFilter: x outer, y inner, :60-63 */
+                        for (int by = -pr; by <= pr; ++by) {
                             const int ii = wrapi(i - by, H), jj = wrapi(j - bx, W);
                             const float d = y[(long)ii * W + jj] - y[(long)wrapi(ii - dy, H) * W + wrapi(jj - dx, W)];
                             D += d * d;
@@ -244,6 +246,15 @@ static void nlm_image(const float* in, float* out, float h, int H, int W) {
             out[o] = clamp01f(num0 / den); out[o + plane] = clamp01f(num1 / den); out[o + 2 * plane] = clamp01f(num2 / den);
         }
     free(rgb); free(y);
+}
+static void nlm_image(const float* in, float* out, float h, int H, int W) { nlm_image_sp(in, out, h, H, W, 5, 2, 1); }
+
+/* NonLocalMeansGray(search, patch).forward(img, h): the counterpart of adaisp_nlm_general (include/adaisp.h) */
+int oracle_nlm_general(const float* img, float* out, const float* h, int B, int H, int W, int search, int patch) {
+    if (!img || !out || !h || B <= 0 || H <= 0 || W <= 0 || search < 1 || patch < 1 || !(search & 1) || !(patch & 1)) return -1;
+    for (int b = 0; b < B; ++b)
+        nlm_image_sp(img + (long)b * 3 * H * W, out + (long)b * 3 * H * W, h[b], H, W, search / 2, patch / 2, 0);
+    return 0;
 }
 
 /* ---- exported entry points (host pointers; same argument meaning as include/adaisp.h) ------------- */

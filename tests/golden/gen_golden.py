@@ -277,6 +277,31 @@ def main():
     print("fixtures written, total bytes:", tot)
 
 
+def gen_nlm_general():
+    """NonLocalMeansGray(search, patch) of the reference (isp/denoise.py:93-119) for window sizes other than the ISP's 11 / 5:
+    the class default 21 / 7 and small ones, on images inside AND outside [0, 1] (only the luminance is clipped by the class)."""
+    import_reference()
+    import torch
+    from isp import denoise
+    out = {}
+    cases = [("s7p3", 7, 3, (2, 24, 31), [0.1, 0.6], 31, False), ("s21p7", 21, 7, (1, 26, 33), [0.25], 32, False),
+             ("s5p5", 5, 5, (1, 9, 12), [0.4], 33, False), ("s3p1", 3, 1, (1, 7, 8), [0.05], 34, False),
+             ("s9p3_out_of_range", 9, 3, (1, 20, 22), [0.3], 35, True), ("s11p5", 11, 5, (1, 18, 25), [0.2], 36, False)]
+    with torch.no_grad():
+        for tag, search, patch, shape, hs, seed, wide in cases:
+            x = test_image(shape[0], shape[1], shape[2], seed=seed, special=False)
+            x += np.random.default_rng(seed).normal(0, 0.02, x.shape).astype(np.float32)
+            if wide:
+                x = (x * 3.0 - 0.4).astype(np.float32)
+            else:
+                x = np.clip(x, 0.0, 1.0).astype(np.float32)
+            h = np.asarray(hs, np.float32).reshape(-1, 1, 1, 1)
+            out[f"{tag}.img"], out[f"{tag}.h"] = x, h.reshape(-1)
+            out[f"{tag}.sizes"] = np.asarray([search, patch], np.int32)
+            out[f"{tag}.out"] = denoise.NonLocalMeansGray(search, patch)(torch.from_numpy(x), torch.from_numpy(h)).numpy()
+    np.savez_compressed(os.path.join(HERE, "nlm_general.npz"), **out)
+
+
 def gen_value_path():
     """The critic-to-actor gradient (train.py:281-305 with cfg.use_TD): L = -mean(V(retouch, new_states)) where retouch
     comes out of Agent.forward — the reference back-propagates through AdaptiveAvgPool2d and the selected filter into
@@ -308,6 +333,10 @@ def gen_value_path():
 
 if __name__ == "__main__" and "--value-path-only" in sys.argv:
     gen_value_path()
+    sys.exit(0)
+
+if __name__ == "__main__" and "--nlm-general-only" in sys.argv:
+    gen_nlm_general()
     sys.exit(0)
 
 if __name__ == "__main__" and not any(f in sys.argv for f in ("--eval-only", "--ckpt-only", "--replay-only", "--mosaic-only", "--midsize-only")):

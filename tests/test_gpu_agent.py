@@ -335,6 +335,14 @@ def test_eval_loop_reuses_the_pooling_of_the_filter_launch(golden):
         (y, _, _, _), _, _ = ag((T(g["x"]).to(dev), z, T(g["s0"]).to(dev)), 0.5)
         _lib.process(_lib.OP_EXPOSURE, T(g["x"]).to(dev), torch.ones(y.shape[0], 1, device=dev), out=y)   # raw-pointer write
         assert ag._cached_pool(y) is None
+        # the two switches for callers whose writers go around torch AND this package
+        (y, _, _, _), _, _ = ag((T(g["x"]).to(dev), z, T(g["s0"]).to(dev)), 0.5)
+        assert ag._cached_pool(y) is not None
+        ag.forget_pooled_planes()
+        assert ag._cached_pool(y) is None
+        (y, _, _, _), _, _ = ag((T(g["x"]).to(dev), z, T(g["s0"]).to(dev)), 0.5)
+        ag.reuse_pooled_planes = False
+        assert ag._cached_pool(y) is None
 
 
 def test_eval_loop_under_inference_mode(golden):

@@ -71,6 +71,30 @@ def test_golden_nlm_wrap(golden, tag):
     close("golden_nlm_wrap#1", out, g[f"{tag}.out"], rtol=RTOL, atol=ATOL)
 
 
+@pytest.mark.parametrize("tag", ["s3p1", "s5p5", "s7p3", "s9p3_out_of_range", "s11p5", "s21p7"])
+def test_nlm_general_window_sizes(golden, oracle_mod, tag):
+    """NonLocalMeansGray(search, patch) for window sizes other than the ISP's 11 / 5 (adaisp_nlm_general, the class API of
+    isp/denoise.py:93-119) against the reference's outputs and the oracle; 11 / 5 goes through the tuned kernel."""
+    from adaptiveisp_amd import _lib
+    from adaptiveisp_amd.isp.denoise import NonLocalMeansGray
+    g = golden("nlm_general")
+    search, patch = (int(v) for v in g[f"{tag}.sizes"])
+    img, h = torch.from_numpy(g[f"{tag}.img"]).to(dev()), torch.from_numpy(g[f"{tag}.h"]).to(dev())
+    with torch.no_grad():
+        out = NonLocalMeansGray(search, patch)(img, h.reshape(-1, 1, 1, 1))
+    torch.cuda.synchronize()
+    close("nlm_general_vs_reference", out.cpu().numpy(), g[f"{tag}.out"], rtol=RTOL, atol=ATOL)
+    gen = _lib.nlm_general(img, h, search, patch)                       # the gather kernel itself, also for 11 / 5
+    close("nlm_general_vs_oracle", gen.cpu().numpy(), oracle_mod.nlm_general(g[f"{tag}.img"], g[f"{tag}.h"], search, patch),
+          rtol=RTOL, atol=ATOL)
+    with pytest.raises(ValueError):
+        NonLocalMeansGray(4, 3)
+    with pytest.raises(_lib.AdaispError):
+        _lib.nlm_general(img, h, 5, 2)
+    with pytest.raises(_lib.AdaispError):
+        _lib.nlm_general(img, h, search, patch, out=img)                 # in place
+
+
 @pytest.mark.parametrize("tag", ["a", "tiny", "odd"])
 def test_nlm_reference_order_kernel(golden, oracle_mod, tag):
     """ADAISP_NLM_EXACT: the 25 patch terms in the reference's running-sum order; and how far the default

@@ -29,6 +29,21 @@ def test_nlm_wraparound(golden, oracle_mod, tag):
     assert np.abs(out - g[f"{tag}.out"]).max() <= ABS_TOL
 
 
+@pytest.mark.parametrize("tag", ["s3p1", "s5p5", "s7p3", "s9p3_out_of_range", "s11p5", "s21p7"])
+def test_nlm_general_window_sizes(golden, oracle_mod, tag):
+    """oracle_nlm_general against the reference's NonLocalMeansGray(search, patch) for sizes other than the ISP's 11 / 5
+    (class default 21 / 7), incl. an image outside [0, 1]: only the luminance is clipped (isp/denoise.py:11-17,93-119)."""
+    g = golden("nlm_general")
+    search, patch = (int(v) for v in g[f"{tag}.sizes"])
+    out = oracle_mod.nlm_general(g[f"{tag}.img"], g[f"{tag}.h"], search, patch)
+    assert np.abs(out - g[f"{tag}.out"]).max() <= ABS_TOL
+    if tag == "s11p5":                                   # in range: the DenoiseFilter path computes the same thing
+        via_op = oracle_mod.forward(g[f"{tag}.img"], OPS["NLM"], g[f"{tag}.h"].reshape(-1, 1), clip=True)
+        assert np.array_equal(via_op, out)
+    with pytest.raises(ValueError):
+        oracle_mod.nlm_general(g[f"{tag}.img"], g[f"{tag}.h"], 4, 3)
+
+
 @pytest.mark.parametrize("tag", ["a", "small", "exact", "hd"])
 def test_pool64_bit_exact(golden, oracle_mod, tag):
     g = golden("pool64")
