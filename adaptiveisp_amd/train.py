@@ -281,7 +281,9 @@ def main(argv=None):
                           "unit": "images/sec", "n_gpus": world, "steps": timed, "warmup": min(a.warmup, n),
                           "ms_per_step": round(ms_it, 2), "iterations_per_sec": round(1e3 / ms_it, 2) if timed else None,
                           "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-                          "dtype": "bf16 detector / fp32 ISP + heads", "data": "synthetic" + (" (DRY REHEARSAL: no device)" if dry else ""),
+                          "dtype": "bf16 detector / fp32 ISP + heads", "data": "synthetic" + (" (DRY REHEARSAL: no device)" if dry else
+                                                 " (REHEARSAL: all ranks share one device over gloo; not a measurement)"
+                                                 if os.environ.get("ADAISP_DP_REHEARSAL") == "1" and world > 1 else ""),
                           "iters": timed, "ms_per_iter": round(ms_it, 2),
                           "per_gpu_batch": a.batch, "global_batch": a.batch * world, "image": f"{a.size}x{a.size}",
                           "config": {"workload": f"RL iteration (agent + value + replay + frozen YOLOv3 reward, train.py:234-351) "
