@@ -77,7 +77,10 @@ class GradBucket:
         self._check_pending()
         dev = self.params[0].device
         if self.flat is None or self.flat.device != dev:
-            self.flat = torch.zeros(self.numel + len(self.params), dtype=torch.float32, device=dev)
+            # [gradients | presence mask | 1 float: "some rank skipped an update last iteration" (see _check_pending)]
+            self.flat = torch.zeros(self.numel + len(self.params) + 1, dtype=torch.float32, device=dev)
+            self._late_dev = torch.zeros(1, dtype=torch.float32, device=dev)
+            self._late_host = torch.zeros(1, dtype=torch.float32, pin_memory=dev.type == "cuda")
             self.views, off = [], 0
             for p in self.params:                                # one view of the bucket per parameter, made once
                 self.views.append(self.flat[off:off + p.numel()].view_as(p))
@@ -88,7 +91,9 @@ class GradBucket:
         ph = self._present_host
         for i, p in enumerate(self.params):
             ph[i] = 0.0 if p.grad is None else 1.0
-        self.flat[self.numel:].copy_(ph, non_blocking=True)
+        self.flat[self.numel:self.numel + len(self.params)].copy_(ph, non_blocking=True)
+        self.flat[-1:].copy_(self._late_dev)                     # last iteration's local finding travels with this one's gradients
+        self._late_dev.zero_()
         have = [(v, p.grad) for v, p in zip(self.views, self.params) if p.grad is not None]
         absent = [v for v, p in zip(self.views, self.params) if p.grad is None]
         if have:                                                 # two multi-tensor launches instead of one copy per parameter
@@ -106,23 +111,26 @@ class GradBucket:
     # configuration data parallelism exists for. It is needed only when THIS rank lacks a gradient for a parameter that may
     # have one elsewhere. So: the set of parameters without a gradient on any rank is learned by a (blocking) read the first
     # time this rank lacks one, and afterwards a rank whose missing gradients all lie in that set reads nothing. That the
-    # set is still right is verified on the device — (mask of the set) > 0 anywhere -> a pinned flag behind an event, read
-    # one iteration later, when it has long landed: a parameter of the set that receives a gradient on another rank raises
-    # loudly (the replicas have diverged by one update) instead of drifting. ADAISP_DP_FETCH_MASK=1: read every iteration.
+    # set is still right is verified on the DEVICE: (reduced mask of the set) > 0 anywhere means this rank skipped an update
+    # another rank made. That finding (one float) rides in the NEXT iteration's bucket, so after that all-reduce every rank
+    # holds the same verdict; it is copied to pinned memory behind an event and read at the start of the iteration after —
+    # when it has long landed — where ALL ranks raise together (a raise on some ranks only would leave the others hanging in
+    # the next collective). Two iterations late, loud, and only for a case this model does not produce (the only parameters
+    # without gradients are the fc_mask heads, on every rank). ADAISP_DP_FETCH_MASK=1: read the mask every iteration.
     def _check_pending(self):
         pend, self._pending = getattr(self, "_pending", None), None
         if pend is not None:
             flag, event = pend
             if event is not None:
                 event.synchronize()
-            if bool(flag[0]):
-                raise RuntimeError("GradBucket: a parameter that had no gradient on any rank received one on another rank in the "
-                                   "previous iteration; this rank skipped its update (replicas diverged by one step). Set "
-                                   "ADAISP_DP_FETCH_MASK=1 to read the presence mask every iteration.")
+            if float(flag[0]) > 0:
+                raise RuntimeError("GradBucket: a parameter that had no gradient on any rank received one on some rank two "
+                                   "iterations ago and the ranks that lacked it skipped its update (replicas diverged by one "
+                                   "step). Set ADAISP_DP_FETCH_MASK=1 to read the presence mask every iteration.")
 
     def _fetch_anywhere(self):
         self.mask_fetches = getattr(self, "mask_fetches", 0) + 1
-        anywhere = (self.flat[self.numel:].cpu() > 0).tolist()
+        anywhere = (self.flat[self.numel:self.numel + len(self.params)].cpu() > 0).tolist()
         self._never = frozenset(i for i, a in enumerate(anywhere) if not a)
         self._never_idx = None
         return anywhere
@@ -145,14 +153,14 @@ class GradBucket:
             anywhere = None                                      # all of them are known to be absent everywhere: verify, do not wait
             if getattr(self, "_never_idx", None) is None:
                 self._never_idx = torch.tensor(sorted(never), dtype=torch.int64, device=self.flat.device) + self.numel
-                self._flag_host = torch.zeros(1, dtype=torch.bool, pin_memory=self.flat.device.type == "cuda")
-            bad = (self.flat.index_select(0, self._never_idx) > 0).any().reshape(1)
-            self._flag_host.copy_(bad, non_blocking=True)
-            event = None
-            if self.flat.is_cuda:
-                event = torch.cuda.Event()
-                event.record()
-            self._pending = (self._flag_host, event)
+            self._late_dev.copy_((self.flat.index_select(0, self._never_idx) > 0).any().reshape(1))
+        # the verdict every rank reduced in THIS iteration (what any rank found in the previous one), read one iteration on
+        self._late_host.copy_(self.flat[-1:], non_blocking=True)
+        event = None
+        if self.flat.is_cuda:
+            event = torch.cuda.Event()
+            event.record()
+        self._pending = (self._late_host, event)
         dst, src = [], []
         for i, (p, v) in enumerate(zip(self.params, self.views)):
             if p.grad is None:

@@ -253,7 +253,7 @@ def main(argv=None):
     # the collective alone: the iteration's ONE flattened gradient bucket all-reduced 5 times back to back, bracketed by a
     # pair of events on the stream it is issued from (host clock without a device) — what the xGMI ring costs per iteration
     bucket = (tr.buckets[0] if hasattr(tr, "buckets") else tr.bucket)
-    bucket_bytes = 4 * (bucket.numel + len(bucket.params))
+    bucket_bytes = 4 * (bucket.numel + len(bucket.params) + 1)       # gradients + presence mask + one status float
     ar_ms = None
     if world > 1 and bucket.flat is not None:
         reps = 5

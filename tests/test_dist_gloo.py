@@ -133,12 +133,13 @@ def _mask_worker(rank, world, port, out):
     run(False); run(False)
     assert getattr(b2, "mask_fetches", 0) == 1
     run(True)                                           # rank 0 alone produces a gradient for the "never" parameter
+    run(False)                                          # the ranks that skipped it found out on the device; the finding rides in this bucket
     raised = False
     try:
         b2._check_pending()                             # what the next iteration's all_reduce_mean() starts with
     except RuntimeError as e:
         raised = "ADAISP_DP_FETCH_MASK" in str(e)
-    assert raised == (rank != 0), (rank, raised)        # every rank that skipped the update says so
+    assert raised, (rank, raised)                       # EVERY rank raises, at the same point (no rank is left in a collective)
     out.put((rank, fetches))
     dist.destroy_process_group()
 
@@ -329,4 +330,4 @@ def test_train_gpus_n_launches_n_ranks():
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "config"):
         assert k in line, k
     assert line["steps"] == 2 and line["scaling"] == "weak" and line["config"]["parallelism"] == "dp2"
-    assert line["grad_bucket_bytes"] == 4 * (8 * 8 + 8 + 2) and line["all_reduce_ms"] > 0
+    assert line["grad_bucket_bytes"] == 4 * (8 * 8 + 8 + 2 + 1) and line["all_reduce_ms"] > 0
