@@ -41,12 +41,16 @@ def run_eval(agent, detector, batches, cfg, steps=5, conf_thres=0.001, iou_thres
             for i in range(steps):
                 pipe = None if pipeline is None else pipeline[i]
                 (retouch, states, _, _), dbg, _ = agent((retouch, noises[i], states), 1.0, None, pipe)
-                ids.append([int(v) for v in dbg["selected_filter"].detach().cpu().tolist()])
+                # the step's two host reads — the chosen filter ids (records.txt) and image 0's "stopped" state (the early
+                # exit below, val_adaptiveisp.py:302-303) — in ONE device-to-host copy: the loop is host-bound at batch 1
+                host = torch.cat([dbg["selected_filter"].detach().to(torch.float32),
+                                  states[0:1, STATE_STOPPED_DIM].detach().to(torch.float32)]).cpu().tolist()
+                ids.append([int(v) for v in host[:-1]])
                 if param_dir:
                     k = ids[-1][0]
                     params[filter_names[k]] = dbg["filter_debug_info"][k]["filter_parameters"].detach().cpu().numpy().tolist()
                     params["pipeline"].append(k)
-                if states[0][STATE_STOPPED_DIM] > 0:
+                if host[-1] > 0:
                     break
             preds = detector(retouch)
         if param_dir:
