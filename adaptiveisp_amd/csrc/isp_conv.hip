@@ -394,9 +394,7 @@ __global__ __launch_bounds__(64 * kPoolWaves) void k_conv_rows_pool(const float*
         const int ox = i & 63, w = i >> 6, oyw = oy + w;
         if (oyw > 63) break;
         const int xs = win_lo(ox, W), xe = win_hi(ox, W);
-        const float* col = colsum_lds + w * Wp;
-        float a = 0.f;
-        for (int xx = xs; xx < xe; ++xx) a += col[xx];
+        const float a = window_sum(colsum_lds + w * Wp, xs, xe);
         pooled[(((long)b * 3 + c) * 64 + oyw) * 64 + ox] = a / (float)(win_hi(oyw, H) - win_lo(oyw, H)) / (float)(xe - xs);
     }
 }

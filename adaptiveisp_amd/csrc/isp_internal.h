@@ -101,6 +101,25 @@ struct Clip {
 
 __device__ __forceinline__ float clamp01(float v) { return fminf(fmaxf(v, 0.0f), 1.0f); }
 
+// x-window sum of a pool cell from column sums in LDS, ascending x from 0.0f (k_pool64's order). The additions are a dependent
+// chain either way; when the window is a whole number of quads (W % 256 == 0: xs and the width are multiples of 4) its values
+// are fetched with 16-byte reads issued together instead of one 4-byte read per addition (a chain of ~20 LDS round trips at
+// the tail of every workgroup of the fused-pooling kernels).
+__device__ __forceinline__ float window_sum(const float* col, int xs, int xe) {
+    float a = 0.f;
+    if (((xs | xe) & 3) == 0 && xe - xs <= 64) {
+        float4 v[16];
+        const int nq = (xe - xs) >> 2;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) if (q < nq) v[q] = *reinterpret_cast<const float4*>(col + xs + 4 * q);
+#pragma unroll
+        for (int q = 0; q < 16; ++q) if (q < nq) { a += v[q].x; a += v[q].y; a += v[q].z; a += v[q].w; }
+        return a;
+    }
+    for (int xx = xs; xx < xe; ++xx) a += col[xx];
+    return a;
+}
+
 // Streaming access policy (tools/stream_ceiling.hip, profiles/round4_stream_ceiling.txt): on tensors that do not stay in the
 // 256 MB Infinity Cache a grid-stride float4 copy moves 6.2 TB/s with non-temporal loads AND stores, 5.6 with plain loads +
 // non-temporal stores, 5.2-5.4 with plain / plain (the vendor's copy: 5.1-5.2). Every pixel of the pointwise filters is read

@@ -450,9 +450,7 @@ void k_pointwise_pool(const float* __restrict__ img, float* __restrict__ out, fl
     for (int i = threadIdx.x; i < 3 * 64; i += blockDim.x) {
         const int c = i >> 6, ox = i & 63;
         const int xs = win_lo(ox, W), xe = win_hi(ox, W);
-        const float* col = colsum + c * Wp;
-        float a = 0.f;
-        for (int xx = xs; xx < xe; ++xx) a += col[xx];
+        const float a = window_sum(colsum + c * Wp, xs, xe);
         pooled[(((long)b * 3 + c) * 64 + oy) * 64 + ox] = a / kh / (float)(xe - xs);
     }
 }
