@@ -14,13 +14,52 @@ from .metrics import ap_per_class, process_batch
 from .nms import non_max_suppression
 
 
+class _EpisodeGraph:
+    """One batch's ISP episode + detector forward as ONE hipGraph replay (run_eval(graph=True)). At batch 1 the loop is bound by
+    the host — ~60 launches and one device-to-host read per RL step for 2 ms of kernels — so the fixed-shape part is captured
+    once per (batch, H, W, steps, pipeline): `steps` x Agent.forward, then the detector, with the per-step selections and image
+    0's `stopped` flags gathered on the device and read in ONE copy after the replay. The reference's early exit
+    (val_adaptiveisp.py:302-303) can only be honoured afterwards: if a flag is set before the last step the caller redoes that
+    batch with the eager loop (with the default states, `stopped` is raised on the last step only)."""
+
+    def __init__(self, agent, detector, im, noises, states, steps, pipeline):
+        self.im, self.z, self.s0 = im.clone(), noises.clone(), states.clone()
+        dev = im.device
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side), torch.no_grad():       # warm-up outside the capture (lazy initialisation, workspaces)
+            self._body(agent, detector, steps, pipeline)
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph), torch.no_grad():
+            self.retouch, self.host_view, self.preds = self._body(agent, detector, steps, pipeline)
+
+    def _body(self, agent, detector, steps, pipeline):
+        retouch, states, sel, stop = self.im, self.s0, [], []
+        for i in range(steps):
+            pipe = None if pipeline is None else pipeline[i]
+            (retouch, states, _, _), dbg, _ = agent((retouch, self.z[i], states), 1.0, None, pipe)
+            sel.append(dbg["selected_filter"].to(torch.float32))
+            stop.append(states[0:1, STATE_STOPPED_DIM].to(torch.float32))
+        preds = detector(retouch)
+        return retouch, torch.cat(sel + stop), preds
+
+    def run(self, im, noises, states):
+        self.im.copy_(im); self.z.copy_(noises); self.s0.copy_(states)
+        self.graph.replay()
+        return self.host_view.cpu().tolist()
+
+
 def run_eval(agent, detector, batches, cfg, steps=5, conf_thres=0.001, iou_thres=0.6, max_det=300, single_cls=False,
-             pipeline=None, records_path=None, nc=80, nms_fn=None, param_dir=None, details=None):
+             pipeline=None, records_path=None, nc=80, nms_fn=None, param_dir=None, details=None, graph=False):
     """Returns dict(mp, mr, map50, map75, map, seen, nt, ap_class, ap, records). `detector(x)` -> [B, N, 5+nc]
     decoded predictions (YoloEngine or the module tree in eval mode). `pipeline`: optional list of forced filter ids
     per step (val_adaptiveisp.py:292, --pipeline). `param_dir`: write one JSON per batch (named after its first image) with
     the chosen filter ids and image 0's regressed parameters per step, as `--save_param` does (:296-301,324-327).
-    `details`: a list that receives one dict per image (path, retouched image, detections after NMS, `correct` matrix)."""
+    `details`: a list that receives one dict per image (path, retouched image, detections after NMS, `correct` matrix).
+    `graph`: replay each batch's ISP episode + detector forward as one hipGraph (captured once per batch shape; HIP device,
+    eval-mode agent, no `param_dir`) — same records, detections and mAP as the eager loop, which stays the default."""
     import collections
     import json
     from ..util import get_initial_states, get_noise
@@ -28,6 +67,7 @@ def run_eval(agent, detector, batches, cfg, steps=5, conf_thres=0.001, iou_thres
     iouv = torch.linspace(0.5, 0.95, 10, device=dev)
     niou = iouv.numel()
     stats, records, seen = [], [], 0
+    graphs = {}
     filter_names = [f.get_short_name() for f in agent.filters]
     for im, targets, paths, shapes in batches:
         im = im.to(dev).float()
@@ -37,8 +77,19 @@ def run_eval(agent, detector, batches, cfg, steps=5, conf_thres=0.001, iou_thres
         states = torch.from_numpy(get_initial_states(nb, cfg.num_state_dim, len(agent.filters))).to(dev)
         retouch, ids = im, []
         params = collections.OrderedDict(pipeline=[])
+        replayed = False
+        if graph and im.is_cuda and not param_dir and not agent.training:
+            key = (tuple(im.shape), steps, None if pipeline is None else tuple(pipeline))
+            eg = graphs.get(key)
+            if eg is None:
+                eg = graphs[key] = _EpisodeGraph(agent, detector, im, noises, states, steps, pipeline)
+            host = eg.run(im, noises, states)
+            sel, stop = host[:steps * nb], host[steps * nb:]
+            if not any(v > 0 for v in stop[:-1]):                      # no early exit before the last step: the replay IS the loop
+                ids = [[int(v) for v in sel[i * nb:(i + 1) * nb]] for i in range(steps)]
+                retouch, preds, replayed = eg.retouch, eg.preds, True
         with torch.no_grad():
-            for i in range(steps):
+            for i in range(0 if not replayed else steps, steps):
                 pipe = None if pipeline is None else pipeline[i]
                 (retouch, states, _, _), dbg, _ = agent((retouch, noises[i], states), 1.0, None, pipe)
                 # the step's two host reads — the chosen filter ids (records.txt) and image 0's "stopped" state (the early
@@ -52,7 +103,8 @@ def run_eval(agent, detector, batches, cfg, steps=5, conf_thres=0.001, iou_thres
                     params["pipeline"].append(k)
                 if host[-1] > 0:
                     break
-            preds = detector(retouch)
+            if not replayed:
+                preds = detector(retouch)
         if param_dir:
             os.makedirs(param_dir, exist_ok=True)
             stem = os.path.splitext(os.path.split(str(paths[0]))[1])[0]

@@ -705,15 +705,21 @@ def extra_eval_config3(dev, images=24):
             out.append((im.pin_memory(), t, [f"img{i}.png"], [((512, 512), ((1.0, 1.0), (0.0, 0.0)))]))
         return out
     data = batches(images)
-    run_eval(agent, eng, data[:3], cfg)                      # warm-up
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    res = run_eval(agent, eng, data, cfg)
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+    out = {}
+    for key, graph in (("eager", False), ("graph", True)):  # the reference's loop launch by launch / one hipGraph replay per image
+        run_eval(agent, eng, data[:3], cfg, graph=graph)     # warm-up (and, with graph=True, a throw-away capture)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        res = run_eval(agent, eng, data, cfg, graph=graph)
+        torch.cuda.synchronize()
+        out[key] = (time.perf_counter() - t0, int(res["seen"]))
+    dt, seen = out["eager"]
+    dtg = out["graph"][0]
     return {"workload": "config 3 loop: batch 1 x 512x512, 5 ISP steps (early-exit check) + YOLOv3 + NMS + matching, synthetic frames",
-            "ms_per_image": round(dt / images * 1e3, 2), "images_per_sec": round(images / dt, 1), "images": images,
-            "seen": int(res["seen"])}
+            "ms_per_image": round(dt / images * 1e3, 2), "images_per_sec": round(images / dt, 1), "images": images, "seen": seen,
+            # run_eval(graph=True): episode + detector of an image as ONE hipGraph replay (the capture itself is inside this time:
+            # one per run_eval call) — same records / detections / mAP (tests/test_gpu_eval.py)
+            "graph_ms_per_image": round(dtg / images * 1e3, 2), "graph_images_per_sec": round(images / dtg, 1)}
 
 
 def extra_config5(dev, steps=6):

@@ -77,6 +77,51 @@ def test_run_eval_hip_path(tmp_path):
     assert len(r1["records"][0][1]) == 5
 
 
+def test_run_eval_graph_replay_equals_the_eager_loop():
+    """run_eval(graph=True): each batch's ISP episode + detector forward as one hipGraph replay (the batch-1 loop of config 3
+    is host-bound). Same records, same detections after NMS, same `correct` matrices and mAP as the eager loop — over several
+    batches of one shape (one capture, replayed) and a second shape (a second capture); and the reference's early exit still
+    wins when `stopped` is raised before the last step (steps beyond cfg.test_steps: the batch is redone eagerly)."""
+    from _synth import synth_state_dict
+    from adaptiveisp_amd.agent import Agent
+    from adaptiveisp_amd.config import cfg
+    from adaptiveisp_amd.val import run_eval
+    from adaptiveisp_amd.yolo import YoloEngine, yolov3
+    torch.manual_seed(0)
+    agent = Agent(cfg, shape=(6 + len(cfg.filters), 64, 64), device=DEV).to(DEV)
+    agent.load_state_dict(synth_state_dict(agent, seed=0))
+    agent.eval()
+    torch.manual_seed(1)
+    det = yolov3().eval()
+    engines = {(1, 128, 160): YoloEngine(det, 1, 128, 160, device=DEV), (2, 96, 128): YoloEngine(det, 2, 96, 128, device=DEV)}
+    detector = lambda x: engines[(x.shape[0], x.shape[2], x.shape[3])](x)          # noqa: E731
+    g = torch.Generator().manual_seed(9)
+    batches = []
+    for i in range(5):
+        B, H, W = (1, 128, 160) if i != 2 else (2, 96, 128)
+        t = torch.zeros(2 * B, 6)
+        t[:, 0] = torch.arange(2 * B) // 2
+        t[:, 1] = torch.randint(0, 80, (2 * B,), generator=g).float()
+        t[:, 2:4] = torch.rand(2 * B, 2, generator=g) * 0.5 + 0.25
+        t[:, 4:6] = torch.rand(2 * B, 2, generator=g) * 0.3 + 0.1
+        batches.append((torch.rand(B, 3, H, W, generator=g) * 0.6, t, [f"im{i}_{b}.png" for b in range(B)],
+                        [((H, W), ((1.0, 1.0), (0.0, 0.0)))] * B))
+    for steps in (5, 7):                                   # 7 > cfg.test_steps: `stopped` is raised at step 5 -> early exit
+        out = {}
+        for mode in (False, True):
+            np.random.seed(3)
+            det_list = []
+            out[mode] = (run_eval(agent, detector, batches, cfg, steps=steps, conf_thres=0.2, graph=mode, details=det_list), det_list)
+        (ra, da), (rb, db) = out[False], out[True]
+        assert ra["records"] == rb["records"] and ra["seen"] == rb["seen"] == 6
+        assert ra["map50"] == rb["map50"] and ra["map"] == rb["map"] and np.array_equal(ra["nt"], rb["nt"])
+        for a, b in zip(da, db):
+            assert a["path"] == b["path"] and torch.equal(a["retouch"], b["retouch"]) and torch.equal(a["pred"], b["pred"])
+            assert (a["correct"] is None and b["correct"] is None) or torch.equal(a["correct"], b["correct"])
+        if steps == 7:
+            assert all(row[5:] == ["-1", "-1"] for _, row in ra["records"])       # the loop stopped after step 5
+
+
 def _write_lod_folder(root):
     """A synthetic LOD-style folder: images/ + labels/ (YOLO txt), four PNGs of different native sizes and aspect ratios."""
     import os
