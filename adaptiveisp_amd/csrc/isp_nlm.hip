@@ -21,6 +21,9 @@
 // No barriers inside the 121-shift loop. Compute-bound on the fp32 VALU (≈3.3 kflop/px + 242
 // transcendentals per px), not on HBM (24 B/px).
 #include "isp_internal.h"
+#ifndef NLM_FMA
+#define NLM_FMA 0             // k_nlm_fwd: column sums as fused multiply-add chains (measured: see DESIGN 9)
+#endif
 #ifndef NLM_ABL
 #define NLM_ABL 0             // measurement builds of k_nlm_fwd: 1 no transcendentals, 2 no row sums, 3 no colour sums, 4 exp2 only
 #endif
@@ -498,19 +501,38 @@ __global__ __launch_bounds__(kThreads) void k_nlm_fwd(const float* __restrict__ 
     for (int dx = -SR; dx <= SR; ++dx) {
         for (int dy = -SR; dy <= SR; ++dy) {        // (unrolling the 11 y-shifts was measured: no gain)
             const v2f* ys = y2 + (rb + HY - PR - dy) * SP + lane + SR - dx;
+            float c[2 * RQ];
+#if NLM_FMA
+            // 5-row column sums as fused chains: d4^2, then fma(d3, d3, .) ... fma(d0, d0, .) — the same order of the five terms as
+            // the mul + add form below, one rounding per term instead of two: 7 sub + 3 x (1 mul + 4 fma) = 22 packed instructions
+            // per shift instead of 7 + 7 + 12 = 26 (the squares are recomputed instead of shared)
+            v2f dd[RQ + 2 * PR];
+#pragma unroll
+            for (int j = 0; j < RQ + 2 * PR; ++j) dd[j] = yc2[j] - ys[j * SP];
+#pragma unroll
+            for (int i = 0; i < RQ; ++i) {
+                v2f cc = dd[i + 4] * dd[i + 4];
+                cc = __builtin_elementwise_fma(dd[i + 3], dd[i + 3], cc);
+                cc = __builtin_elementwise_fma(dd[i + 2], dd[i + 2], cc);
+                cc = __builtin_elementwise_fma(dd[i + 1], dd[i + 1], cc);
+                cc = __builtin_elementwise_fma(dd[i], dd[i], cc);
+                c[2 * i] = cc.x;
+                c[2 * i + 1] = cc.y;
+            }
+#else
             v2f S[RQ + 2 * PR];
 #pragma unroll
             for (int j = 0; j < RQ + 2 * PR; ++j) {
                 const v2f d = yc2[j] - ys[j * SP];
                 S[j] = d * d;
             }
-            float c[2 * RQ];
 #pragma unroll
             for (int i = 0; i < RQ; ++i) {
                 const v2f cc = (((S[i + 4] + S[i + 3]) + S[i + 2]) + S[i + 1]) + S[i];
                 c[2 * i] = cc.x;
                 c[2 * i + 1] = cc.y;
             }
+#endif
             float D[2 * RQ], t1[2 * RQ], t2[2 * RQ], P[2 * RQ];
 #if NLM_ABL == 2          // measurement build: no 5-lane row sums
 #pragma unroll
