@@ -341,44 +341,42 @@ def time_isp_kernels(x0, sched, iters=24):
     outs = [torch.empty_like(x0) for _ in range(NSETS)]
     res = {"rotation_MB": round(NSETS * 2 * x0.numel() * 4 / 1e6)}
 
-    def timed(op, p, n, rotate):
+    def graph_timed(launch, n, rotate=True):
+        """ms per launch of `launch(k)` (k = buffer set), n launches captured in ONE hipGraph and replayed: the launches are
+        30-40 us kernels, and the Python binding's per-call host work (argument checks, version bumps) is of that order —
+        back-to-back eager calls measure the host, not the kernel (round 4: `with_pool_ms` read 38.6 us where the same
+        launches through bare ctypes calls took 35-36, tools/isp_step_ab.py)."""
         for k in range(NSETS):
-            _lib.process(op, ins[k], p, clip=True, out=outs[k])
+            launch(k)
+        torch.cuda.synchronize()
+        side = torch.cuda.Stream()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=side):
+            for i in range(n):
+                launch(i % NSETS if rotate else 0)
+        g.replay()
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        for i in range(n):
-            k = i % NSETS if rotate else 0
-            _lib.process(op, ins[k], p, clip=True, out=outs[k])
+        g.replay(); g.replay()
         e1.record()
         torch.cuda.synchronize()
-        return e0.elapsed_time(e1) / n
+        return e0.elapsed_time(e1) / (2 * n)
+
+    def timed(op, p, n, rotate):
+        return graph_timed(lambda k: _lib.process(op, ins[k], p, clip=True, out=outs[k]), n, rotate)
 
     pools = [torch.empty((B, 3, 64, 64), dtype=torch.float32, device=x0.device) for _ in range(NSETS)]
 
     def timed_step(op, p, n):
         """The RL step's form of the launch: host-known op + the next step's 64x64 pooling out of the same launch."""
-        for k in range(NSETS):
-            _lib.forward(ins[k], None, p, clip=True, out=outs[k], pooled=pools[k], host_op=op)
-        torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for i in range(n):
-            _lib.forward(ins[i % NSETS], None, p, clip=True, out=outs[i % NSETS], pooled=pools[i % NSETS], host_op=op)
-        e1.record()
-        torch.cuda.synchronize()
-        return e0.elapsed_time(e1) / n
+        return graph_timed(lambda k: _lib.forward(ins[k], None, p, clip=True, out=outs[k], pooled=pools[k], host_op=op), n)
 
-    for k in range(NSETS):
-        _lib.pool64(ins[k])
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for i in range(iters):
-        _lib.pool64(ins[i % NSETS])
-    e1.record()
-    torch.cuda.synchronize()
-    res["pool64"] = {"ms": round(e0.elapsed_time(e1) / iters, 4), "bytes_per_px": 12}
+    pooled_out = [None] * NSETS
+
+    def pool_launch(k):
+        pooled_out[k] = _lib.pool64(ins[k])
+    res["pool64"] = {"ms": round(graph_timed(pool_launch, iters), 4), "bytes_per_px": 12}
     for op in sorted(set(sched)):
         p = torch.rand(B, npar[op], device=x0.device) * 0.8 + 0.6
         n = 6 if op == 4 else iters
