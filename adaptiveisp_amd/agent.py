@@ -17,7 +17,7 @@ import torch.nn as nn
 from .isp.isp_function import isp_apply_selected
 from .nets import FeatureExtractor as _Trunk
 from .nets import Pool64
-from . import _lib
+from . import _lib, trunk_train
 from .util import STATE_DROPOUT_BEGIN, STATE_REWARD_DIM, STATE_STEP_DIM, STATE_STOPPED_DIM, enrich_image_input
 
 
@@ -332,8 +332,18 @@ class Agent(nn.Module):
         [B,1], new_states [B,3+F], pdf [B,F], params_table [B,F,w]) and, with `with_masks`, the list of fc_mask outputs
         (unused while masking is off, isp/filters.py:161-162)."""
         num_filters = len(self.filters)
-        net_in = enrich_image_input(self.cfg, x_down, states)
-        filter_features = self.feature_extractor(net_in)
+        sv = states if self.cfg.img_include_states else None
+        fe, sel_trunk = self.feature_extractor, self.action_selection
+        if (train and trunk_train.serves(fe, x_down, sv) and trunk_train.serves(sel_trunk, x_down, sv)
+                and not x_down.requires_grad and fe.droupout.p == sel_trunk.droupout.p):
+            # both trunks in one autograd node on the HIP kernels (csrc/isp_trunk_train.hip): 8 launches forward, 11 backward
+            # instead of ~300; the state planes are read from the vector (no concat tensor). One dropout call for both
+            # feature rows: independent masks, as two calls would draw
+            feats = torch.nn.functional.dropout(trunk_train.trunk_features([fe, sel_trunk], [x_down], [sv]), fe.droupout.p, True)
+            filter_features, selector_features = feats.unbind(0)
+        else:
+            net_in = enrich_image_input(self.cfg, x_down, states)
+            filter_features, selector_features = fe(net_in), None
 
         # every filter's heads (cheap), no pixels yet
         B = x_down.shape[0]
@@ -351,7 +361,9 @@ class Agent(nn.Module):
                                  for p in params], dim=1)                   # [B,F,width]
 
         # action selection
-        selector = self.lrelu(self.fc1(self.action_selection(net_in)))
+        if selector_features is None:
+            selector_features = sel_trunk(net_in)
+        selector = self.lrelu(self.fc1(selector_features))
         pdf = self.softmax(self.fc2(selector)) + 1e-37
         pdf = pdf * (1 - self.cfg.exploration) + self.cfg.exploration * 1.0 / num_filters
         pdf = pdf / (torch.sum(pdf, dim=1, keepdim=True) + 1e-30)

@@ -101,12 +101,16 @@ def train_iteration(cfg, agent, value, detector, loss_fn, imgs, z, states, label
             assigned = assign_labels(loss_fn, p_in, labels)      # same labels, same map shapes for both batches
             l_in = per_sample_loss(loss_fn, p_in, labels, assigned)
         l_re = per_sample_loss(loss_fn, detector(retouch), labels, assigned)
-    old_value = value(imgs, states)
-    new_value = value(retouch, new_states)
+    if hasattr(value, "forward_pair") and os.environ.get("ADAISP_CRITIC_PAIR", "1") == "1":
+        old_value, new_value = value.forward_pair(imgs, states, retouch, new_states)     # one node for both trunk passes
+    else:
+        old_value = value(imgs, states)
+        new_value = value(retouch, new_states)
     out = td_losses(cfg, l_in, l_re, penalty, surrogate, new_states, old_value, new_value,
                     torch.mean(retouch, dim=(1, 2, 3)).unsqueeze(-1), use_truncated, max_bri)
-    out["value_loss"].backward(retain_graph=False)
-    out["agent_loss"].backward(retain_graph=False)
+    # train.py:341-342 calls backward() on the two losses in turn; gradients accumulate, so one engine pass over both roots
+    # deposits the same sums (and the critic's two calls may share autograd nodes)
+    torch.autograd.backward([out["value_loss"], out["agent_loss"]])
     models = [agent, value]
     if buckets is None:
         buckets = [adist.GradBucket(*models)]

@@ -4,6 +4,7 @@ import torch.nn as nn
 
 from .nets import FeatureExtractor as _Trunk
 from .nets import Pool64
+from . import trunk_train
 
 
 class FeatureExtractor(_Trunk):
@@ -26,9 +27,8 @@ class Value(nn.Module):
         self.tanh = nn.Tanh()          # defined, not applied (as in the reference)
         self.down_sample = Pool64((shape[1], shape[2]))
 
-    def forward(self, images, states=None, pooled=None):
-        """`pooled` (optional) is a precomputed 64x64 pooling of `images` (e.g. the fused output of the
-        previous ISP step); it saves one pass over the full-resolution tensor."""
+    def _planes(self, images, states, pooled):
+        """The critic's input: the 64x64 pooling and the state vector extended by the three hand statistics."""
         small = self.down_sample(images) if pooled is None else pooled
         lum = (small[:, 0] * 0.27 + small[:, 1] * 0.67 + small[:, 2] * 0.06 + 1e-5)[:, None]
         luminance = torch.mean(lum, dim=(1, 2, 3))
@@ -43,6 +43,30 @@ class Value(nn.Module):
         else:
             assert states.dim() == stats.dim()
             states = torch.cat([states, stats], dim=1)
-        planes = states[:, :, None, None].expand(-1, -1, small.shape[2], small.shape[3])
-        feature = self.feature_extractor(torch.cat([small, planes], dim=1))
+        return small, states
+
+    def forward(self, images, states=None, pooled=None):
+        """`pooled` (optional) is a precomputed 64x64 pooling of `images` (e.g. the fused output of the
+        previous ISP step); it saves one pass over the full-resolution tensor."""
+        small, states = self._planes(images, states, pooled)
+        if trunk_train.serves(self.feature_extractor, small, states):
+            feature = trunk_train.trunk_features([self.feature_extractor], [small], [states])[0]
+        else:
+            planes = states[:, :, None, None].expand(-1, -1, small.shape[2], small.shape[3])
+            feature = self.feature_extractor(torch.cat([small, planes], dim=1))
         return self.fc2(self.lrelu(self.fc1(feature)))
+
+    def forward_pair(self, images_a, states_a, images_b, states_b):
+        """(V(images_a, states_a), V(images_b, states_b)) — the two critic calls of an RL iteration (train.py:282-283) — with
+        both trunk passes in ONE autograd node on the HIP kernels (BatchNorm statistics per call, running statistics updated
+        call by call, as two module calls would) and the two fully-connected layers on the stacked features. Falls back to two
+        plain calls when the kernels do not serve the trunk (eval mode, SyncBatchNorm, CPU)."""
+        small_a, sv_a = self._planes(images_a, states_a, None)
+        small_b, sv_b = self._planes(images_b, states_b, None)
+        fe = self.feature_extractor
+        if not (trunk_train.serves(fe, small_a, sv_a) and small_a.shape == small_b.shape and sv_a.shape == sv_b.shape):
+            return self.forward(images_a, states_a, pooled=small_a), self.forward(images_b, states_b, pooled=small_b)
+        feats = trunk_train.trunk_features([fe, fe], [small_a, small_b], [sv_a, sv_b], share_params=True)
+        B = small_a.shape[0]
+        v = self.fc2(self.lrelu(self.fc1(feats.view(2 * B, -1))))
+        return v[:B], v[B:]

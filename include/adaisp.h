@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define ADAISP_ABI_VERSION 5
+#define ADAISP_ABI_VERSION 6
 
 /* Kernel op codes. 0..9 follow the reference's default filter order (config.py:19-22). */
 enum adaisp_op {
@@ -217,6 +217,67 @@ int adaisp_policy_fc1(const float* feats, const int32_t* head_src, const float* 
 
 /* Everything after the hidden layers (see struct). `args` is a HOST struct holding DEVICE pointers. */
 int adaisp_policy_finish(const adaisp_policy_finish_args* args, int B, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * Training-mode trunk of the policy / critic networks (FeatureExtractor, agent.py:26-60 / value.py:6-44, in train
+ * mode as train.py:258,282-283 runs them): [Conv2d(k4 s2 p1) -> BatchNorm2d(batch statistics) -> LeakyReLU(0.2)] x 4
+ * on a 64x64 input, forward and backward, fp32. One call serves G <= 2 trunk INSTANCES:
+ *   the agent's two trunks (feature_extractor + action_selection: same input, two parameter sets), or
+ *   the critic's two calls of an iteration (V(imgs, states), V(retouch, new_states): two inputs, ONE parameter set —
+ *   pass the same `adaisp_trunk_params` twice and share_params = 1: statistics stay per instance, the running
+ *   statistics are updated in instance order and the parameter gradients are the sum over instances, in that order).
+ * Layer-1 input of instance g: the 3 planes img[g] [B,3,64,64] followed by svec[g] [B,n_state] as constant planes
+ * (enrich_image_input, util.py:58-63; for the critic the state vector with its three hand statistics, value.py:65-80).
+ * Channels: C[0] = 3 + n_state, C[1..4] the four conv widths (C[1..4] % 16 == 0). Output feat [G][B][C[4]*16] =
+ * the last activation flattened channel-major (agent.py:57 reshape). Every reduction (batch statistics, their
+ * backward sums, weight gradients) runs in a fixed order: results are bit-reproducible run to run.
+ * `workspace` keeps what backward needs (pre-BatchNorm outputs, activations, mean / rstd); `scratch` holds backward
+ * temporaries. Sizes: adaisp_trunk_train_workspace_bytes / _scratch_bytes.
+ * --------------------------------------------------------------------------------------------------------- */
+#define ADAISP_TRUNK_MAX_G 2
+#define ADAISP_TRUNK_LAYERS 4
+
+typedef struct adaisp_trunk_params {
+    const float* w[ADAISP_TRUNK_LAYERS];        /* [C[l+1]][C[l]][4][4]                              */
+    const float* bias[ADAISP_TRUNK_LAYERS];     /* [C[l+1]]                                          */
+    const float* gamma[ADAISP_TRUNK_LAYERS];    /* BatchNorm weight                                  */
+    const float* beta[ADAISP_TRUNK_LAYERS];     /* BatchNorm bias                                    */
+    float* running_mean[ADAISP_TRUNK_LAYERS];   /* updated in place by the forward (NULL: left alone) */
+    float* running_var[ADAISP_TRUNK_LAYERS];
+} adaisp_trunk_params;
+
+typedef struct adaisp_trunk_grads {             /* every tensor written (not accumulated into)       */
+    float* w[ADAISP_TRUNK_LAYERS];
+    float* bias[ADAISP_TRUNK_LAYERS];
+    float* gamma[ADAISP_TRUNK_LAYERS];
+    float* beta[ADAISP_TRUNK_LAYERS];
+} adaisp_trunk_grads;
+
+typedef struct adaisp_trunk_args {
+    int32_t G, B, n_state, share_params;
+    int32_t C[ADAISP_TRUNK_LAYERS + 1];
+    float momentum, eps, slope;                 /* BatchNorm momentum / eps, LeakyReLU slope          */
+    const float* img[ADAISP_TRUNK_MAX_G];
+    const float* svec[ADAISP_TRUNK_MAX_G];
+    adaisp_trunk_params p[ADAISP_TRUNK_MAX_G];
+    float* feat;                                /* forward output [G][B][C[4]*16]                     */
+    float* workspace;
+    size_t workspace_bytes;
+    /* backward only */
+    const float* dfeat;                         /* [G][B][C[4]*16]                                    */
+    adaisp_trunk_grads g[ADAISP_TRUNK_MAX_G];   /* share_params: g[0] only                            */
+    float* dimg[ADAISP_TRUNK_MAX_G];            /* [B,3,64,64] or NULL (input gradient not wanted)    */
+    float* dsvec[ADAISP_TRUNK_MAX_G];           /* [B,n_state] or NULL (both or neither per instance) */
+    float* scratch;
+    size_t scratch_bytes;
+} adaisp_trunk_args;
+
+size_t adaisp_trunk_train_workspace_bytes(const adaisp_trunk_args* args);
+size_t adaisp_trunk_train_scratch_bytes(const adaisp_trunk_args* args);
+/* `args` is a HOST struct holding DEVICE pointers. 8 launches. */
+int adaisp_trunk_train_fwd(const adaisp_trunk_args* args, void* stream);
+/* After adaisp_trunk_train_fwd with the same args / workspace. 11-13 launches. */
+int adaisp_trunk_train_bwd(const adaisp_trunk_args* args, void* stream);
 
 /* Number of regressed parameters an op reads per image (0 for ADAISP_OP_ZERO, -1 if unknown). */
 int adaisp_num_params(int op);
