@@ -25,6 +25,8 @@ ABI_VERSION = 6
 EXPORTS = ("adaisp_forward", "adaisp_forward_uniform", "adaisp_process", "adaisp_backward_params", "adaisp_pool64", "adaisp_pool64_backward", "adaisp_demosaic", "adaisp_nlm_general", "adaisp_nlm_general_workspace_bytes", "adaisp_num_params",
            "adaisp_policy_conv", "adaisp_policy_fc1", "adaisp_policy_finish",
            "adaisp_trunk_train_fwd", "adaisp_trunk_train_bwd", "adaisp_trunk_train_workspace_bytes", "adaisp_trunk_train_scratch_bytes",
+           "adaisp_critic_planes_fwd", "adaisp_critic_planes_bwd", "adaisp_td_fwd", "adaisp_td_bwd",
+           "adaisp_policy_tail_fwd", "adaisp_policy_tail_bwd",
            "adaisp_strerror", "adaisp_abi_version")
 
 _lib = None
@@ -58,7 +60,8 @@ def load():
     L.adaisp_nlm_general.restype = ci
     L.adaisp_nlm_general_workspace_bytes.argtypes = [ci, ci, ci]
     L.adaisp_nlm_general_workspace_bytes.restype = ctypes.c_size_t
-    for name in ("adaisp_trunk_train_fwd", "adaisp_trunk_train_bwd"):
+    for name in ("adaisp_trunk_train_fwd", "adaisp_trunk_train_bwd", "adaisp_critic_planes_fwd", "adaisp_critic_planes_bwd",
+                 "adaisp_td_fwd", "adaisp_td_bwd", "adaisp_policy_tail_fwd", "adaisp_policy_tail_bwd"):
         getattr(L, name).argtypes = [vp, vp]
         getattr(L, name).restype = ci
     for name in ("adaisp_trunk_train_workspace_bytes", "adaisp_trunk_train_scratch_bytes"):

@@ -226,9 +226,8 @@ class Agent(nn.Module):
             raise ValueError("current just support shared_feature_extractor")
         x_down = self.down_sample(x)
         coef = (1.0 - progress) * self.cfg.exploration_penalty
-        coef_t = torch.full((1,), coef, dtype=torch.float32, device=x.device)
         res = self.policy_heads(
-            x_down, z[:, 0:1], states, coef_t, train=bool(train), forced_id=selected_filter_id, with_masks=not train)
+            x_down, z[:, 0:1], states, coef, train=bool(train), forced_id=selected_filter_id, with_masks=not train)
         packed, op_ids, selected, surrogate, penalty, new_states, pdf, table = res[:8]
         masks = res[8] if len(res) > 8 else None            # fc_mask outputs: eval only (unused while masking is off)
 
@@ -302,7 +301,8 @@ class Agent(nn.Module):
                                     rows=torch.tensor(rows, dtype=torch.int64, device=device))
         return c
 
-    def _heads_batched(self, features):
+    def _heads_pre(self, features):
+        """Pre-activations [B,F,width] of every filter's fc_filter (zero-padded slots), ten heads as three matmuls."""
         c = self._head_consts(features.device)
         F, pw, B = len(self.filters), self._param_width, features.shape[0]
         hid = self.cfg.fc1_size
@@ -313,7 +313,11 @@ class Agent(nn.Module):
         br = torch.cat([f.fc_filter.bias for f in self.filters], 0)
         wf = wr.new_zeros(F * pw, hid).index_copy(0, c["rows"], wr).view(F, pw, hid)
         bf = br.new_zeros(F * pw).index_copy(0, c["rows"], br).view(F, 1, pw)
-        x = torch.baddbmm(bf, hidden.transpose(0, 1), wf.transpose(1, 2)).transpose(0, 1)      # [B,F,pw]
+        return torch.baddbmm(bf, hidden.transpose(0, 1), wf.transpose(1, 2)).transpose(0, 1)      # [B,F,pw]
+
+    def _heads_batched(self, features):
+        c = self._head_consts(features.device)
+        x = self._heads_pre(features)
         base = (torch.tanh(x * c["keep"] + c["bias"]) * 0.5 + 0.5) * c["scale"] + c["lo"]       # tanh_range (isp/filters.py:25-34)
         out = torch.where(c["is_exp"], torch.exp(base), base)               # gamma, white balance
         out = torch.where(c["is_sig"], torch.sigmoid(x), out)               # NLM, S+, BW
@@ -348,7 +352,17 @@ class Agent(nn.Module):
         # every filter's heads (cheap), no pixels yet
         B = x_down.shape[0]
         masks = []
-        if train and not with_masks and self.batched_heads and self._head_consts(x_down.device) is not None:
+        batched = train and not with_masks and self.batched_heads and self._head_consts(x_down.device) is not None
+        if batched and x_down.is_cuda and isinstance(entropy_coef, (int, float)):
+            # regressors, pdf, sampling, surrogate, gather, state update, penalties: one launch each way (policy_train.py)
+            from . import policy_train
+            x = self._heads_pre(filter_features)
+            if selector_features is None:
+                selector_features = sel_trunk(net_in)
+            logits = self.fc2(self.lrelu(self.fc1(selector_features)))
+            if policy_train.serves(self, x, logits, entropy_coef):
+                return policy_train.policy_tail(self, x, logits, noise, states, entropy_coef, sample=True, forced_id=forced_id)
+        if batched:
             table = self._heads_batched(filter_features)                    # [B,F,width], ten heads as three matmuls
         else:
             params = []

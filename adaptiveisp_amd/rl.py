@@ -5,6 +5,7 @@ The literal semantics are kept, including the `truncated` flag: the bootstrap te
 (1 - truncated) where truncated = 1 for images whose mean brightness is inside (0.01, max_bri), i.e. the value
 bootstrap survives only for too-dark / too-bright results (train.py:287-291).
 """
+import ctypes
 import os
 
 import torch
@@ -12,11 +13,81 @@ import torch
 from .util import STATE_STEP_DIM, STATE_STOPPED_DIM
 
 
+class _TdArgs(ctypes.Structure):
+    _fields_ = ([(k, ctypes.c_int32) for k in ("B", "state_dim", "use_penalty", "use_truncated", "use_td")] +
+                [(k, ctypes.c_float) for k in ("detect_loss_weight", "all_reward", "critic_logit_multiplier", "discount_factor",
+                                               "parameter_lr_mul", "maximum_trajectory_length", "max_bri")] +
+                [(k, ctypes.c_void_p) for k in ("l_in", "l_re", "penalty", "surrogate", "new_states", "old_value", "new_value",
+                                                "retouch_mean", "reward", "q_value", "advantage", "losses", "dlosses",
+                                                "d_l_re", "d_penalty", "d_surrogate", "d_old_value", "d_new_value")])
+
+
+class _TdFn(torch.autograd.Function):
+    """td_losses as one launch forward and one backward (csrc/isp_rl_train.hip): ~40 + ~60 ATen launches on B floats."""
+
+    @staticmethod
+    def forward(ctx, consts, l_in, l_re, penalty, surrogate, new_states, old_value, new_value, retouch_mean):
+        from . import _lib
+        L = _lib.load()
+        B = int(new_states.shape[0])
+        ins = [t.contiguous() for t in (l_in, l_re, penalty, surrogate, new_states, old_value, new_value, retouch_mean)]
+        a = _TdArgs()
+        a.B, a.state_dim = B, int(new_states.shape[1])
+        for k, v in consts.items():
+            setattr(a, k, v)
+        for k, t in zip(("l_in", "l_re", "penalty", "surrogate", "new_states", "old_value", "new_value", "retouch_mean"), ins):
+            setattr(a, k, t.data_ptr())
+        out = torch.empty((3, B, 1), dtype=torch.float32, device=new_states.device)
+        losses = torch.empty((2,), dtype=torch.float32, device=new_states.device)
+        a.reward, a.q_value, a.advantage, a.losses = out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr(), losses.data_ptr()
+        with torch.cuda.device(new_states.device):
+            _lib._check(L.adaisp_td_fwd(ctypes.byref(a), _lib._stream()), "adaisp_td_fwd")
+        ctx.a, ctx.keep = a, ins
+        reward, q_value, advantage = out.unbind(0)
+        value_loss, agent_loss = losses.unbind(0)
+        ctx.mark_non_differentiable(reward, q_value, advantage)
+        return reward, q_value, advantage, value_loss, agent_loss
+
+    @staticmethod
+    def backward(ctx, _r, _q, _a, g_value, g_agent):
+        from . import _lib
+        L = _lib.load()
+        a, ins = ctx.a, ctx.keep
+        dev = ins[4].device
+        zero = None
+        if g_value is None or g_agent is None:
+            zero = torch.zeros((), dtype=torch.float32, device=dev)
+        dl = torch.stack([zero if g_value is None else g_value, zero if g_agent is None else g_agent])
+        d = torch.empty((5, a.B, 1), dtype=torch.float32, device=dev)
+        a.dlosses = dl.data_ptr()
+        a.d_l_re, a.d_penalty, a.d_surrogate, a.d_old_value, a.d_new_value = (d[i].data_ptr() for i in range(5))
+        with torch.cuda.device(dev):
+            _lib._check(L.adaisp_td_bwd(ctypes.byref(a), _lib._stream()), "adaisp_td_bwd")
+        d_l_re, d_pen, d_sur, d_old, d_new = (d[i].view_as(t) for i, t in zip(range(5), (ins[1], ins[2], ins[3], ins[5], ins[6])))
+        return None, None, d_l_re, d_pen, d_sur, None, d_old, d_new, None
+
+
+def _td_kernel_serves(*tensors):
+    return (os.environ.get("ADAISP_TD_KERNEL", "1") == "1"
+            and all(t.is_cuda and t.dtype == torch.float32 for t in tensors)
+            and all(t.numel() == tensors[0].numel() for t in tensors))
+
+
 def td_losses(cfg, detect_input_loss, detect_retouch_loss, penalty, surrogate, new_states, old_value, new_value,
               retouch_mean, use_truncated=True, max_bri=0.9):
     """All inputs [B,1] except new_states [B,3+F]. Returns dict(reward, q_value, advantage, value_loss, agent_loss).
 
     detect_*_loss are the per-sample detection losses BEFORE weighting/clipping (train.py:264-271)."""
+    if new_states.is_cuda and new_states.dtype == torch.float32 and _td_kernel_serves(
+            detect_input_loss, detect_retouch_loss, penalty, surrogate, old_value, new_value, retouch_mean):
+        consts = dict(use_penalty=int(bool(cfg.use_penalty)), use_truncated=int(bool(use_truncated)), use_td=int(bool(cfg.use_TD)),
+                      detect_loss_weight=float(cfg.detect_loss_weight), all_reward=float(cfg.all_reward),
+                      critic_logit_multiplier=float(cfg.critic_logit_multiplier), discount_factor=float(cfg.discount_factor),
+                      parameter_lr_mul=float(cfg.parameter_lr_mul),
+                      maximum_trajectory_length=float(cfg.maximum_trajectory_length), max_bri=float(max_bri))
+        reward, q_value, advantage, value_loss, agent_loss = _TdFn.apply(
+            consts, detect_input_loss, detect_retouch_loss, penalty, surrogate, new_states, old_value, new_value, retouch_mean)
+        return dict(reward=reward, q_value=q_value, advantage=advantage, value_loss=value_loss, agent_loss=agent_loss)
     l_in = torch.clip(detect_input_loss * cfg.detect_loss_weight, 0, 1.0)
     l_re = torch.clip(detect_retouch_loss * cfg.detect_loss_weight, 0, 1.0)
     stopped = new_states[:, STATE_STOPPED_DIM:STATE_STOPPED_DIM + 1]

@@ -48,25 +48,29 @@ class Value(nn.Module):
     def forward(self, images, states=None, pooled=None):
         """`pooled` (optional) is a precomputed 64x64 pooling of `images` (e.g. the fused output of the
         previous ISP step); it saves one pass over the full-resolution tensor."""
-        small, states = self._planes(images, states, pooled)
-        if trunk_train.serves(self.feature_extractor, small, states):
-            feature = trunk_train.trunk_features([self.feature_extractor], [small], [states])[0]
+        fe = self.feature_extractor
+        small = self.down_sample(images) if pooled is None else pooled
+        if trunk_train.serves(fe, small, states, extra=3):
+            # statistics + trunk, forward and backward, in one autograd node on the HIP kernels
+            feature = trunk_train.trunk_features([fe], [small], [states], critic_planes=True)[0]
         else:
+            small, states = self._planes(images, states, small)
             planes = states[:, :, None, None].expand(-1, -1, small.shape[2], small.shape[3])
-            feature = self.feature_extractor(torch.cat([small, planes], dim=1))
+            feature = fe(torch.cat([small, planes], dim=1))
         return self.fc2(self.lrelu(self.fc1(feature)))
 
     def forward_pair(self, images_a, states_a, images_b, states_b):
         """(V(images_a, states_a), V(images_b, states_b)) — the two critic calls of an RL iteration (train.py:282-283) — with
-        both trunk passes in ONE autograd node on the HIP kernels (BatchNorm statistics per call, running statistics updated
-        call by call, as two module calls would) and the two fully-connected layers on the stacked features. Falls back to two
-        plain calls when the kernels do not serve the trunk (eval mode, SyncBatchNorm, CPU)."""
-        small_a, sv_a = self._planes(images_a, states_a, None)
-        small_b, sv_b = self._planes(images_b, states_b, None)
+        both statistics + trunk passes in ONE autograd node on the HIP kernels (BatchNorm statistics per call, running
+        statistics updated call by call, as two module calls would) and the two fully-connected layers on the stacked
+        features. Falls back to two plain calls when the kernels do not serve the trunk (eval mode, SyncBatchNorm, CPU)."""
         fe = self.feature_extractor
-        if not (trunk_train.serves(fe, small_a, sv_a) and small_a.shape == small_b.shape and sv_a.shape == sv_b.shape):
+        small_a, small_b = self.down_sample(images_a), self.down_sample(images_b)
+        if not (trunk_train.serves(fe, small_a, states_a, extra=3) and small_a.shape == small_b.shape
+                and (states_a is None) == (states_b is None) and (states_a is None or states_a.shape == states_b.shape)):
             return self.forward(images_a, states_a, pooled=small_a), self.forward(images_b, states_b, pooled=small_b)
-        feats = trunk_train.trunk_features([fe, fe], [small_a, small_b], [sv_a, sv_b], share_params=True)
+        feats = trunk_train.trunk_features([fe, fe], [small_a, small_b], [states_a, states_b], share_params=True,
+                                           critic_planes=True)
         B = small_a.shape[0]
         v = self.fc2(self.lrelu(self.fc1(feats.view(2 * B, -1))))
         return v[:B], v[B:]

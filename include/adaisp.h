@@ -279,6 +279,75 @@ int adaisp_trunk_train_fwd(const adaisp_trunk_args* args, void* stream);
 /* After adaisp_trunk_train_fwd with the same args / workspace. 11-13 launches. */
 int adaisp_trunk_train_bwd(const adaisp_trunk_args* args, void* stream);
 
+/*
+ * The critic's hand statistics (value.py:65-80) of G <= 2 batches of 64x64 planes `small` [B,3,64,64]:
+ *   svec[b] = [states[b][0..n_state), mean luminance, luminance variance (unbiased, torch.var), mean saturation]
+ * i.e. the state vector the critic's trunk reads as constant planes. Backward: dsmall = dsmall_in (or 0) + the gradient
+ * of the three statistics given dsvec [B,n_state+3] (torch's rules: clip passes on the closed interval, max / min over
+ * channels give the first index on ties, minimum splits a tie); dsmall may alias dsmall_in; instances with
+ * dsmall[g] == NULL are skipped. One launch each.
+ */
+typedef struct adaisp_critic_planes_args {
+    int32_t G, B, n_state;
+    const float* small[ADAISP_TRUNK_MAX_G];
+    const float* states[ADAISP_TRUNK_MAX_G];      /* [B,n_state] (NULL when n_state == 0) */
+    float* svec[ADAISP_TRUNK_MAX_G];              /* [B,n_state+3]                        */
+    /* backward only */
+    const float* dsvec[ADAISP_TRUNK_MAX_G];
+    const float* dsmall_in[ADAISP_TRUNK_MAX_G];
+    float* dsmall[ADAISP_TRUNK_MAX_G];
+} adaisp_critic_planes_args;
+int adaisp_critic_planes_fwd(const adaisp_critic_planes_args* args, void* stream);
+int adaisp_critic_planes_bwd(const adaisp_critic_planes_args* args, void* stream);
+
+/*
+ * Reward / TD target / losses of one RL iteration (train.py:262-305): per-sample vectors of B floats in, the per-sample
+ * reward / q_value / advantage and losses = [value_loss, agent_loss] out; backward from dlosses [2] to the five inputs
+ * that carry gradients. The same operation order as the element-wise reference arithmetic. One launch each.
+ */
+typedef struct adaisp_td_args {
+    int32_t B, state_dim;                          /* new_states [B,state_dim]: [., stopped, step, usage...] */
+    int32_t use_penalty, use_truncated, use_td;
+    float detect_loss_weight, all_reward, critic_logit_multiplier, discount_factor, parameter_lr_mul,
+          maximum_trajectory_length, max_bri;
+    const float *l_in, *l_re, *penalty, *surrogate, *new_states, *old_value, *new_value, *retouch_mean;
+    float *reward, *q_value, *advantage, *losses;
+    /* backward only */
+    const float* dlosses;
+    float *d_l_re, *d_penalty, *d_surrogate, *d_old_value, *d_new_value;
+} adaisp_td_args;
+int adaisp_td_fwd(const adaisp_td_args* args, void* stream);
+int adaisp_td_bwd(const adaisp_td_args* args, void* stream);
+
+/*
+ * The policy's tail in TRAINING mode (agent.py:103-149, 234-280): from the heads' pre-activations x [B][F][param_width]
+ * (fc_filter outputs, zero-padded slots) and the selector's logits [B][F] to everything Agent.forward hands on — the regressed
+ * parameter table, pdf, sampled / forced selection, surrogate, packed row + op code for adaisp_forward, state update, penalty —
+ * with the arithmetic of adaisp_policy_finish; and its backward: d_x (non-zero on the selected filter's row only: nothing else
+ * reaches the pixels) and d_logits from d_packed [B][param_width], d_surrogate [B], d_penalty [B] (any may be NULL = zero).
+ * One launch each.
+ */
+typedef struct adaisp_policy_tail_args {
+    int32_t B, num_filters, param_width, noise_stride;
+    int32_t sample;            /* 1: pdf_sample with noise[b][0] (training), 0: argmax                 */
+    int32_t forced_id;         /* >= 0: teacher-forced selected_filter_id                              */
+    float one_minus_exploration, exploration_over_f, entropy_coef, log_num_filters, test_steps, filter_usage_penalty,
+          early_stop_penalty, runtime_lambda;
+    adaisp_regressor reg[ADAISP_POLICY_MAX_FILTERS];
+    const float *x, *logits, *noise, *states, *runtime;       /* runtime [F] or NULL                   */
+    float* table;              /* [B][F][param_width] regressed parameters of every filter              */
+    float* packed;             /* [B][param_width]                                                      */
+    int32_t* op_ids;           /* [B]                                                                   */
+    long long* selected;       /* [B]  (read by the backward)                                           */
+    float* pdf;                /* [B][F] (read by the backward)                                         */
+    float *surrogate, *new_states, *penalty;                  /* [B], [B][3+F], [B]                    */
+    /* backward only */
+    const float *d_packed, *d_surrogate, *d_penalty;
+    float *d_x, *d_logits;
+} adaisp_policy_tail_args;
+int adaisp_policy_tail_fwd(const adaisp_policy_tail_args* args, void* stream);
+int adaisp_policy_tail_bwd(const adaisp_policy_tail_args* args, void* stream);
+
 /* Number of regressed parameters an op reads per image (0 for ADAISP_OP_ZERO, -1 if unknown). */
 int adaisp_num_params(int op);
 

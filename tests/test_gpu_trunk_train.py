@@ -154,3 +154,185 @@ def test_unserved_trunks_are_reported():
     assert not trunk_train.serves(sync, img, sv)
     with pytest.raises(Exception):
         trunk_train.trunk_features([sync], [img], [sv])
+
+
+# ---- the critic's statistics + trunk as one node, and the TD arithmetic kernel (csrc/isp_rl_train.hip) --------------------
+def _value_net(dev, seed=3):
+    from adaptiveisp_amd.config import cfg
+    from adaptiveisp_amd.value import Value
+    torch.manual_seed(seed)
+    return Value(cfg, shape=(9 + len(cfg.filters), 64, 64)).to(dev).train()
+
+
+def _edge_images(B, H, seed, dev):
+    """Images whose 64x64 pooling holds what the statistics' backward has rules for: saturated blocks (ties of max / min
+    over channels at exactly 1.0 / 0.0), values outside [0,1], grey pixels (max == min)."""
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    x = torch.rand((B, 3, H, H), generator=g) * 1.3 - 0.15
+    x[:, :, : H // 4, : H // 4] = 1.0
+    x[:, :2, H // 4: H // 2, : H // 4] = 1.0
+    x[:, :, : H // 4, H // 4: H // 2] = 0.0
+    x[:, :, H // 2:, : H // 8] = x[:, :1, H // 2:, : H // 8]            # grey
+    x[:, 0, -H // 8:, -H // 8:] = 0.75
+    x[:, 1, -H // 8:, -H // 8:] = 0.25                                   # max + min == 1 exactly: the minimum's tie
+    x[:, 2, -H // 8:, -H // 8:] = 0.5
+    return x.to(dev)
+
+
+@pytest.mark.parametrize("pair", [False, True])
+def test_critic_node_matches_the_module_path(pair, monkeypatch):
+    """Value.forward / forward_pair (statistics + trunk in one node) against the ATen path (value.py:61-81): values, the
+    gradient at the full-resolution image (through the pooling), every parameter gradient, the buffers."""
+    dev = torch.device("cuda:0")
+    B, H, S = 8, 128, 13
+    ours = _value_net(dev)
+    ref = copy.deepcopy(ours)
+    g = torch.Generator(device="cpu").manual_seed(5)
+    img_a = torch.rand((B, 3, H, H), generator=g).to(dev)
+    st_a, st_b = torch.rand((B, S), generator=g).to(dev), torch.rand((B, S), generator=g).to(dev)
+    img_b = _edge_images(B, H, 6, dev).requires_grad_(True)
+    img_br = img_b.detach().clone().requires_grad_(True)
+    if pair:
+        va, vb = ours.forward_pair(img_a, st_a, img_b, st_b)
+    else:
+        va, vb = ours(img_a, st_a), ours(img_b, st_b)
+    monkeypatch.setenv("ADAISP_TRUNK_KERNELS", "0")
+    ra, rb = ref(img_a, st_a), ref(img_br, st_b)
+    monkeypatch.setenv("ADAISP_TRUNK_KERNELS", "1")
+    close_scaled("trunk_train.value.out", torch.cat([va, vb]), torch.cat([ra, rb]), frac=2e-5)
+    w = torch.linspace(-1.0, 1.0, 2 * B, device=dev)[:, None]
+    (torch.cat([va, vb]) * w).sum().backward()
+    (torch.cat([ra, rb]) * w).sum().backward()
+    close_scaled("trunk_train.value.grad_image", img_b.grad, img_br.grad, frac=2e-4, floor=1e-12)
+    for (name, pg), (_, pr) in zip(ours.named_parameters(), ref.named_parameters()):
+        if name.startswith("feature_extractor"):
+            continue
+        close_scaled("trunk_train.value.grad_fc", pg.grad, pr.grad, frac=2e-4, floor=1e-9, err_msg=name)
+    _compare_params("value", ours.feature_extractor, ref.feature_extractor)
+
+
+def test_critic_statistics_kernel_alone():
+    """adaisp_critic_planes_fwd / _bwd against Value._planes under autograd on the edge-case planes."""
+    from adaptiveisp_amd import trunk_train
+    dev = torch.device("cuda:0")
+    B, S = 4, 5
+    net = _value_net(dev)
+    small = torch.nn.functional.adaptive_avg_pool2d(_edge_images(B, 128, 8, dev), (64, 64)).contiguous()
+    st = torch.rand((B, S), device=dev)
+    s_ref = small.clone().requires_grad_(True)
+    _, ext_ref = net._planes(None, st, s_ref)
+    L = trunk_train._lib.load()
+    a = trunk_train._PlanesArgs()
+    ext = torch.empty((B, S + 3), device=dev)
+    a.G, a.B, a.n_state = 1, B, S
+    a.small[0], a.states[0], a.svec[0] = small.data_ptr(), st.data_ptr(), ext.data_ptr()
+    import ctypes
+    assert L.adaisp_critic_planes_fwd(ctypes.byref(a), None) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(ext[:, :S], st)
+    close_scaled("trunk_train.planes.stats", ext[:, S:], ext_ref[:, S:], frac=2e-6)
+    dext = torch.randn((B, S + 3), device=dev)
+    ext_ref.backward(dext)
+    base = torch.randn_like(small)
+    dsmall = base.clone()
+    a.dsvec[0], a.dsmall_in[0], a.dsmall[0] = dext.data_ptr(), dsmall.data_ptr(), dsmall.data_ptr()
+    assert L.adaisp_critic_planes_bwd(ctypes.byref(a), None) == 0
+    torch.cuda.synchronize()
+    close_scaled("trunk_train.planes.grad", dsmall - base, s_ref.grad, frac=2e-5, floor=1e-12)
+
+
+@pytest.mark.parametrize("use_td,use_truncated,use_penalty", [(True, True, True), (False, True, True), (True, False, False)])
+def test_td_kernel_matches_the_elementwise_arithmetic(use_td, use_truncated, use_penalty, monkeypatch):
+    from adaptiveisp_amd import rl
+    from adaptiveisp_amd.config import cfg as base_cfg
+    from adaptiveisp_amd.util import Dict
+    dev = torch.device("cuda:0")
+    cfg = Dict(base_cfg)
+    cfg.use_TD, cfg.use_penalty, cfg.all_reward, cfg.detect_loss_weight, cfg.discount_factor = use_td, use_penalty, 0.7, 1.5, 0.9
+    B, F = 16, len(base_cfg.filters)
+    g = torch.Generator(device="cpu").manual_seed(3)
+    r = lambda *sh: torch.rand(sh, generator=g)          # noqa: E731
+    new_states = torch.cat([r(B, 1).round(), r(B, 1).round(), (r(B, 1) * 10).floor(), r(B, F).round()], dim=1).to(dev)
+    retouch_mean = torch.tensor([0.005, 0.95] + [0.4] * (B - 2))[:, None].to(dev)
+    leaves = {k: v.to(dev).requires_grad_(True) for k, v in dict(
+        l_re=r(B, 1) * 1.2 - 0.1, penalty=r(B, 1), surrogate=-r(B, 1) * 3, old_value=r(B, 1) * 4 - 2, new_value=r(B, 1) * 4 - 2).items()}
+    l_in = (r(B, 1) * 1.2 - 0.1).to(dev)
+    outs = []
+    for kernel in ("1", "0"):
+        monkeypatch.setenv("ADAISP_TD_KERNEL", kernel)
+        for v in leaves.values():
+            v.grad = None
+        o = rl.td_losses(cfg, l_in, leaves["l_re"], leaves["penalty"], leaves["surrogate"], new_states, leaves["old_value"],
+                         leaves["new_value"], retouch_mean, use_truncated=use_truncated, max_bri=0.9)
+        torch.autograd.backward([o["value_loss"] * 0.5, o["agent_loss"] * 2.0])
+        outs.append(({k: o[k].detach().clone() for k in o},
+                     {k: (torch.zeros_like(v) if v.grad is None else v.grad.clone()) for k, v in leaves.items()}))
+    for k in outs[0][0]:
+        close_scaled(f"trunk_train.td.{k}", outs[0][0][k], outs[1][0][k], frac=2e-6, floor=1e-6)
+    for k in leaves:
+        close_scaled(f"trunk_train.td.grad_{k}", outs[0][1][k], outs[1][1][k], frac=2e-6, floor=1e-9)
+
+
+# ---- the agent's training step with trunk + tail kernels against the ATen path ---------------------------------------------
+def _train_agent(dev):
+    from _synth import synth_state_dict
+    from adaptiveisp_amd.agent import Agent
+    from adaptiveisp_amd.config import cfg
+    ag = Agent(cfg, shape=(6 + len(cfg.filters), 64, 64), device=dev)
+    ag.load_state_dict(synth_state_dict(ag, seed=0))
+    ag = ag.to(dev).train()
+    ag.feature_extractor.droupout.p = ag.action_selection.droupout.p = 0.0      # (the two paths draw different masks)
+    return ag, cfg
+
+
+@pytest.mark.parametrize("forced", [None, 9, 4])
+def test_agent_training_step_kernels_match_the_module_path(forced, monkeypatch):
+    """Agent.forward in train mode (agent.py:88-285) with the trunk pair and the policy tail on the HIP kernels, against the
+    same step on ATen (ADAISP_TRUNK_KERNELS=0, ADAISP_POLICY_TAIL_KERNEL=0): identical selections, the outputs and — through a
+    loss on (retouch, surrogate, penalty) — every parameter gradient."""
+    from _synth import test_image
+    dev = torch.device("cuda:0")
+    ours, cfg = _train_agent(dev)
+    ref = copy.deepcopy(ours)
+    B = 8
+    x = torch.from_numpy(test_image(B, 96, 128, seed=5, special=False)).to(dev)
+    g = torch.Generator().manual_seed(3)
+    z = torch.rand(B, cfg.z_dim, generator=g).to(dev)
+    z[0, 0], z[1, 0] = 0.0, 0.999999                                    # the all-zero one-hot and the last filter
+    states = torch.zeros(B, cfg.num_state_dim, device=dev)
+    states[:, 2] = torch.arange(B, device=dev) % 5
+    states[:, 3:] = (torch.rand(B, len(cfg.filters), generator=g) < 0.3).float().to(dev)
+    w = torch.rand(x.shape, generator=g).to(dev)
+
+    def run(ag):
+        (y, ns, sur, pen), dbg, _ = ag((x, z, states), 0.25, selected_filter_id=forced)
+        loss = (y * w).sum() * 1e-3 + (sur * torch.linspace(-1, 1, B, device=dev)[:, None]).sum() + pen.sum() * 0.7
+        loss.backward()
+        return y.detach(), ns.detach(), sur.detach(), pen.detach(), dbg
+
+    yo, nso, so, po, dbo = run(ours)
+    monkeypatch.setenv("ADAISP_TRUNK_KERNELS", "0")
+    monkeypatch.setenv("ADAISP_POLICY_TAIL_KERNEL", "0")
+    yr, nsr, sr, pr, dbr = run(ref)
+    assert torch.equal(dbo["selected_filter"], dbr["selected_filter"])
+    if forced is None:
+        assert int(dbo["selected_filter"][0]) == -1 and len(set(dbo["selected_filter"].tolist())) > 2
+    assert torch.equal(nso, nsr)
+    close_scaled("trunk_train.agent_step.pdf", dbo["pdf"], dbr["pdf"], frac=2e-5)
+    close_scaled("trunk_train.agent_step.retouch", yo, yr, frac=2e-5)
+    close_scaled("trunk_train.agent_step.surrogate", so, sr, frac=2e-5)
+    close_scaled("trunk_train.agent_step.penalty", po, pr, frac=2e-5)
+    for i in range(len(ours.filters)):
+        a, b = dbo["filter_debug_info"][i]["filter_parameters"], dbr["filter_debug_info"][i]["filter_parameters"]
+        close_scaled("trunk_train.agent_step.params", a, b, frac=2e-5, err_msg=ours.filters[i].get_short_name())
+    gg, rr = dict(ours.named_parameters()), dict(ref.named_parameters())
+    for name, p in gg.items():
+        if "fc_mask" in name:
+            continue
+        is_conv_bias = ("feature_extractor" in name or "action_selection" in name) and name.endswith(".bias") and \
+            name.split(".")[-2] in ("0", "3", "6", "9")
+        if is_conv_bias:
+            continue                                                     # (exactly 0 in exact arithmetic: rounding noise on both sides)
+        assert (p.grad is None) == (rr[name].grad is None), name
+        if p.grad is not None:
+            close_scaled("trunk_train.agent_step.grad", p.grad, rr[name].grad, frac=5e-4, floor=1e-7, err_msg=name)

@@ -12,10 +12,9 @@ python3 - "$OUT/train_trace/tr_kernel_trace.csv" <<'PY'
 import csv, sys, collections
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-# steady state: the window between the optimizer launches of the 6th-from-last and the last iteration (two
-# multi_tensor_apply bursts per iteration: agent, value)
-adam = [i for i, r in enumerate(rows) if "multi_tensor_apply" in r["Kernel_Name"]]
-starts = [adam[0]] + [adam[k] for k in range(1, len(adam)) if int(rows[adam[k]]["Start_Timestamp"]) - int(rows[adam[k - 1]]["End_Timestamp"]) > 3_000_000]
+# steady state: the window between the TD-arithmetic launches (one per iteration, csrc/isp_rl_train.hip) of the 6th-from-last
+# and the last iteration
+starts = [i for i, r in enumerate(rows) if "k_td_fwd" in r["Kernel_Name"]]
 NIT = 6
 seg = rows[starts[-1 - NIT]:starts[-1]]
 span = int(seg[-1]["End_Timestamp"]) - int(seg[0]["Start_Timestamp"])
@@ -25,7 +24,7 @@ for r in seg:
     s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
     busy += e - max(s, last_end) if e > last_end else 0
     last_end = max(last_end, e)
-    k = r["Kernel_Name"].split("(")[0][-60:]
+    k = r["Kernel_Name"].split("(")[0].replace("(anonymous namespace)::", "")[-60:]
     agg[k][0] += 1; agg[k][1] += e - s
 print(f"{NIT} iterations: span {span/1e6/NIT:.2f} ms each, GPU busy {busy/1e6/NIT:.2f} ms ({100*busy/span:.0f} %), {len(seg)//NIT} kernels per iteration")
 for k, (n, t) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:28]:
