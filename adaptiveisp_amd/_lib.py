@@ -26,7 +26,7 @@ EXPORTS = ("adaisp_forward", "adaisp_forward_uniform", "adaisp_process", "adaisp
            "adaisp_policy_conv", "adaisp_policy_fc1", "adaisp_policy_finish",
            "adaisp_trunk_train_fwd", "adaisp_trunk_train_bwd", "adaisp_trunk_train_workspace_bytes", "adaisp_trunk_train_scratch_bytes",
            "adaisp_critic_planes_fwd", "adaisp_critic_planes_bwd", "adaisp_td_fwd", "adaisp_td_bwd",
-           "adaisp_policy_tail_fwd", "adaisp_policy_tail_bwd",
+           "adaisp_policy_tail_fwd", "adaisp_policy_tail_bwd", "adaisp_image_stats",
            "adaisp_strerror", "adaisp_abi_version")
 
 _lib = None
@@ -67,6 +67,8 @@ def load():
     for name in ("adaisp_trunk_train_workspace_bytes", "adaisp_trunk_train_scratch_bytes"):
         getattr(L, name).argtypes = [vp]
         getattr(L, name).restype = ctypes.c_size_t
+    L.adaisp_image_stats.argtypes = [vp, vp, vp, ci, ctypes.c_long, vp]
+    L.adaisp_image_stats.restype = ci
     L.adaisp_num_params.argtypes = [ci]
     L.adaisp_strerror.argtypes = [ci]
     L.adaisp_strerror.restype = ctypes.c_char_p
@@ -109,6 +111,18 @@ def _img_shape(img):
     if img.dim() != 4 or img.shape[1] != 3:
         raise ValueError(f"expected a [B,3,H,W] image, got {tuple(img.shape)}")
     return int(img.shape[0]), int(img.shape[2]), int(img.shape[3])
+
+
+def image_stats(img):
+    """[B,2] = (mean, number of non-finite values) per image of a [B,...] fp32 batch (adaisp_image_stats)."""
+    L = load()
+    img = _dev_f32(img.detach(), "img")
+    B = int(img.shape[0])
+    buf = torch.empty((B, 2 + 128), dtype=torch.float32, device=img.device)
+    with torch.cuda.device(img.device):
+        rc = L.adaisp_image_stats(img.data_ptr(), buf.data_ptr(), buf.data_ptr() + 8 * B, B, img.numel() // B, _stream())
+    _check(rc, "adaisp_image_stats")
+    return buf.view(-1)[:2 * B].view(B, 2)
 
 
 def process(op, img, params, clip=False, out=None, nlm_exact=False, nlm_v1=False, nlm_tile32=False):

@@ -365,6 +365,51 @@ __global__ __launch_bounds__(256) void k_policy_tail_bwd(adaisp_policy_tail_args
     }
 }
 
+// ---- per-image mean and non-finite count of a batch (the TD target's brightness test, train.py:287-291, and the replay
+// guard, train.py:374-381): 64 chunks per image summed in lane / wave / chunk order, then the chunks in index order ---------
+constexpr int kStatChunks = 64;
+__global__ __launch_bounds__(256) void k_image_stats_partial(const float* __restrict__ img, float* __restrict__ partial,
+                                                             long n) {
+    __shared__ float red[4];
+    const int b = blockIdx.y, ch = blockIdx.x;
+    const long per = ((n / 4 + kStatChunks - 1) / kStatChunks) * 4;            // floats per chunk, a multiple of 4
+    const long lo = ch * per, hi = lo + per < n ? lo + per : n;
+    const float* p = img + (long)b * n;
+    float sum = 0.0f, bad = 0.0f;
+    const bool vec = (n % 4 == 0) && ((reinterpret_cast<uintptr_t>(p) & 15) == 0);
+    if (vec) {
+        for (long i = lo + 4 * threadIdx.x; i < hi; i += 4 * 256) {
+            const float4 v = *reinterpret_cast<const float4*>(p + i);
+            sum += (v.x + v.y) + (v.z + v.w);
+            bad += (float)((!isfinite(v.x)) + (!isfinite(v.y)) + (!isfinite(v.z)) + (!isfinite(v.w)));
+        }
+    } else {
+        for (long i = lo + threadIdx.x; i < hi; i += 256) {
+            const float v = p[i];
+            sum += v;
+            bad += isfinite(v) ? 0.0f : 1.0f;
+        }
+    }
+    sum = block_sum256(sum, red);
+    bad = block_sum256(bad, red);
+    if (threadIdx.x == 0) {
+        partial[((long)b * kStatChunks + ch) * 2] = sum;
+        partial[((long)b * kStatChunks + ch) * 2 + 1] = bad;
+    }
+}
+__global__ __launch_bounds__(64) void k_image_stats_finish(const float* __restrict__ partial, float* __restrict__ stats, int B,
+                                                           long n) {
+    const int b = blockIdx.x * 64 + threadIdx.x;
+    if (b >= B) return;
+    float sum = 0.0f, bad = 0.0f;
+    for (int c = 0; c < kStatChunks; ++c) {
+        sum += partial[((long)b * kStatChunks + c) * 2];
+        bad += partial[((long)b * kStatChunks + c) * 2 + 1];
+    }
+    stats[2 * b] = sum / (float)n;
+    stats[2 * b + 1] = bad;
+}
+
 PlanesIO planes_io(const adaisp_critic_planes_args& a) {
     PlanesIO io{};
     for (int g = 0; g < a.G; ++g) {
@@ -419,6 +464,14 @@ int adaisp_td_bwd(const adaisp_td_args* a, void* stream) {
     if (rc != ADAISP_OK) return rc;
     if (!a->dlosses || !a->d_l_re || !a->d_penalty || !a->d_surrogate || !a->d_old_value || !a->d_new_value) return ADAISP_EINVAL;
     hipLaunchKernelGGL(k_td_bwd, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream), *a);
+    return hipGetLastError() == hipSuccess ? ADAISP_OK : ADAISP_ELAUNCH;
+}
+
+int adaisp_image_stats(const float* img, float* stats, float* workspace, int B, long n, void* stream) {
+    if (!img || !stats || !workspace || B < 1 || n < 1) return ADAISP_EINVAL;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(k_image_stats_partial, dim3(kStatChunks, B), dim3(256), 0, s, img, workspace, n);
+    hipLaunchKernelGGL(k_image_stats_finish, dim3((B + 63) / 64), dim3(64), 0, s, workspace, stats, B, n);
     return hipGetLastError() == hipSuccess ? ADAISP_OK : ADAISP_ELAUNCH;
 }
 

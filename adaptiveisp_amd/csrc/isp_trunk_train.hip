@@ -28,6 +28,7 @@ namespace {
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 constexpr int kU = 8;                       // reduction steps whose loads are all issued before the first MFMA
 constexpr int kMaxG = ADAISP_TRUNK_MAX_G;
+constexpr int kMaxWSplit = 8;               // pixel-range chunks of a weight-gradient tile (times the instances that share it)
 
 // sum over the workgroup, the same order every run: lane butterfly, then the waves in index order. `red` holds 16 floats.
 __device__ __forceinline__ float block_sum(float v, float* red) {
@@ -279,23 +280,29 @@ struct WgIO {
 // A[row = co][k = px] = dy, B[k = px][col = tap] = the input pixel the tap sees. Lane (col, kq) fetches 4 consecutive
 // pixels of its dy row (one 16-byte load) and the 4 input pixels its tap pairs with them; MFMA j takes element j of both.
 template <int U>
-__global__ __launch_bounds__(1024) void k_twgrad(WgIO io, int Gseq, int n_state, int B, int Cin, int Hin, int Cout, int KS,
-                                                 int spw) {
-    __shared__ float part[15 * 4 * 64];
+__global__ __launch_bounds__(1024) void k_twgrad(WgIO io, int Gseq, int PS, float* part, int n_state, int B, int Cin, int Hin,
+                                                 int Cout, int KS, int spw) {
+    __shared__ float part_lds[15 * 4 * 64];
     const int Ho = Hin >> 1, HW = Hin * Hin, HoHo = Ho * Ho;
-    const int ci = blockIdx.x, co0 = blockIdx.y * 16;
+    // blockIdx.x = ci + Cin * split; split = (instance of a shared parameter set, chunk of the pixel range): with more than
+    // one split the tile goes to `part` [split][Cout][Cin][16] and k_twgrad_reduce adds the splits in index order
+    const int ci = blockIdx.x % Cin, split = blockIdx.x / Cin;
+    const int gs = split / PS, chunk = split - gs * PS;
+    const int co0 = blockIdx.y * 16;
     const int lane = threadIdx.x & 63, ks = threadIdx.x >> 6;
     const int col = lane & 15, kq = lane >> 4;
     const int kh = col >> 2, kw = col & 3;
     f32x4_t acc = {0.0f, 0.0f, 0.0f, 0.0f};
-    for (int s = 0; s < Gseq; ++s) {
-        const int gg = blockIdx.z * Gseq + s;               // (instances of a shared parameter set: summed in order)
+    // one instance per workgroup when the range is cut (PS > 1), else the instances of a shared parameter set in order
+    for (int g = (PS > 1 ? gs : 0); g < (PS > 1 ? gs + 1 : Gseq); ++g) {
+        const int gg = blockIdx.z * Gseq + g;
         const float* sv = io.svec[gg];
         const bool plane = !sv || ci < 3;
         const int n_img = sv ? 3 : Cin;
         const float* dy = io.dy[gg];
         const float* ain = io.ain[gg];
-        for (int st = ks * spw; st < (ks + 1) * spw; st += U) {
+        const int st0 = (chunk * KS + ks) * spw;
+        for (int st = st0; st < st0 + spw; st += U) {
             float4 av[U];
             float xb[U][4];
 #pragma unroll
@@ -323,11 +330,21 @@ __global__ __launch_bounds__(1024) void k_twgrad(WgIO io, int Gseq, int n_state,
             }
         }
     }
-    if (!meet_in_lds(acc, part, ks, KS, lane)) return;
+    if (!meet_in_lds(acc, part_lds, ks, KS, lane)) return;
     // D[row = co][col = tap]
-    float* dw = io.dw[blockIdx.z * Gseq] + ((long)(co0 + 4 * kq) * Cin + ci) * 16 + col;
+    float* dw = (PS > 1 ? part + ((long)blockIdx.z * Gseq * PS + split) * Cout * Cin * 16 : io.dw[blockIdx.z * Gseq]) +
+                ((long)(co0 + 4 * kq) * Cin + ci) * 16 + col;
 #pragma unroll
     for (int e = 0; e < 4; ++e) dw[(long)e * Cin * 16] = acc[e];
+}
+
+__global__ __launch_bounds__(256) void k_twgrad_reduce(WgIO io, const float* __restrict__ part, int nsplit, int n) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float* p = part + (long)blockIdx.z * nsplit * n + i;
+    float t = p[0];
+    for (int k = 1; k < nsplit; ++k) t += p[(long)k * n];
+    io.dw[blockIdx.z][i] = t;
 }
 
 // ---- data gradient -------------------------------------------------------------------------------------------------------
@@ -410,7 +427,15 @@ struct Plan {
     size_t ws_per_g;
     size_t dy[ADAISP_TRUNK_LAYERS + 1], da[ADAISP_TRUNK_LAYERS + 1];
     size_t scr_per_g;
+    size_t wpart, scr_total;            // weight-gradient partial tiles (one region, after the per-instance blocks)
 };
+
+// chunks the pixel steps of a weight-gradient tile are cut into: waves split them 16 ways, more than 4 steps per wave -> cut
+int wgrad_chunks(int steps) {
+    int PS = 1;
+    while (PS < kMaxWSplit && steps % (2 * PS) == 0 && steps / (2 * PS) >= 16 * 4) PS *= 2;
+    return PS;
+}
 
 Plan make_plan(const adaisp_trunk_args& t) {
     Plan p{};
@@ -428,6 +453,14 @@ Plan make_plan(const adaisp_trunk_args& t) {
     p.da[0] = s; s += (size_t)t.B * t.C[0] * 64 * 64;                      // state-plane gradients of the first layer
     p.ws_per_g = o;
     p.scr_per_g = s;
+    p.wpart = s * t.G;
+    size_t wp = 0;
+    for (int l = 1; l <= ADAISP_TRUNK_LAYERS; ++l) {
+        const int PS = wgrad_chunks(t.B * p.H[l] * p.H[l] / 16);
+        const size_t n = PS > 1 ? (size_t)PS * t.G * t.C[l] * t.C[l - 1] * 16 : 0;
+        wp = n > wp ? n : wp;
+    }
+    p.scr_total = p.wpart + wp;
     return p;
 }
 
@@ -479,7 +512,7 @@ size_t adaisp_trunk_train_workspace_bytes(const adaisp_trunk_args* t) {
 
 size_t adaisp_trunk_train_scratch_bytes(const adaisp_trunk_args* t) {
     if (!t || t->G < 1 || t->G > kMaxG) return 0;
-    return make_plan(*t).scr_per_g * t->G * sizeof(float);
+    return make_plan(*t).scr_total * sizeof(float);
 }
 
 int adaisp_trunk_train_fwd(const adaisp_trunk_args* t, void* stream) {
@@ -576,14 +609,26 @@ int adaisp_trunk_train_bwd(const adaisp_trunk_args* t, void* stream) {
             hipLaunchKernelGGL(k_tbn_bwd<false>, dim3(Cout, Gpar), dim3(nthr), 0, s, n, Gseq, B, Cout, Ho * Ho, t->slope);
         {
             const int steps = N / 16;
-            const int KS = largest_divisor_le(steps, 16), spw = steps / KS;
-            const dim3 grid(Cin, Cout / 16, Gpar), block(64 * KS);
+            // waves of a workgroup split the pixel steps 16 ways; where that leaves a wave more than 4 steps (the wide early
+            // layers) the range is also cut into PS chunks -> partial tiles + one ordered reduction
+            const int PS = wgrad_chunks(steps);
+            const int per = steps / PS;
+            const int KS = largest_divisor_le(per, 16), spw = per / KS;
+            const int nsplit = PS > 1 ? Gseq * PS : 1;
+            float* part = t->scratch + p.wpart;
+            const dim3 grid(Cin * nsplit, Cout / 16, Gpar), block(64 * KS);       // (per launch: Gpar * nsplit * Cout * Cin * 16 partials)
             if (spw % 4 == 0)
-                hipLaunchKernelGGL(k_twgrad<4>, grid, block, 0, s, wg, Gseq, t->n_state, B, Cin, Hin, Cout, KS, spw);
+                hipLaunchKernelGGL(k_twgrad<4>, grid, block, 0, s, wg, Gseq, PS, part, t->n_state, B, Cin, Hin, Cout, KS, spw);
             else if (spw % 2 == 0)
-                hipLaunchKernelGGL(k_twgrad<2>, grid, block, 0, s, wg, Gseq, t->n_state, B, Cin, Hin, Cout, KS, spw);
+                hipLaunchKernelGGL(k_twgrad<2>, grid, block, 0, s, wg, Gseq, PS, part, t->n_state, B, Cin, Hin, Cout, KS, spw);
             else
-                hipLaunchKernelGGL(k_twgrad<1>, grid, block, 0, s, wg, Gseq, t->n_state, B, Cin, Hin, Cout, KS, spw);
+                hipLaunchKernelGGL(k_twgrad<1>, grid, block, 0, s, wg, Gseq, PS, part, t->n_state, B, Cin, Hin, Cout, KS, spw);
+            if (nsplit > 1) {
+                const int n = Cout * Cin * 16;
+                WgIO rd{};
+                for (int g = 0; g < Gpar; ++g) rd.dw[g] = wg.dw[g * Gseq];
+                hipLaunchKernelGGL(k_twgrad_reduce, dim3((n + 255) / 256, 1, Gpar), dim3(256), 0, s, rd, part, nsplit, n);
+            }
         }
         if (l > 1 || want_input) {
             int KS = Cout / kU;

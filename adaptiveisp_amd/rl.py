@@ -128,12 +128,23 @@ def lr_lambda(max_iter):
     return lambda it: 0.1 ** (3.0 * it / max_iter)
 
 
+def retouch_stats(retouch):
+    """[B,2]: per-image mean and number of non-finite values of the retouched batch — one pass (adaisp_image_stats) for the TD
+    target's brightness test (train.py:287-291) and the trainer's replay guard (train.py:374-381)."""
+    d = retouch.detach()
+    if d.is_cuda and d.dtype == torch.float32:
+        from . import _lib
+        return _lib.image_stats(d)
+    return torch.stack([d.mean(dim=tuple(range(1, d.dim()))), (~torch.isfinite(d)).flatten(1).sum(1).to(d.dtype)], dim=1)
+
+
 def train_iteration(cfg, agent, value, detector, loss_fn, imgs, z, states, labels, progress, optimizers, buckets=None,
                     use_truncated=True, max_bri=0.9, on_retouch=None):
     """One optimisation step (train.py:255-351). `detector(x)` must return the three raw head maps with autograd
     through to x (the frozen reward model); `buckets` (adaptiveisp_amd.dist.GradBucket per model) enables the
     data-parallel gradient all-reduce before the 1e-5 clip. `on_retouch(retouch)` is called as soon as the retouched batch
-    is enqueued (the trainer starts its NaN / brightness guard there, long before the iteration's backward is launched).
+    is enqueued, with `retouch_stats(retouch)` as second argument (the trainer starts its NaN / brightness guard there, long
+    before the iteration's backward is launched).
     Returns the scalars of td_losses plus the retouched batch."""
     from . import dist as adist
     from .yolo.loss import batched_per_sample_loss as per_sample_loss
@@ -152,21 +163,24 @@ def train_iteration(cfg, agent, value, detector, loss_fn, imgs, z, states, label
             with torch.cuda.stream(side), torch.no_grad():
                 l_in = detector.per_sample_loss(loss_fn, imgs, packed)
             (retouch, new_states, surrogate, penalty), _, _ = agent((imgs, z, states), progress)
+            stats = retouch_stats(retouch)
             if on_retouch is not None:
-                on_retouch(retouch.detach())
+                on_retouch(retouch.detach(), stats)
             cur.wait_stream(side)                           # the engine's buffers are free again
             l_in.record_stream(cur)
         else:
             (retouch, new_states, surrogate, penalty), _, _ = agent((imgs, z, states), progress)
+            stats = retouch_stats(retouch)
             if on_retouch is not None:
-                on_retouch(retouch.detach())
+                on_retouch(retouch.detach(), stats)
             with torch.no_grad():
                 l_in = detector.per_sample_loss(loss_fn, imgs, packed)
         l_re = detector.per_sample_loss(loss_fn, retouch, packed)
     else:
         (retouch, new_states, surrogate, penalty), _, _ = agent((imgs, z, states), progress)
+        stats = retouch_stats(retouch)
         if on_retouch is not None:
-            on_retouch(retouch.detach())
+            on_retouch(retouch.detach(), stats)
         with torch.no_grad():
             p_in = detector(imgs)
             assigned = assign_labels(loss_fn, p_in, labels)      # same labels, same map shapes for both batches
@@ -178,7 +192,7 @@ def train_iteration(cfg, agent, value, detector, loss_fn, imgs, z, states, label
         old_value = value(imgs, states)
         new_value = value(retouch, new_states)
     out = td_losses(cfg, l_in, l_re, penalty, surrogate, new_states, old_value, new_value,
-                    torch.mean(retouch, dim=(1, 2, 3)).unsqueeze(-1), use_truncated, max_bri)
+                    stats[:, 0:1], use_truncated, max_bri)
     # train.py:341-342 calls backward() on the two losses in turn; gradients accumulate, so one engine pass over both roots
     # deposits the same sums (and the critic's two calls may share autograd nodes)
     torch.autograd.backward([out["value_loss"], out["agent_loss"]])

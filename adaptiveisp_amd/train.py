@@ -61,15 +61,18 @@ class Trainer:
         labels = [torch.as_tensor(lb) for lb in feed["label"]]
         guard = {}
 
-        def start_guard(retouch):
+        def start_guard(retouch, stats):
             """The reference's check of the retouched batch (train.py:374-381: NaN / too dark / too bright -> the records are
-            dropped instead of re-entering the pool). Its inputs exist as soon as the filters have run, so it is launched
-            THEN, on a second stream, with its one flag copied to pinned host memory behind an event: the host reads it after
-            it has enqueued the rest of the iteration without waiting for that rest (a `bool(tensor)` on the main stream at
-            the end of the iteration drains the GPU every iteration)."""
+            dropped instead of re-entering the pool) from the batch's per-image statistics (rl.retouch_stats: [B,2] mean /
+            non-finite count). They exist as soon as the filters have run, so the flag is made THEN, on a second stream, and
+            copied to pinned host memory behind an event: the host reads it after it has enqueued the rest of the iteration
+            without waiting for that rest (a `bool(tensor)` on the main stream at the end of the iteration drains the GPU
+            every iteration)."""
+            def flag():
+                mean = stats[:, 0].mean()
+                return ((stats[:, 1].sum() > 0) | ~torch.isfinite(mean) | (mean < 0.01) | (mean > self.max_bri)).reshape(1)
             if not retouch.is_cuda:
-                mean = torch.mean(retouch)
-                guard["bad"] = bool((~torch.isfinite(retouch)).any() | (mean < 0.01) | (mean > self.max_bri))
+                guard["bad"] = bool(flag())
                 return
             from .rl import _side_stream
             cur, side = torch.cuda.current_stream(), _side_stream(retouch.device)
@@ -77,12 +80,10 @@ class Trainer:
                 self._flag_host = torch.empty((1,), dtype=torch.bool, pin_memory=True)
             side.wait_stream(cur)
             with torch.cuda.stream(side):
-                mean = torch.mean(retouch)
-                bad = ((~torch.isfinite(retouch)).any() | (mean < 0.01) | (mean > self.max_bri)).reshape(1)
-                self._flag_host.copy_(bad, non_blocking=True)
+                self._flag_host.copy_(flag(), non_blocking=True)
                 guard["event"] = torch.cuda.Event()
                 guard["event"].record(side)
-            retouch.record_stream(side)
+            stats.record_stream(side)
 
         out = train_iteration(self.cfg, self.agent, self.value, self.detector, self.loss_fn, feed["im"], feed["z"],
                               feed["state"], labels, progress, [self.agent_optimizer, self.value_optimizer],

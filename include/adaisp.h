@@ -348,6 +348,13 @@ typedef struct adaisp_policy_tail_args {
 int adaisp_policy_tail_fwd(const adaisp_policy_tail_args* args, void* stream);
 int adaisp_policy_tail_bwd(const adaisp_policy_tail_args* args, void* stream);
 
+/*
+ * stats[b] = (mean, number of non-finite values) of image b of a batch of B images of n floats each — what the TD target's
+ * brightness test (train.py:287-291) and the replay guard (train.py:374-381) read, in one pass over the batch. `workspace`:
+ * B * 128 floats. Fixed summation order. Two launches.
+ */
+int adaisp_image_stats(const float* img, float* stats, float* workspace, int B, long n, void* stream);
+
 /* Number of regressed parameters an op reads per image (0 for ADAISP_OP_ZERO, -1 if unknown). */
 int adaisp_num_params(int op);
 

@@ -336,3 +336,21 @@ def test_agent_training_step_kernels_match_the_module_path(forced, monkeypatch):
         assert (p.grad is None) == (rr[name].grad is None), name
         if p.grad is not None:
             close_scaled("trunk_train.agent_step.grad", p.grad, rr[name].grad, frac=5e-4, floor=1e-7, err_msg=name)
+
+
+@pytest.mark.parametrize("shape", [(8, 3, 512, 512), (3, 3, 30, 50), (2, 3, 63, 65)])
+def test_image_stats(shape):
+    """adaisp_image_stats: per-image mean and non-finite count (rl.retouch_stats), against torch on the same batch."""
+    from adaptiveisp_amd import _lib, rl
+    dev = torch.device("cuda:0")
+    x = torch.rand(shape, generator=torch.Generator().manual_seed(2)).to(dev)
+    x[1, 0, 3, 4:7] = float("nan")
+    x[1, 2, 5, 1] = float("inf")
+    st = _lib.image_stats(x)
+    assert st.shape == (shape[0], 2)
+    assert st[:, 1].tolist() == [0.0, 4.0] + [0.0] * (shape[0] - 2)
+    ref = rl.retouch_stats(x.cpu())
+    assert torch.equal(st[:, 1].cpu(), ref[:, 1]) and not torch.isfinite(st[1, 0])
+    keep = [i for i in range(shape[0]) if i != 1]
+    close_scaled("trunk_train.image_stats.mean", st[keep, 0], x[keep].double().mean(dim=(1, 2, 3)).float(), frac=2e-6)
+    assert torch.equal(torch.nan_to_num(st, nan=-1.0), torch.nan_to_num(_lib.image_stats(x), nan=-1.0))
