@@ -150,10 +150,11 @@ int adayolo_conv_keep_fwd(const void* in, int in_cstride, const void* weight, co
     if (rc != ADAYOLO_OK) return rc;
     if (pre_cstride % 8 || pre_cstride < Cout) return ADAYOLO_ESHAPE;
     const bool dma2 = variant == 5 || variant == 22 || variant == 26 || variant == 27;
-    if (!dma2 && variant != 60) return ADAYOLO_EINVAL;       // the kernels whose epilogue has the second output
+    const bool pq = variant == 80 || variant == 85;
+    if (!dma2 && !pq && variant != 60) return ADAYOLO_EINVAL;       // the kernels whose epilogue has the second output
     a.pre = static_cast<unsigned short*>(pre); a.pre_cs = pre_cstride;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const hipError_t e = dma2 ? launch_conv_dma2(a, s, variant) : launch_conv_pp128(a, s, variant);
+    const hipError_t e = dma2 ? launch_conv_dma2(a, s, variant) : pq ? launch_conv_pq(a, s, variant) : launch_conv_pp128(a, s, variant);
     if (e == hipErrorInvalidValue) return ADAYOLO_ESHAPE;    // this kernel does not serve the shape: the caller keeps two launches
     return e == hipSuccess ? ADAYOLO_OK : ADAYOLO_ELAUNCH;
 }
@@ -217,6 +218,8 @@ int adayolo_conv_dsilu_fwd(const void* in, int in_cstride, const void* weight, c
         e = launch_conv_dma2(a, s, variant);
     } else if (variant == 60) {
         e = launch_conv_pp128(a, s, variant);
+    } else if (variant == 80 || variant == 85) {
+        e = launch_conv_pq(a, s, variant);
     } else {
         return ADAYOLO_EINVAL;                               // the kernels whose epilogue has this form
     }
@@ -292,6 +295,15 @@ int adayolo_stem_fwd_act(const float* img, const float* weight, const float* bia
     if (Cout != 32 || out_cstride % 8 || out_cstride < Cout || B > 65535) return ADAYOLO_ESHAPE;
     return launch_stem(img, weight, bias, out, out_cstride, B, H, W, Hp, pad_top, pad_value, act,
                        static_cast<hipStream_t>(stream)) == hipSuccess ? ADAYOLO_OK : ADAYOLO_ELAUNCH;
+}
+
+int adayolo_stem_keep_fwd(const float* img, const float* weight, const float* bias, void* out, int out_cstride, void* pre,
+                          int pre_cstride, int B, int H, int W, int Hp, int pad_top, float pad_value, int Cout, void* stream) {
+    if (!img || !weight || !bias || !out || !pre) return ADAYOLO_EINVAL;
+    if (B <= 0 || H <= 0 || W <= 0 || Hp < H || pad_top < 0 || pad_top + H > Hp) return ADAYOLO_EINVAL;
+    if (Cout != 32 || out_cstride % 8 || out_cstride < Cout || pre_cstride % 8 || pre_cstride < Cout || B > 65535) return ADAYOLO_ESHAPE;
+    return launch_stem(img, weight, bias, out, out_cstride, B, H, W, Hp, pad_top, pad_value, ADAYOLO_ACT_SILU,
+                       static_cast<hipStream_t>(stream), pre, pre_cstride) == hipSuccess ? ADAYOLO_OK : ADAYOLO_ELAUNCH;
 }
 
 int adayolo_letterbox_pack(const float* img, void* out, int out_cstride, int B, int H, int W, int Hp, int pad_top,

@@ -277,8 +277,12 @@ __global__ __launch_bounds__(256, 2) void k_conv_pq(const ConvArgs a) {
     // ---- epilogue (see yolo_conv_pp.hip): D[row = channel][col = pixel]; each wave transposes its 128 px x 64 ch through a
     //      private LDS region (pitch 144 B) and writes 128-byte row segments; activation / residual are compile-time copies
     unsigned char* my = smem + wave * (32 * MI * kEpiPitch);
-    auto epilogue = [&](auto silu_tag, auto res_tag) __attribute__((always_inline)) {
-        constexpr bool kSilu = decltype(silu_tag)::value, kRes = decltype(res_tag)::value;
+    // kKeep (training forward): the tile goes through LDS as the bf16 PRE-activation, is stored to a.pre, then activated from
+    // that rounded value; kDs (backward): the result (+ residual) is dL/d(layer output), stored when a.out is set, and
+    // a.gpre = it * silu'(a.pre) — the contracts of yolo_conv_pp128.hip's epilogue, bit for bit the separate SiLU launches
+    auto epilogue = [&](auto silu_tag, auto res_tag, auto keep_tag, auto ds_tag) __attribute__((always_inline)) {
+        constexpr bool kKeep = decltype(keep_tag)::value, kAct = decltype(silu_tag)::value, kDs = decltype(ds_tag)::value;
+        constexpr bool kSilu = kAct && !kKeep, kRes = decltype(res_tag)::value;
         const int chunk = lane & 7, r0 = lane >> 3;
         const int mrow = m0 + wm * (32 * MI) + r0, n = n0 + wn * 64 + chunk * 8;
         unsigned short* const op = a.out + (long)mrow * a.out_cs + n;
@@ -311,6 +315,16 @@ __global__ __launch_bounds__(256, 2) void k_conv_pq(const ConvArgs a) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
             for (int it = 0; it < 4; ++it) v[it] = *reinterpret_cast<const u32x4*>(rd + (mi * 32 + it * 8) * kEpiPitch);
+            if (kKeep) {
+#pragma unroll
+                for (int it = 0; it < 4; ++it) {
+                    if (ok[it]) *reinterpret_cast<u32x4*>(a.pre + (long)(mrow + 8 * (4 * mi + it)) * a.pre_cs + n) = v[it];
+                    if (kAct) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) v[it][j] = silu_bf16x2(v[it][j]);
+                    }
+                }
+            }
             if (kRes) {
 #pragma unroll
                 for (int it = 0; it < 4; ++it)
@@ -321,17 +335,43 @@ __global__ __launch_bounds__(256, 2) void k_conv_pq(const ConvArgs a) {
                         v[it][j] = pack_bf16x2(x.x, x.y);
                     }
             }
+            if (kDs) {
+                u32x4 p[4];
+#pragma unroll
+                for (int it = 0; it < 4; ++it) {
+                    p[it] = u32x4{0u, 0u, 0u, 0u};
+                    if (ok[it]) p[it] = *reinterpret_cast<const u32x4*>(a.pre + (long)(mrow + 8 * (4 * mi + it)) * a.pre_cs + n);
+                }
+                if (a.out) {
+#pragma unroll
+                    for (int it = 0; it < 4; ++it)
+                        if (ok[it]) __builtin_nontemporal_store(v[it], reinterpret_cast<u32x4*>(op + (4 * mi + it) * ostep));
+                }
+#pragma unroll
+                for (int it = 0; it < 4; ++it) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[it][j] = dsilu_bf16x2(v[it][j], p[it][j]);
+                    if (ok[it])
+                        __builtin_nontemporal_store(v[it], reinterpret_cast<u32x4*>(a.gpre + (long)(mrow + 8 * (4 * mi + it)) * a.gpre_cs + n));
+                }
+                continue;
+            }
 #pragma unroll
             for (int it = 0; it < 4; ++it)
                 if (ok[it]) __builtin_nontemporal_store(v[it], reinterpret_cast<u32x4*>(op + (4 * mi + it) * ostep));
         }
     };
-    if (a.act == ADAYOLO_ACT_SILU) {
-        if (a.res) epilogue(std::true_type{}, std::true_type{});
-        else epilogue(std::true_type{}, std::false_type{});
+    const std::false_type no{};
+    const std::true_type yes{};
+    if (a.gpre) {
+        if (a.res) epilogue(no, yes, no, yes); else epilogue(no, no, no, yes);
+    } else if (a.pre) {
+        if (a.act == ADAYOLO_ACT_SILU) { if (a.res) epilogue(yes, yes, yes, no); else epilogue(yes, no, yes, no); }
+        else { if (a.res) epilogue(no, yes, yes, no); else epilogue(no, no, yes, no); }
+    } else if (a.act == ADAYOLO_ACT_SILU) {
+        if (a.res) epilogue(yes, yes, no, no); else epilogue(yes, no, no, no);
     } else {
-        if (a.res) epilogue(std::false_type{}, std::true_type{});
-        else epilogue(std::false_type{}, std::false_type{});
+        if (a.res) epilogue(no, yes, no, no); else epilogue(no, no, no, no);
     }
 }
 
@@ -364,7 +404,7 @@ static hipError_t launch(ConvArgs a, hipStream_t s) {
 // hipErrorInvalidValue -> not served.
 hipError_t launch_conv_pq(ConvArgs a, hipStream_t s, int variant) {
     const long nK = (long)a.ks * a.ks * a.Cin / 32;
-    if (a.Cin % 32 || a.Cout % 128 || nK < 3 || a.sh_hw < 0 || a.sh_w < 0) return hipErrorInvalidValue;
+    if (a.Cin % 32 || a.Cout % 128 || nK < 3 || a.sh_hw < 0 || a.sh_w < 0 || a.d2s_c) return hipErrorInvalidValue;
     const unsigned long long lim = 0xFFFFFF00ull - 64;
     const unsigned long long in_b = 2ull * a.B * a.H * a.W * a.in_cs + 4ull * (a.W + 1) * a.in_cs + 2ull * a.Cin;
     if (in_b > lim || 2ull * a.Cout * a.ks * a.ks * a.Cin > lim) return hipErrorInvalidValue;

@@ -105,7 +105,7 @@ hipError_t launch_bottleneck256(const void* x, int x_cs, const void* w1, const f
 hipError_t launch_conv_pq(ConvArgs a, hipStream_t s, int variant);    // 256x128, 4 waves, two workgroups per CU (yolo_conv_pq.hip)
 hipError_t launch_conv_ws(ConvArgs a, hipStream_t s, int variant);    // 3x3 s1, Cin 32 / 64: weights in registers, patch in LDS, persistent (yolo_conv_ws.hip)
 hipError_t launch_stem(const float* img, const float* w, const float* bias, void* out, int out_cs, int B, int H,
-                       int W, int Hp, int pad_top, float pad_value, int act, hipStream_t s);
+                       int W, int Hp, int pad_top, float pad_value, int act, hipStream_t s, void* pre = nullptr, int pre_cs = 0);
 hipError_t launch_letterbox_pack(const float* img, void* out, int out_cs, int B, int H, int W, int Hp, int pad_top,
                                  float pad_value, hipStream_t s);
 hipError_t launch_stem_down(const float* img, const float* w0, const float* b0, const void* w1, const float* b1, void* out,

@@ -35,7 +35,8 @@ constexpr int S_TW = 64, S_TH = 16, S_LW = S_TW + 2, S_LH = S_TH + 2;
 
 __global__ __launch_bounds__(256) void k_stem(const float* __restrict__ img, const float* __restrict__ w,
                                               const float* __restrict__ bias, unsigned short* __restrict__ out,
-                                              int out_cs, int H, int W, int Hp, int pad_top, float pad_value, int act) {
+                                              int out_cs, int H, int W, int Hp, int pad_top, float pad_value, int act,
+                                              unsigned short* __restrict__ pre, int pre_cs) {
     __shared__ float tile[3 * S_LH * S_LW];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.z, x0 = blockIdx.x * S_TW, y0 = blockIdx.y * S_TH;
@@ -98,19 +99,26 @@ __global__ __launch_bounds__(256) void k_stem(const float* __restrict__ img, con
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 v[i] = d0[i] + bv[i]; v[4 + i] = d1[i] + bv[4 + i];
-                if (act) { v[i] = silu(v[i]); v[4 + i] = silu(v[4 + i]); }
+                if (act && !pre) { v[i] = silu(v[i]); v[4 + i] = silu(v[4 + i]); }
             }
             u32x4 o = {pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7])};
+            if (pre) {      // training forward: keep the bf16 pre-activation, activate THAT value (adayolo_silu_fwd's arithmetic)
+                *reinterpret_cast<u32x4*>(pre + (((long)b * Hp + gy) * W + gx) * pre_cs + 8 * g) = o;
+                if (act) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) o[j] = silu_bf16x2(o[j]);
+                }
+            }
             *reinterpret_cast<u32x4*>(out + (((long)b * Hp + gy) * W + gx) * out_cs + 8 * g) = o;
         }
     }
 }
 
 hipError_t launch_stem(const float* img, const float* w, const float* bias, void* out, int out_cs, int B, int H,
-                       int W, int Hp, int pad_top, float pad_value, int act, hipStream_t s) {
+                       int W, int Hp, int pad_top, float pad_value, int act, hipStream_t s, void* pre, int pre_cs) {
     dim3 grid((W + S_TW - 1) / S_TW, (Hp + S_TH - 1) / S_TH, B);
     hipLaunchKernelGGL(k_stem, grid, dim3(256), 0, s, img, w, bias, static_cast<unsigned short*>(out), out_cs, H, W,
-                       Hp, pad_top, pad_value, act);
+                       Hp, pad_top, pad_value, act, static_cast<unsigned short*>(pre), pre_cs);
     return hipGetLastError();
 }
 

@@ -7,9 +7,9 @@ import torch
 _HERE = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 # ADAYOLO_LIB: another BUILD of the same library (measurement builds of tools/build_variant.py); never a fallback
 LIB_PATH = os.environ.get("ADAYOLO_LIB") or os.path.join(_HERE, "csrc", "libadayolo.so")
-ABI_VERSION = 6
+ABI_VERSION = 7
 ACT_NONE, ACT_SILU = 0, 1
-EXPORTS = ("adayolo_conv_fwd", "adayolo_conv_fwd_variant", "adayolo_conv_fused1x1_fwd", "adayolo_bottleneck256_fwd", "adayolo_conv_keep_fwd", "adayolo_conv_splitk_fwd", "adayolo_conv_dsilu_fwd", "adayolo_conv_s2grad_fwd", "adayolo_conv_splitk_workspace_bytes", "adayolo_stem_fwd", "adayolo_upsample2x", "adayolo_detect_decode", "adayolo_nms", "adayolo_nms_workspace_bytes", "adayolo_stem_fwd_act", "adayolo_stem_down_fwd", "adayolo_letterbox_pack", "adayolo_silu_fwd", "adayolo_silu_bwd",
+EXPORTS = ("adayolo_conv_fwd", "adayolo_conv_fwd_variant", "adayolo_conv_fused1x1_fwd", "adayolo_bottleneck256_fwd", "adayolo_conv_keep_fwd", "adayolo_conv_splitk_fwd", "adayolo_conv_dsilu_fwd", "adayolo_conv_s2grad_fwd", "adayolo_conv_splitk_workspace_bytes", "adayolo_stem_fwd", "adayolo_upsample2x", "adayolo_detect_decode", "adayolo_nms", "adayolo_nms_workspace_bytes", "adayolo_stem_fwd_act", "adayolo_stem_keep_fwd", "adayolo_stem_down_fwd", "adayolo_letterbox_pack", "adayolo_silu_fwd", "adayolo_silu_bwd",
            "adayolo_zero_insert2x", "adayolo_upsample2x_bwd", "adayolo_image_grad", "adayolo_detloss_fwd", "adayolo_detloss_bwd",
            "adayolo_strerror",
            "adayolo_abi_version")
@@ -58,6 +58,7 @@ def load():
     L.adayolo_detect_decode.argtypes = [vp, ci, vp, ci, ci, vp, cf, ci, ci, ci, ci, ci, vp]
     cl = ctypes.c_long
     L.adayolo_stem_fwd_act.argtypes = [vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, cf, ci, ci, vp]
+    L.adayolo_stem_keep_fwd.argtypes = [vp, vp, vp, vp, ci, vp, ci, ci, ci, ci, ci, ci, cf, ci, vp]
     L.adayolo_stem_down_fwd.argtypes = [vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, cf, vp, vp, vp, ci, vp]
     L.adayolo_stem_down_fwd.restype = ci
     L.adayolo_letterbox_pack.argtypes = [vp, vp, ci, ci, ci, ci, ci, ci, cf, vp]
@@ -67,7 +68,7 @@ def load():
     L.adayolo_zero_insert2x.argtypes = [vp, ci, vp, ci, ci, ci, ci, ci, ci, ci, vp]
     L.adayolo_upsample2x_bwd.argtypes = [vp, ci, vp, ci, ci, ci, ci, ci, ci, vp]
     L.adayolo_image_grad.argtypes = [vp, ci, vp, ci, ci, ci, ci, ci, vp]
-    for n in ("adayolo_stem_fwd_act", "adayolo_stem_down_fwd", "adayolo_letterbox_pack", "adayolo_silu_fwd", "adayolo_silu_bwd", "adayolo_zero_insert2x",
+    for n in ("adayolo_stem_fwd_act", "adayolo_stem_keep_fwd", "adayolo_stem_down_fwd", "adayolo_letterbox_pack", "adayolo_silu_fwd", "adayolo_silu_bwd", "adayolo_zero_insert2x",
               "adayolo_upsample2x_bwd", "adayolo_image_grad"):
         getattr(L, n).restype = ci
     for n in ("adayolo_detloss_fwd", "adayolo_detloss_bwd"):

@@ -229,6 +229,12 @@ class YoloTrainEngine(YoloEngine):
                 rc = self.L.adayolo_stem_fwd_act(ctypes.c_void_p(img.data_ptr()), ctypes.c_void_p(w.data_ptr()),
                                                  ctypes.c_void_p(b.data_ptr()), ctypes.c_void_p(P.ptr), P.cs, self.B, self.H,
                                                  self.W, self.Hp, self.pad_top, LETTERBOX_VALUE, 32, _lib.ACT_NONE, st)
+            elif kind == "stemkeep":                       # stem + its SiLU in one launch (args: the SiLU launch's)
+                w, b, _ = self._stem
+                P = self._stem_pre
+                rc = self.L.adayolo_stem_keep_fwd(ctypes.c_void_p(img.data_ptr()), ctypes.c_void_p(w.data_ptr()),
+                                                  ctypes.c_void_p(b.data_ptr()), args[4], args[5], ctypes.c_void_p(P.ptr), P.cs,
+                                                  self.B, self.H, self.W, self.Hp, self.pad_top, LETTERBOX_VALUE, 32, st)
             elif kind == "imggrad":
                 g = self._gimg
                 rc = self.L.adayolo_image_grad(ctypes.c_void_p(g.ptr), g.cs, ctypes.c_void_p(grad_img.data_ptr()), self.B,
@@ -239,7 +245,7 @@ class YoloTrainEngine(YoloEngine):
                 _lib.check(rc, f"adayolo {kind}")
 
     # kernels whose epilogue stores the pre-activation beside the activation
-    KEEP_VARIANTS = (5, 22, 26, 27, 60) + YoloEngine.SPLITK_CANDIDATES
+    KEEP_VARIANTS = (5, 22, 26, 27, 60, 80, 85) + YoloEngine.SPLITK_CANDIDATES
 
     def _conv_keep_launch(self, *a):
         """adayolo_conv_keep_fwd's argument list (19 + stream); the split-K variants go to their own entry point."""
@@ -261,6 +267,11 @@ class YoloTrainEngine(YoloEngine):
         while i < len(self.tfwd):
             e = self.tfwd[i]
             nxt = self.tfwd[i + 1] if i + 1 < len(self.tfwd) else None
+            if (fuse and e[0] == "stem" and nxt is not None and nxt[0] == "silu" and nxt[2][0].value == self._stem_pre.ptr
+                    and nxt[2][2] is None):
+                plan.append(("stemkeep", None, nxt[2]))
+                i += 2
+                continue
             if (fuse and e[0] == "conv" and nxt is not None and nxt[0] == "silu" and e[2][16] in self.KEEP_VARIANTS
                     and e[2][6].value == nxt[2][0].value):        # the conv's output IS the SiLU kernel's pre-activation
                 a, sl = e[2], nxt[2]

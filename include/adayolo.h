@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define ADAYOLO_ABI_VERSION 6
+#define ADAYOLO_ABI_VERSION 7
 
 #define ADAYOLO_ACT_NONE 0
 #define ADAYOLO_ACT_SILU 1
@@ -136,7 +136,7 @@ int adayolo_stem_down_fwd(const float* img, const float* w_stem, const float* b_
  * Training forward of `Conv` (common.py:45-59) in ONE launch: pre = bf16(conv + bias) is stored (the backward needs
  * silu'(pre)), out = act(pre) (+ residual) is computed from that ROUNDED value — exactly adayolo_conv_fwd_variant with
  * ADAYOLO_ACT_NONE into `pre` followed by adayolo_silu_fwd(pre, residual, out), bit for bit. Served by the kernels whose
- * epilogue has the second output: variants 5 / 22 / 26 / 27 and 60 (EINVAL for any other; ESHAPE when the named kernel
+ * epilogue has the second output: variants 5 / 22 / 26 / 27, 60 and 80 / 85 (EINVAL for any other; ESHAPE when the named kernel
  * does not take the shape — the caller then keeps the two launches).
  */
 int adayolo_conv_keep_fwd(const void* in, int in_cstride, const void* weight, const float* bias, const void* residual,
@@ -168,7 +168,7 @@ int adayolo_conv_splitk_fwd(const void* in, int in_cstride, const void* weight, 
  * `out` (may be NULL: not needed again) receives g, `grad_pre` receives bf16(g * silu'(pre)) computed from that ROUNDED g —
  * bit for bit adayolo_conv_fwd_variant(..., ADAYOLO_ACT_NONE) into a buffer followed by adayolo_silu_bwd on it.
  * `in` / `weight` are what the data-gradient conv takes anyway (dL/d(pre) of the consumer layer, its weights transposed
- * and flipped). Variants 5 / 22 / 26 / 27 / 60 and the split-K ones (then with their workspace, see above; NULL / 0
+ * and flipped). Variants 5 / 22 / 26 / 27 / 60 / 80 / 85 and the split-K ones (then with their workspace, see above; NULL / 0
  * otherwise); EINVAL for any other, ESHAPE when the named kernel does not take the shape.
  */
 int adayolo_conv_dsilu_fwd(const void* in, int in_cstride, const void* weight, const float* bias, const void* residual,
@@ -197,6 +197,13 @@ int adayolo_conv_s2grad_fwd(const void* grad_out, int go_cstride, const void* we
 /* adayolo_stem_fwd with the activation selectable (ADAYOLO_ACT_NONE keeps the pre-activation for training). */
 int adayolo_stem_fwd_act(const float* img, const float* weight, const float* bias, void* out, int out_cstride,
                          int B, int H, int W, int Hp, int pad_top, float pad_value, int Cout, int act, void* stream);
+
+/*
+ * Training forward of the stem in ONE launch: pre = bf16(conv + bias) is stored, out = SiLU of that ROUNDED value — bit for bit
+ * adayolo_stem_fwd_act(ADAYOLO_ACT_NONE) into `pre` followed by adayolo_silu_fwd(pre, NULL, out).
+ */
+int adayolo_stem_keep_fwd(const float* img, const float* weight, const float* bias, void* out, int out_cstride, void* pre,
+                          int pre_cstride, int B, int H, int W, int Hp, int pad_top, float pad_value, int Cout, void* stream);
 
 /*
  * Training side of the frozen reward model (train.py:239-243,262-271,341-342: weights have requires_grad False, the

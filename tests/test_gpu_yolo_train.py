@@ -249,7 +249,7 @@ def test_fused_detection_loss_matches_the_pytorch_loss(B, H, W, dup):
         stale.sum().backward()
 
 
-@pytest.mark.parametrize("variant", [5, 22, 26, 27, 60])
+@pytest.mark.parametrize("variant", [5, 22, 26, 27, 60, 80, 85])
 def test_conv_keep_fwd_equals_conv_then_silu(variant):
     """adayolo_conv_keep_fwd (one launch: pre-activation stored, activation applied to its bf16 value, residual added) ==
     adayolo_conv_fwd_variant(ACT_NONE) into `pre` + adayolo_silu_fwd, bit for bit, on every shape the kernel serves."""
@@ -342,7 +342,7 @@ def test_graph_replay_and_fused_train_forward_change_nothing():
     assert torch.equal(grad_a, grad_b)
 
 
-@pytest.mark.parametrize("variant", [5, 22, 26, 27, 60, 104])
+@pytest.mark.parametrize("variant", [5, 22, 26, 27, 60, 80, 85, 104])
 def test_conv_dsilu_fwd_equals_conv_then_silu_bwd(variant):
     """adayolo_conv_dsilu_fwd (one launch: g = conv + residual rounded to bf16, optionally stored; grad_pre = g * silu'(pre))
     == adayolo_conv_fwd_variant(ACT_NONE) + adayolo_silu_bwd, bit for bit, with and without the stored gradient, on
