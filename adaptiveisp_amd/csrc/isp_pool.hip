@@ -81,30 +81,37 @@ __global__ __launch_bounds__(kThreads) void k_pool64(const float* __restrict__ i
 // grad_pooled[oy][ox] / kh / kw, accumulated oy-major in ascending order (ATen's adaptive_avg_pool2d_backward order).
 // The critic reads the retouched image through this pooling and back-propagates into the filter parameters
 // (train.py:281-305: agent_loss contains -q_value = -(reward + gamma * V(retouch, new_states)) when cfg.use_TD).
+// One thread = one column x over kBwdRows rows: the column's windows (1..2, more when W < 64) and their widths are found once,
+// the rows' are uniform over the workgroup (scalar unit); the per-pixel work is the two divisions and the store.
+constexpr int kBwdRows = 8;
 __global__ __launch_bounds__(kThreads) void k_pool64_bwd(const float* __restrict__ gp, float* __restrict__ gimg, int H,
                                                          int W) {
-    const int x = blockIdx.x * kThreads + threadIdx.x, y = blockIdx.y, bc = blockIdx.z;
+    const int x = blockIdx.x * kThreads + threadIdx.x, bc = blockIdx.z;
     if (x >= W) return;
-    int oy0 = (int)(((long)y * 64) / H), oy1 = oy0;
-    while (oy0 > 0 && win_hi(oy0 - 1, H) > y) --oy0;
-    while (oy1 < 63 && win_lo(oy1 + 1, H) <= y) ++oy1;
-    int ox0 = (int)(((long)x * 64) / W), ox1 = ox0;
+    int ox0 = (int)(((unsigned)x * 64u) / (unsigned)W), ox1 = ox0;
     while (ox0 > 0 && win_hi(ox0 - 1, W) > x) --ox0;
     while (ox1 < 63 && win_lo(ox1 + 1, W) <= x) ++ox1;
     const float* g = gp + (long)bc * 64 * 64;
-    float acc = 0.f;
-    for (int oy = oy0; oy <= oy1; ++oy) {
-        const float kh = (float)(win_hi(oy, H) - win_lo(oy, H));
-        for (int ox = ox0; ox <= ox1; ++ox)
-            acc += g[oy * 64 + ox] / kh / (float)(win_hi(ox, W) - win_lo(ox, W));
+    const int y_end = min((int)(blockIdx.y + 1) * kBwdRows, H);
+    for (int y = blockIdx.y * kBwdRows; y < y_end; ++y) {
+        int oy0 = (int)(((unsigned)y * 64u) / (unsigned)H), oy1 = oy0;
+        while (oy0 > 0 && win_hi(oy0 - 1, H) > y) --oy0;
+        while (oy1 < 63 && win_lo(oy1 + 1, H) <= y) ++oy1;
+        float acc = 0.f;
+        for (int oy = oy0; oy <= oy1; ++oy) {
+            const float kh = (float)(win_hi(oy, H) - win_lo(oy, H));
+            for (int ox = ox0; ox <= ox1; ++ox)
+                acc += g[oy * 64 + ox] / kh / (float)(win_hi(ox, W) - win_lo(ox, W));
+        }
+        gimg[((long)bc * H + y) * W + x] = acc;
     }
-    gimg[((long)bc * H + y) * W + x] = acc;
 }
 
 }  // namespace
 
 hipError_t launch_pool64_bwd(const float* grad_pooled, float* grad_img, int B, int H, int W, hipStream_t s) {
-    hipLaunchKernelGGL(k_pool64_bwd, dim3((W + kThreads - 1) / kThreads, H, B * 3), dim3(kThreads), 0, s, grad_pooled,
+    if ((long)W * 64 >= (1L << 32) || (long)H * 64 >= (1L << 32)) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_pool64_bwd, dim3((W + kThreads - 1) / kThreads, (H + kBwdRows - 1) / kBwdRows, B * 3), dim3(kThreads), 0, s, grad_pooled,
                        grad_img, H, W);
     return hipGetLastError();
 }

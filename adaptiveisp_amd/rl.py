@@ -149,7 +149,17 @@ def train_iteration(cfg, agent, value, detector, loss_fn, imgs, z, states, label
     from . import dist as adist
     from .yolo.loss import batched_per_sample_loss as per_sample_loss
     from .yolo.loss import assign_labels, assign_labels_packed
-    if getattr(detector, "per_sample_loss", None) is not None and os.environ.get("ADAYOLO_FUSED_LOSS", "1") == "1":
+    if getattr(detector, "per_sample_loss_pair", None) is not None:
+        # HIP training engine, pair form (yolo.YoloTrainPairEngine): ONE detector forward over [input batch; retouched batch],
+        # one loss launch for both, the backward over the retouched half only
+        with torch.no_grad():
+            packed, packed_pair = assign_labels_packed(loss_fn, detector.head_shapes(), labels, imgs.device, pair=True)
+        (retouch, new_states, surrogate, penalty), _, _ = agent((imgs, z, states), progress)
+        stats = retouch_stats(retouch)
+        if on_retouch is not None:
+            on_retouch(retouch.detach(), stats)
+        l_in, l_re = detector.per_sample_loss_pair(loss_fn, imgs, retouch, packed, packed_pair)
+    elif getattr(detector, "per_sample_loss", None) is not None and os.environ.get("ADAYOLO_FUSED_LOSS", "1") == "1":
         # HIP training engine: detector forward + one loss launch on its bf16 head maps (csrc/yolo_loss.hip), no fp32 copies.
         # The detection loss of the INPUT batch needs nothing the agent computes: it runs on a second stream beside the
         # agent's forward (a latency chain of ~250 small launches that leaves most CUs idle); the retouched batch's forward

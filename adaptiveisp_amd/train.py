@@ -150,7 +150,7 @@ def build_trainer(cfg, rank, world, device, batch_size, image_size, lr=3e-5, epo
     from .agent import Agent
     from .replay import DeviceReplayMemory, SyntheticSource
     from .value import Value
-    from .yolo import YoloTrainEngine, yolov3
+    from .yolo import YoloTrainEngine, YoloTrainPairEngine, yolov3
     from .yolo.checkpoint import load_detector_checkpoint, load_isp_checkpoint
     from .yolo.loss import DetectionLoss, default_hyp
     H = W = int(image_size)
@@ -168,7 +168,11 @@ def build_trainer(cfg, rank, world, device, batch_size, image_size, lr=3e-5, epo
         p.requires_grad_(False)
     nc = det.model[-1].nc
     loss_fn = DetectionLoss(det.model[-1].anchors, nc=nc, hyp=default_hyp(nc, H), device=device)
-    detector = YoloTrainEngine(det, batch_size, H, W, device=device)
+    # one 2B-image forward for the input + retouched batches (yolo.YoloTrainPairEngine); ADAYOLO_TRAIN_PAIR=0: two B-image passes
+    if os.environ.get("ADAYOLO_TRAIN_PAIR", "1") == "1":
+        detector = YoloTrainPairEngine(det, batch_size, H, W, device=device)
+    else:
+        detector = YoloTrainEngine(det, batch_size, H, W, device=device)
     if tune_cache:
         detector.autotune(cache=tune_cache, write=(rank == 0))
     if source is None:

@@ -95,7 +95,20 @@ class YoloEngine:
 
     # ------------------------------------------------------------------------------------------
     def _new(self, H, W, C):
-        t = torch.empty((self.B, H, W, C), dtype=torch.bfloat16, device=self.dev)
+        """An NHWC bf16 buffer [B,H,W,C]. With `self._shared = (parent, first)` — an engine built over the same model with a
+        larger batch — the buffer IS images [first, first + B) of the parent's buffer of the same allocation index (both
+        constructors walk the model the same way): what the parent's forward leaves there (activations, kept
+        pre-activations) this engine's launches read (YoloTrainPairEngine)."""
+        allocs = self.__dict__.setdefault("_allocs", [])
+        shared = getattr(self, "_shared", None)
+        if shared is not None:
+            parent, first = shared
+            t = parent._allocs[len(allocs)][first:first + self.B]
+            if tuple(t.shape) != (self.B, H, W, C):
+                raise _lib.AdayoloError("shared buffers: the two engines do not allocate alike")
+        else:
+            t = torch.empty((self.B, H, W, C), dtype=torch.bfloat16, device=self.dev)
+        allocs.append(t)
         self._keep.append(t)
         return t
 

@@ -147,7 +147,7 @@ def pack_assigned(assigned):
     return packed
 
 
-def assign_labels_packed(loss_fn, shapes, labels, device):
+def assign_labels_packed(loss_fn, shapes, labels, device, pair=False):
     """`pack_assigned(assign_labels(...))` computed on the HOST in numpy (the labels are a handful of host rows; as
     device-side PyTorch the assignment is ~200 launches and several synchronising boolean gathers, 2 ms per training
     iteration) and moved to `device` in one copy per array. Same float32 arithmetic, same row order as
@@ -168,7 +168,7 @@ def assign_labels_packed(loss_fn, shapes, labels, device):
     tgt = np.concatenate((np.repeat(targets[None], na, 0), ai[..., None]), 2)                 # [na, nt, 7]
     off = np.array([[0, 0], [1, 0], [0, 1], [-1, 0], [0, -1]], f32) * f32(0.5)
     thr = f32(loss_fn.hyp["anchor_t"])
-    packed = []
+    packed, packed2 = [], []                # (`pair`: also the assignment of the batch [labels; labels], see below)
     for i in range(loss_fn.nl):
         ny, nx = int(shapes[i].shape[2]), int(shapes[i].shape[3])
         gain = np.array([1, 1, nx, ny, nx, ny, 1], f32)
@@ -194,9 +194,17 @@ def assign_labels_packed(loss_fn, shapes, labels, device):
         gij[:, 1] = np.clip(gij[:, 1], 0, ny - 1)
         idx = np.stack((t[:, 0].astype(np.int64), a, gij[:, 1], gij[:, 0], t[:, 1].astype(np.int64)), 1).astype(np.int32)
         box = np.concatenate((gxy - gij.astype(f32), gwh, anc[i][a]), 1).astype(f32)
+        if pair:            # the same assignment for the batch [labels; labels]: image ids b and b + B, one upload for both forms
+            n, B = idx.shape[0], len(labels)
+            idx2 = np.concatenate((idx, idx + np.array([B, 0, 0, 0, 0], np.int32)), 0)
+            d_idx = torch.from_numpy(np.ascontiguousarray(idx2)).to(device, non_blocking=True)
+            d_box = torch.from_numpy(np.ascontiguousarray(np.concatenate((box, box), 0))).to(device, non_blocking=True)
+            packed.append((d_idx[:n], d_box[:n]))
+            packed2.append((d_idx, d_box))
+            continue
         packed.append((torch.from_numpy(np.ascontiguousarray(idx)).to(device, non_blocking=True),
                        torch.from_numpy(np.ascontiguousarray(box)).to(device, non_blocking=True)))
-    return packed
+    return (packed, packed2) if pair else packed
 
 
 def batched_per_sample_loss(loss_fn, preds, labels, assigned=None):

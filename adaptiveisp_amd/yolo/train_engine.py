@@ -24,7 +24,13 @@ from .engine import LETTERBOX_VALUE, YoloEngine, _View
 
 
 class YoloTrainEngine(YoloEngine):
-    def __init__(self, model, batch, height, width, device="cuda:0"):
+    def __init__(self, model, batch, height, width, device="cuda:0", share_with=None, first_image=0, capture=("fwd", "bwd")):
+        """`share_with` / `first_image`: this engine's activation buffers are images [first_image, first_image + batch) of
+        that (larger-batch) engine's — its backward then runs on what THAT engine's forward kept (YoloTrainPairEngine).
+        `capture`: which launch sequences are replayed from hipGraphs."""
+        if share_with is not None:
+            self._shared = (share_with, int(first_image))
+        self._capture = tuple(capture)
         super().__init__(model, batch, height, width, device)
         self._gen = 0
         self._build_train()
@@ -398,11 +404,18 @@ class YoloTrainEngine(YoloEngine):
                 torch.cuda.synchronize()
                 side = torch.cuda.Stream()
                 side.wait_stream(torch.cuda.current_stream())
+                cap = self._capture
                 with torch.cuda.stream(side):             # warm-up outside the capture (lazy kernel attributes)
-                    self._run(self._forward_plan(), img=st["img"])
-                    self._run(self._backward_plan(), grad_img=st["grad_img"])
+                    if "fwd" in cap:
+                        self._run(self._forward_plan(), img=st["img"])
+                    if "bwd" in cap:
+                        self._run(self._backward_plan(), grad_img=st["grad_img"])
                 torch.cuda.current_stream().wait_stream(side)
-                for key, plan, kw in (("fwd", self._forward_plan(), dict(img=st["img"])), ("bwd", self._backward_plan(), dict(grad_img=st["grad_img"]))):
+                for key, make, kw in (("fwd", self._forward_plan, dict(img=st["img"])), ("bwd", self._backward_plan, dict(grad_img=st["grad_img"]))):
+                    if key not in cap:
+                        st[key] = False                   # this sequence is launched eagerly (its plan is not even built here:
+                        continue                          # building probes launches on the engine's buffers)
+                    plan = make()
                     g = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(g):
                         self._run(plan, **kw)
@@ -415,11 +428,28 @@ class YoloTrainEngine(YoloEngine):
         with torch.cuda.device(self.dev):
             self._pass_begin()
             try:
-                if st is None:
+                if st is None or not st["fwd"]:
                     self._run(self._forward_plan(), img=img)
                 else:
                     st["img"].copy_(img)
                     st["fwd"].replay()
+            finally:
+                self._pass_end()
+        self._gen += 1
+
+    def _forward_raw_halves(self, first, second):
+        """_forward_raw of the batch [first; second] (two [B/2,3,H,W] tensors) without materialising the concatenation when
+        the sequence replays from a graph (the halves are copied into the graph's input buffer)."""
+        st = self._graph("fwd")
+        if st is None or not st["fwd"]:
+            return self._forward_raw(torch.cat([first, second], 0))
+        h = self.B // 2
+        with torch.cuda.device(self.dev):
+            self._pass_begin()
+            try:
+                st["img"][:h].copy_(first)
+                st["img"][h:].copy_(second)
+                st["fwd"].replay()
             finally:
                 self._pass_end()
         self._gen += 1
@@ -430,7 +460,7 @@ class YoloTrainEngine(YoloEngine):
         with torch.cuda.device(self.dev):
             self._pass_begin()
             try:
-                if st is None:
+                if st is None or not st["bwd"]:
                     grad_img = torch.empty((self.B, 3, self.H, self.W), dtype=torch.float32, device=self.dev)
                     self._run(self._backward_plan(), grad_img=grad_img)
                     return grad_img
@@ -461,16 +491,22 @@ class YoloTrainEngine(YoloEngine):
         import types
         return [types.SimpleNamespace(shape=(self.B, self.na, v.H, v.W, self.no), device=self.dev) for v in self.raw]
 
-    def _loss_args(self, loss_fn, packed):
-        """adayolo_loss_args over this engine's raw maps / gradient buffers and the packed target assignment."""
-        dev, nl = self.dev, len(self.raw)
+    def _loss_workspace(self):
+        """What the loss forward leaves for its backward (objectness targets, match counts) + the reduction scratch."""
         ws = getattr(self, "_loss_ws", None)
         if ws is None:
+            dev = self.dev
             ws = self._loss_ws = dict(
                 tobj=[torch.empty((self.B, self.na, v.H, v.W), dtype=torch.float32, device=dev) for v in self.raw],
                 cnt=[torch.empty((self.B,), dtype=torch.float32, device=dev) for _ in self.raw],
                 part=[torch.empty((self.B, 3), dtype=torch.float32, device=dev) for _ in self.raw],
                 ticket=torch.zeros((self.B,), dtype=torch.int32, device=dev))
+        return ws
+
+    def _loss_args(self, loss_fn, packed):
+        """adayolo_loss_args over this engine's raw maps / gradient buffers and the packed target assignment."""
+        dev, nl = self.dev, len(self.raw)
+        ws = self._loss_workspace()
         a = _lib.LossArgs()
         keep = []
         for i, (v, gv, (idx, box)) in enumerate(zip(self.raw, self._graw, packed)):
@@ -553,3 +589,78 @@ class _DetectorFn(torch.autograd.Function):
             raise RuntimeError("YoloTrainEngine: backward after a newer forward overwrote the saved pre-activations "
                                "(one engine holds one set of buffers; use a second engine for interleaved graphs)")
         return eng.backward_image(grads), None
+
+
+class YoloTrainPairEngine:
+    """The detector of one RL iteration (train.py:262-271): the detection loss of the INPUT batch (a constant) and of the
+    RETOUCHED batch (differentiable) — two forwards of B images in the reference. Here ONE forward of 2B images (the deep
+    layers of a 512 x 512 input are 16 x 16 maps: at B = 8 their launches cannot fill 256 CUs; measured 2.90 ms against
+    2 x 2.02 at 8 x 512 x 512) and the backward over the second half only: a B-image engine whose activation buffers ARE
+    images [B, 2B) of the 2B engine's reads the pre-activations that forward kept. Same kernels, same per-image arithmetic
+    as two YoloTrainEngine passes (a conv output depends on its own image only); what may differ is the kernel variant the
+    tuning table holds for the 2B shapes, i.e. bf16 rounding of the forward."""
+
+    def __init__(self, model, batch, height, width, device="cuda:0"):
+        self.B = int(batch)
+        self.full = YoloTrainEngine(model, 2 * self.B, height, width, device, capture=("fwd",))
+        self.half = YoloTrainEngine(model, self.B, height, width, device, share_with=self.full, first_image=self.B,
+                                    capture=("bwd",))
+        ws = self.full._loss_workspace()
+        B = self.B
+        self.half._loss_ws = dict(tobj=[t[B:] for t in ws["tobj"]], cnt=[t[B:] for t in ws["cnt"]],
+                                  part=[t[B:] for t in ws["part"]], ticket=ws["ticket"][B:])
+        self.dev, self.H, self.W = self.full.dev, self.full.H, self.full.W
+
+    def autotune(self, cache=None, write=True, **kw):
+        self.full.autotune(cache=cache, write=write, **kw)
+        return self.half.autotune(cache=cache, write=write, **kw)
+
+    def head_shapes(self):
+        return self.half.head_shapes()
+
+    def per_sample_loss_pair(self, loss_fn, imgs, retouch, packed, packed_pair):
+        """(loss of `imgs` [B,1], a constant; loss of `retouch` [B,1] with autograd to `retouch`). `packed`: the target
+        assignment of the B label sets, `packed_pair` the same for [labels; labels] (loss.assign_labels_packed(pair=True))."""
+        for t in (imgs, retouch):
+            if t.shape != (self.B, 3, self.H, self.W) or t.dtype != torch.float32 or t.device != self.dev:
+                raise ValueError(f"expected fp32 {(self.B, 3, self.H, self.W)} on {self.dev}")
+        if torch.is_grad_enabled() and retouch.requires_grad:
+            return _PairLossFn.apply(retouch, imgs, self, loss_fn, packed, packed_pair)
+        both = self._forward_losses(loss_fn, imgs, retouch, packed_pair)
+        return both[:self.B], both[self.B:]
+
+    def _forward_losses(self, loss_fn, imgs, retouch, packed_pair):
+        full = self.full
+        if loss_fn.nc + 5 != full.no or len(packed_pair) != len(full.raw) or loss_fn.hyp.get("fl_gamma", 0.0) != 0.0:
+            raise ValueError("loss / detector mismatch (classes, layers) or focal loss requested: use the PyTorch loss")
+        loss = torch.empty((2 * self.B,), dtype=torch.float32, device=self.dev)
+        full._forward_raw_halves(imgs.detach().contiguous(), retouch.detach().contiguous())
+        self.half._gen += 1
+        with torch.cuda.device(self.dev):
+            a, keep = full._loss_args(loss_fn, packed_pair)
+            a.loss = loss.data_ptr()
+            _lib.check(full.L.adayolo_detloss_fwd(ctypes.byref(a), _lib.stream_ptr()), "adayolo_detloss_fwd")
+        return loss.view(2 * self.B, 1)
+
+
+class _PairLossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, retouch, imgs, pair, loss_fn, packed, packed_pair):
+        both = pair._forward_losses(loss_fn, imgs, retouch, packed_pair)
+        ctx.pair, ctx.gen, ctx.loss_fn, ctx.packed = pair, pair.half._gen, loss_fn, packed
+        l_in, l_re = both[:pair.B], both[pair.B:]
+        ctx.mark_non_differentiable(l_in)
+        return l_in, l_re
+
+    @staticmethod
+    def backward(ctx, _g_in, grad_loss):
+        eng = ctx.pair.half
+        if ctx.gen != eng._gen:
+            raise RuntimeError("YoloTrainPairEngine: backward after a newer forward overwrote the saved pre-activations")
+        g = grad_loss.reshape(eng.B).float().contiguous()
+        with torch.cuda.device(eng.dev):
+            a, keep = eng._loss_args(ctx.loss_fn, ctx.packed)
+            scratch = torch.empty((eng.B,), dtype=torch.float32, device=eng.dev)
+            a.loss, a.grad_loss = scratch.data_ptr(), g.data_ptr()
+            _lib.check(eng.L.adayolo_detloss_bwd(ctypes.byref(a), _lib.stream_ptr()), "adayolo_detloss_bwd")
+        return eng._backward_raw(), None, None, None, None, None

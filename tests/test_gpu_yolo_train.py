@@ -547,3 +547,65 @@ def test_config4_shape_tuned_engine_vs_fp32_autograd():
     for i in range(B):                                    # every image of the batch on its own: a wrong tile of one image cannot hide
         _margins.vector_close("yolo.train_engine_image_grad_8x512x512", xh.grad[i], xr.grad[i], max_rel=0.025, min_cos=0.9995)
     _margins.vector_close("yolo.train_engine_image_grad_8x512x512.batch", xh.grad, xr.grad, max_rel=0.025, min_cos=0.9995)
+
+
+@pytest.mark.parametrize("B,H,W", [(2, 64, 96), (8, 512, 512)])
+def test_pair_engine_equals_two_single_passes(B, H, W):
+    """YoloTrainPairEngine — ONE forward over [input batch; retouched batch], the backward over the retouched half on the
+    buffers that forward filled — against two YoloTrainEngine passes: where both run the same kernels (small shape, no tuning
+    table) the per-image losses and the image gradient are bit-identical (a conv output depends on its own image only); with
+    other variants / reduction splits for the 2B shapes they agree to bf16 rounding."""
+    from _margins import close_scaled, vector_close
+    from _synth import synth_yolo_state_dict, test_image
+    from adaptiveisp_amd.yolo import YoloTrainEngine, YoloTrainPairEngine, yolov3
+    from adaptiveisp_amd.yolo.loss import DetectionLoss, assign_labels_packed, default_hyp
+    det = yolov3()
+    det.load_state_dict(synth_yolo_state_dict(det, seed=2))
+    det = det.to(DEV).train()
+    for p in det.parameters():
+        p.requires_grad_(False)
+    loss_fn = DetectionLoss(det.model[-1].anchors, nc=80, hyp=default_hyp(80, max(H, W)), device=DEV)
+    g = torch.Generator().manual_seed(B * 1000 + H)
+    labels = _labels(B, g, True)
+    imgs = torch.from_numpy(test_image(B, H, W, seed=17, special=False)).to(DEV)
+    retouch = torch.from_numpy(test_image(B, H, W, seed=23, special=False)).to(DEV)
+    wgt = (torch.rand(B, 1, generator=g) + 0.5).to(DEV)
+    single = YoloTrainEngine(det, B, H, W, device=DEV)
+    pair = YoloTrainPairEngine(det, B, H, W, device=DEV)
+    for tuned in (False, True):
+        if tuned:
+            import os
+            table = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "adaptiveisp_amd", "yolo", "tuning", "mi355x.json")
+            single.autotune(cache=table, write=False)
+            pair.autotune(cache=table, write=False)
+        packed, packed_pair = assign_labels_packed(loss_fn, pair.head_shapes(), labels, DEV, pair=True)
+        for (i1, b1), (i2, b2) in zip(packed, packed_pair):
+            n = i1.shape[0]
+            assert i2.shape[0] == 2 * n and torch.equal(i2[:n], i1) and torch.equal(i2[n:, 0], i1[:, 0] + B)
+            assert torch.equal(i2[n:, 1:], i1[:, 1:]) and torch.equal(b2[:n], b1) and torch.equal(b2[n:], b1)
+        with torch.no_grad():
+            l_in_ref = single.per_sample_loss(loss_fn, imgs, packed)
+        xr = retouch.clone().requires_grad_(True)
+        l_re_ref = single.per_sample_loss(loss_fn, xr, packed)
+        (l_re_ref * wgt).sum().backward()
+        xp = retouch.clone().requires_grad_(True)
+        l_in, l_re = pair.per_sample_loss_pair(loss_fn, imgs, xp, packed, packed_pair)
+        assert not l_in.requires_grad and l_re.requires_grad
+        (l_re * wgt).sum().backward()
+        torch.cuda.synchronize()
+        if not tuned and B == 2:                         # (at 8 x 512 x 512 the default kernel's split of the deep layers' reduction follows the batch)
+            assert torch.equal(l_in, l_in_ref) and torch.equal(l_re.detach(), l_re_ref.detach())
+            assert torch.equal(xp.grad, xr.grad)
+        else:
+            close_scaled("yolo.pair_engine.loss", torch.cat([l_in, l_re.detach()]), torch.cat([l_in_ref, l_re_ref.detach()]), 2e-2)
+            vector_close("yolo.pair_engine.image_grad", xp.grad, xr.grad, max_rel=5e-2, min_cos=0.998)
+        with torch.no_grad():                                              # the no-grad form: the same numbers
+            a, b = pair.per_sample_loss_pair(loss_fn, imgs, retouch, packed, packed_pair)
+        assert torch.equal(a, l_in) and torch.equal(b, l_re.detach())
+    # a backward after a newer forward fails loudly
+    xs = retouch.clone().requires_grad_(True)
+    _, stale = pair.per_sample_loss_pair(loss_fn, imgs, xs, packed, packed_pair)
+    with torch.no_grad():
+        pair.per_sample_loss_pair(loss_fn, imgs, retouch, packed, packed_pair)
+    with pytest.raises(RuntimeError):
+        stale.sum().backward()

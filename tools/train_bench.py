@@ -34,7 +34,11 @@ for name in ([os.environ["TRAIN_BENCH_ONLY"]] if os.environ.get("TRAIN_BENCH_ONL
         value = value.to(memory_format=torch.channels_last)
     loss_fn = DetectionLoss(det.model[-1].anchors, nc=80, hyp=default_hyp(80, HW), device=DEV)
     replay = DeviceReplayMemory(cfg, SyntheticSource((3, HW, HW), seed=1, device=DEV), B, DEV, (3, HW, HW), rng=random.Random(1))
-    detector = YoloTrainEngine(det, B, HW, HW, device=DEV) if name == "hip" else det
+    if name == "hip":
+        from adaptiveisp_amd.yolo import YoloTrainPairEngine
+        detector = (YoloTrainPairEngine if os.environ.get("ADAYOLO_TRAIN_PAIR", "1") == "1" else YoloTrainEngine)(det, B, HW, HW, device=DEV)
+    else:
+        detector = det
     if name == "hip":
         detector.autotune(cache=os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "adaptiveisp_amd", "yolo", "tuning", "mi355x.json"))
     tr = Trainer(cfg, agent, value, detector, loss_fn, replay, batch_size=B)
@@ -69,6 +73,9 @@ for name in ([os.environ["TRAIN_BENCH_ONLY"]] if os.environ.get("TRAIN_BENCH_ONL
           f".cpu() copies) -> {(t_host - waited[0]) / iters * 1e3:.1f} ms of enqueue work")
     # detector forward+backward alone
     x = torch.rand(B, 3, HW, HW, device=DEV, requires_grad=True)
+    if hasattr(detector, "half"):                                 # pair engine: its B-image member (own forward here)
+        detector = YoloTrainEngine(det, B, HW, HW, device=DEV)
+        detector.autotune(cache=os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "adaptiveisp_amd", "yolo", "tuning", "mi355x.json"), write=False)
     for _ in range(2):
         sum(r.float().sum() for r in detector(x)).backward()
     torch.cuda.synchronize()
