@@ -16,7 +16,7 @@ import random
 import numpy as np
 import torch
 
-from .util import STATE_STEP_DIM, STATE_STOPPED_DIM, Dict
+from .util import STATE_STEP_DIM, STATE_STOPPED_DIM, Dict, to_device_async
 
 
 class DeviceReplayMemory:
@@ -89,18 +89,21 @@ class DeviceReplayMemory:
         """-> dict(im [B,3,H,W] device tensor (a gather, no host copy), label, path, shape, state [B,S] device,
         z [B,z_dim] device, records)."""
         batch = self.get_next_fake_batch(batch_size)
-        idx = torch.tensor([r.slot for r in batch], dtype=torch.long, device=self.device)
-        states = torch.from_numpy(np.stack([r.state for r in batch], 0)).to(self.device)
-        z = torch.from_numpy(self.get_noise(batch_size)).to(self.device)
+        # pinned staging + asynchronous copies: a pageable source would make each of these wait for the whole stream
+        idx = to_device_async([r.slot for r in batch], self.device, dtype=torch.long)
+        states = to_device_async(np.stack([r.state for r in batch], 0), self.device)
+        z = to_device_async(self.get_noise(batch_size), self.device)
         return dict(im=self.images.index_select(0, idx), label=[r.label for r in batch], path=[r.path for r in batch],
-                    shape=[r.shape for r in batch], state=states, z=z, records=batch)
+                    shape=[r.shape for r in batch], state=states, z=z, records=batch, slots=idx)
 
-    def replace_memory(self, batch, retouch, new_states):
+    def replace_memory(self, batch, retouch, new_states, slots=None):
         """Re-insert the retouched batch: `retouch` [B,3,H,W] device tensor is scattered into the records' own slots,
-        `new_states` [B,S] (device or host) becomes their state. Over-long trajectories are kept with probability
-        cfg.over_length_keep_prob; then the pool is topped up with fresh records."""
+        `new_states` [B,S] becomes their state — pass it as a HOST array where the loop must not stall (a device tensor is
+        read back with a blocking copy, i.e. after everything enqueued so far). `slots`: the records' slot indices on the
+        device if the caller still has them (get_feed_dict_and_states()["slots"]). Over-long trajectories are kept with
+        probability cfg.over_length_keep_prob; then the pool is topped up with fresh records."""
         states = new_states.detach().cpu().numpy() if isinstance(new_states, torch.Tensor) else np.asarray(new_states)
-        idx = torch.tensor([r.slot for r in batch], dtype=torch.long, device=self.device)
+        idx = slots if slots is not None else to_device_async([r.slot for r in batch], self.device, dtype=torch.long)
         self.images.index_copy_(0, idx, retouch.detach().to(self.images.dtype))
         self.rng.shuffle(self.image_pool)
         for i, r in enumerate(batch):

@@ -143,8 +143,8 @@ def train_iteration(cfg, agent, value, detector, loss_fn, imgs, z, states, label
     """One optimisation step (train.py:255-351). `detector(x)` must return the three raw head maps with autograd
     through to x (the frozen reward model); `buckets` (adaptiveisp_amd.dist.GradBucket per model) enables the
     data-parallel gradient all-reduce before the 1e-5 clip. `on_retouch(retouch)` is called as soon as the retouched batch
-    is enqueued, with `retouch_stats(retouch)` as second argument (the trainer starts its NaN / brightness guard there, long
-    before the iteration's backward is launched).
+    is enqueued, with `retouch_stats(retouch)` and the new state vectors as further arguments (the trainer starts its NaN /
+    brightness guard and the read-back of the states there, long before the iteration's backward is launched).
     Returns the scalars of td_losses plus the retouched batch."""
     from . import dist as adist
     from .yolo.loss import batched_per_sample_loss as per_sample_loss
@@ -157,7 +157,7 @@ def train_iteration(cfg, agent, value, detector, loss_fn, imgs, z, states, label
         (retouch, new_states, surrogate, penalty), _, _ = agent((imgs, z, states), progress)
         stats = retouch_stats(retouch)
         if on_retouch is not None:
-            on_retouch(retouch.detach(), stats)
+            on_retouch(retouch.detach(), stats, new_states.detach())
         l_in, l_re = detector.per_sample_loss_pair(loss_fn, imgs, retouch, packed, packed_pair)
     elif getattr(detector, "per_sample_loss", None) is not None and os.environ.get("ADAYOLO_FUSED_LOSS", "1") == "1":
         # HIP training engine: detector forward + one loss launch on its bf16 head maps (csrc/yolo_loss.hip), no fp32 copies.
@@ -175,14 +175,14 @@ def train_iteration(cfg, agent, value, detector, loss_fn, imgs, z, states, label
             (retouch, new_states, surrogate, penalty), _, _ = agent((imgs, z, states), progress)
             stats = retouch_stats(retouch)
             if on_retouch is not None:
-                on_retouch(retouch.detach(), stats)
+                on_retouch(retouch.detach(), stats, new_states.detach())
             cur.wait_stream(side)                           # the engine's buffers are free again
             l_in.record_stream(cur)
         else:
             (retouch, new_states, surrogate, penalty), _, _ = agent((imgs, z, states), progress)
             stats = retouch_stats(retouch)
             if on_retouch is not None:
-                on_retouch(retouch.detach(), stats)
+                on_retouch(retouch.detach(), stats, new_states.detach())
             with torch.no_grad():
                 l_in = detector.per_sample_loss(loss_fn, imgs, packed)
         l_re = detector.per_sample_loss(loss_fn, retouch, packed)
@@ -190,7 +190,7 @@ def train_iteration(cfg, agent, value, detector, loss_fn, imgs, z, states, label
         (retouch, new_states, surrogate, penalty), _, _ = agent((imgs, z, states), progress)
         stats = retouch_stats(retouch)
         if on_retouch is not None:
-            on_retouch(retouch.detach(), stats)
+            on_retouch(retouch.detach(), stats, new_states.detach())
         with torch.no_grad():
             p_in = detector(imgs)
             assigned = assign_labels(loss_fn, p_in, labels)      # same labels, same map shapes for both batches

@@ -46,7 +46,7 @@ class Trainer:
         self.value_scheduler = torch.optim.lr_scheduler.LambdaLR(self.value_optimizer, lr_lambda=lf)
         self.buckets = [adist.GradBucket(agent, value)]          # ONE flattened bucket = one collective per iteration
         self.iter = 0
-        self._flag_host = None
+        self._flag_host = self._states_host = None
         adist.broadcast_parameters([agent, value], src=0)
         self.history = []
 
@@ -61,7 +61,7 @@ class Trainer:
         labels = [torch.as_tensor(lb) for lb in feed["label"]]
         guard = {}
 
-        def start_guard(retouch, stats):
+        def start_guard(retouch, stats, new_states):
             """The reference's check of the retouched batch (train.py:374-381: NaN / too dark / too bright -> the records are
             dropped instead of re-entering the pool) from the batch's per-image statistics (rl.retouch_stats: [B,2] mean /
             non-finite count). They exist as soon as the filters have run, so the flag is made THEN, on a second stream, and
@@ -72,18 +72,24 @@ class Trainer:
                 mean = stats[:, 0].mean()
                 return ((stats[:, 1].sum() > 0) | ~torch.isfinite(mean) | (mean < 0.01) | (mean > self.max_bri)).reshape(1)
             if not retouch.is_cuda:
-                guard["bad"] = bool(flag())
+                guard["bad"], guard["states"] = bool(flag()), new_states.cpu().numpy()
                 return
             from .rl import _side_stream
             cur, side = torch.cuda.current_stream(), _side_stream(retouch.device)
-            if self._flag_host is None:
+            if self._flag_host is None or self._states_host.shape != new_states.shape:
                 self._flag_host = torch.empty((1,), dtype=torch.bool, pin_memory=True)
+                self._states_host = torch.empty(new_states.shape, dtype=new_states.dtype, pin_memory=True)
             side.wait_stream(cur)
             with torch.cuda.stream(side):
                 self._flag_host.copy_(flag(), non_blocking=True)
+                # the replay pool keeps the records' states on the host (replay.replace_memory): read back HERE, behind the same
+                # event — a .cpu() at the end of the iteration waits for its whole backward and leaves the GPU idle while the
+                # host enqueues the next iteration
+                self._states_host.copy_(new_states, non_blocking=True)
                 guard["event"] = torch.cuda.Event()
                 guard["event"].record(side)
             stats.record_stream(side)
+            new_states.record_stream(side)
 
         out = train_iteration(self.cfg, self.agent, self.value, self.detector, self.loss_fn, feed["im"], feed["z"],
                               feed["state"], labels, progress, [self.agent_optimizer, self.value_optimizer],
@@ -93,14 +99,14 @@ class Trainer:
         self.value_scheduler.step()
         retouch = out["retouch"]
         if "event" in guard:
-            guard["event"].synchronize()                     # that flag only: the iteration's backward may still be running
-            bad = bool(self._flag_host[0])
+            guard["event"].synchronize()                     # the flag and the states only: the iteration's backward may still be running
+            bad, states_host = bool(self._flag_host[0]), self._states_host.numpy().copy()
         else:
-            bad = guard["bad"]
+            bad, states_host = guard["bad"], guard["states"]
         if bad:
             self.replay.drop_batch(feed["records"])
         else:
-            self.replay.replace_memory(feed["records"], retouch, out["new_states"])
+            self.replay.replace_memory(feed["records"], retouch, states_host, slots=feed.get("slots"))
         # losses stay device tensors here: converting them would wait for the whole iteration; `materialize()` (called by
         # train() at its end, by save(), and by anyone who wants numbers) turns them into floats
         rec = dict(iter=it, agent_loss=out["agent_loss"].detach(), value_loss=out["value_loss"].detach(),

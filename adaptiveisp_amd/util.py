@@ -51,3 +51,13 @@ def get_noise(batch_size, z_type="uniform", z_dim=27):
 def get_initial_states(batch_size, num_state_dim, filters_number):
     """All-zero states: nothing rewarded, nothing stopped, step 0, no filter used yet."""
     return np.zeros((batch_size, num_state_dim), dtype=np.float32)
+
+
+def to_device_async(array, device, dtype=None):
+    """A host array on `device` without draining the stream: staged in pinned memory (the caching host allocator keeps the
+    block alive until the copy has run) and copied with non_blocking=True. A pageable source makes torch's copy synchronise
+    the stream — i.e. wait for every kernel enqueued so far — which costs the RL loop its whole host / device overlap."""
+    t = torch.as_tensor(array) if dtype is None else torch.as_tensor(array, dtype=dtype)
+    if torch.device(device).type != "cuda":
+        return t.to(device)
+    return t.pin_memory().to(device, non_blocking=True)

@@ -168,7 +168,7 @@ def assign_labels_packed(loss_fn, shapes, labels, device, pair=False):
     tgt = np.concatenate((np.repeat(targets[None], na, 0), ai[..., None]), 2)                 # [na, nt, 7]
     off = np.array([[0, 0], [1, 0], [0, 1], [-1, 0], [0, -1]], f32) * f32(0.5)
     thr = f32(loss_fn.hyp["anchor_t"])
-    packed, packed2 = [], []                # (`pair`: also the assignment of the batch [labels; labels], see below)
+    packed, packed2, host = [], [], []      # (`pair`: also the assignment of the batch [labels; labels], see below)
     for i in range(loss_fn.nl):
         ny, nx = int(shapes[i].shape[2]), int(shapes[i].shape[3])
         gain = np.array([1, 1, nx, ny, nx, ny, 1], f32)
@@ -194,16 +194,30 @@ def assign_labels_packed(loss_fn, shapes, labels, device, pair=False):
         gij[:, 1] = np.clip(gij[:, 1], 0, ny - 1)
         idx = np.stack((t[:, 0].astype(np.int64), a, gij[:, 1], gij[:, 0], t[:, 1].astype(np.int64)), 1).astype(np.int32)
         box = np.concatenate((gxy - gij.astype(f32), gwh, anc[i][a]), 1).astype(f32)
-        if pair:            # the same assignment for the batch [labels; labels]: image ids b and b + B, one upload for both forms
-            n, B = idx.shape[0], len(labels)
-            idx2 = np.concatenate((idx, idx + np.array([B, 0, 0, 0, 0], np.int32)), 0)
-            d_idx = torch.from_numpy(np.ascontiguousarray(idx2)).to(device, non_blocking=True)
-            d_box = torch.from_numpy(np.ascontiguousarray(np.concatenate((box, box), 0))).to(device, non_blocking=True)
-            packed.append((d_idx[:n], d_box[:n]))
-            packed2.append((d_idx, d_box))
-            continue
-        packed.append((torch.from_numpy(np.ascontiguousarray(idx)).to(device, non_blocking=True),
-                       torch.from_numpy(np.ascontiguousarray(box)).to(device, non_blocking=True)))
+        host.append((np.ascontiguousarray(idx), np.ascontiguousarray(box)))
+    # ONE upload for all layers (int32 words; the fp32 boxes travel as their bit patterns) from pinned memory: a copy per array
+    # from pageable memory makes torch synchronise the stream each time — the training loop would drain the GPU every iteration
+    B = len(labels)
+    parts = []
+    for idx, box in host:
+        parts += [idx.reshape(-1)] + ([(idx + np.array([B, 0, 0, 0, 0], np.int32)).reshape(-1)] if pair else [])
+        parts += [box.reshape(-1).view(np.int32)] * (2 if pair else 1)
+    flat = np.concatenate(parts) if parts else np.zeros((0,), np.int32)
+    dflat = torch.from_numpy(flat)
+    if torch.device(device).type == "cuda":
+        dflat = dflat.pin_memory().to(device, non_blocking=True)
+    else:
+        dflat = dflat.to(device)
+    off = 0
+    for idx, box in host:
+        n = idx.shape[0]
+        k = 2 if pair else 1
+        d_idx = dflat[off:off + k * n * 5].view(k * n, 5)
+        off += k * n * 5
+        d_box = dflat[off:off + k * n * 6].view(torch.float32).view(k * n, 6)
+        off += k * n * 6
+        packed.append((d_idx[:n], d_box[:n]))
+        packed2.append((d_idx, d_box))
     return (packed, packed2) if pair else packed
 
 

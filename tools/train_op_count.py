@@ -12,7 +12,7 @@ from adaptiveisp_amd.config import cfg
 from adaptiveisp_amd.replay import DeviceReplayMemory, SyntheticSource
 from adaptiveisp_amd.train import Trainer
 from adaptiveisp_amd.value import Value
-from adaptiveisp_amd.yolo import YoloTrainEngine, yolov3
+from adaptiveisp_amd.yolo import YoloTrainEngine, YoloTrainPairEngine, yolov3
 from adaptiveisp_amd.yolo.loss import DetectionLoss, default_hyp
 
 B, HW, DEV = 8, 512, "cuda:0"
@@ -24,7 +24,7 @@ agent = Agent(cfg, shape=(16, 64, 64), device=DEV).to(DEV)
 value = Value(cfg, shape=(19, 64, 64)).to(DEV)
 loss_fn = DetectionLoss(det.model[-1].anchors, nc=80, hyp=default_hyp(80, HW), device=DEV)
 replay = DeviceReplayMemory(cfg, SyntheticSource((3, HW, HW), seed=1, device=DEV), B, DEV, (3, HW, HW), rng=random.Random(1))
-detector = YoloTrainEngine(det, B, HW, HW, device=DEV)
+detector = (YoloTrainPairEngine if os.environ.get("ADAYOLO_TRAIN_PAIR", "1") == "1" else YoloTrainEngine)(det, B, HW, HW, device=DEV)
 detector.autotune(cache=os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "adaptiveisp_amd", "yolo", "tuning", "mi355x.json"), write=False)
 tr = Trainer(cfg, agent, value, detector, loss_fn, replay, batch_size=B)
 tr.train(2)
