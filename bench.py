@@ -671,7 +671,8 @@ def extra_train_iteration(dev, iters=8):
     except Exception as e:                                   # noqa: BLE001 (measurement aid only)
         print(f"[bench] train_iteration: kernel time unavailable ({type(e).__name__}: {e})", file=sys.stderr)
     tr.materialize()
-    return {"workload": "config 4, per rank: RL iteration (agent + value + replay + frozen YOLOv3 fwd x2 + data gradient) batch 8 x 512x512",
+    return {"workload": "config 4, per rank: RL iteration (agent + value + replay + frozen YOLOv3 on the input and the retouched batch + data gradient) batch 8 x 512x512",
+            "detector": "one 16-image forward + 8-image backward" if hasattr(tr.detector, "half") else "two 8-image forwards + backward",
             "ms_per_iteration": round(dt * 1e3, 2), "images_per_sec": round(8 / dt, 1), "iters": iters,
             "host_enqueue_ms": round((t_host - waited[0]) / iters * 1e3, 2), "host_wait_ms": round(waited[0] / iters * 1e3, 2),
             "kernel_ms": round(kernel_ms, 2) if kernel_ms is not None else None, "kernels_per_iteration": n_kernels}
