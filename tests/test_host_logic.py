@@ -230,3 +230,15 @@ def test_pool_cache_stands_aside_for_inference_tensors():
     assert Agent._version_of(u) == v0 + 1
     with torch.inference_mode():
         assert Agent._version_of(u) == v0 + 1
+
+
+def test_retouch_stats_host_form():
+    """rl.retouch_stats without a GPU: per-image mean and non-finite count (the TD brightness test + the replay guard)."""
+    from adaptiveisp_amd import rl
+    x = torch.rand(3, 3, 5, 7, generator=torch.Generator().manual_seed(1))
+    x[1, 0, 2, 3] = float("nan")
+    x[1, 2, 0, 0] = float("inf")
+    st = rl.retouch_stats(x.requires_grad_(True))
+    assert st.shape == (3, 2) and not st.requires_grad
+    assert st[:, 1].tolist() == [0.0, 2.0, 0.0]
+    assert torch.allclose(st[[0, 2], 0], x.detach()[[0, 2]].mean(dim=(1, 2, 3))) and not torch.isfinite(st[1, 0])

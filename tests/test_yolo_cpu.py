@@ -140,3 +140,17 @@ def test_host_target_assignment_equals_the_torch_one(seed):
         assert gi.dtype == torch.int32 and gb.dtype == torch.float32
         assert gi.shape == wi.shape and torch.equal(gi, wi)
         assert gb.shape == wb.shape and torch.equal(gb, wb)
+    # pair form (one detector forward over [input batch; retouched batch], yolo.YoloTrainPairEngine): the same rows, then the
+    # same rows again with image ids b + B; the B-image assignment is its leading half — what the labels duplicated would give
+    one, two = assign_labels_packed(loss_fn, shapes, labels, "cpu", pair=True)
+    dup = [types.SimpleNamespace(shape=(2 * B,) + tuple(sh.shape[1:]), device=sh.device) for sh in shapes]
+    ref2 = assign_labels_packed(loss_fn, dup, labels + labels, "cpu")
+    for (oi, ob), (ti, tb), (wi, wb), (ri, rb) in zip(one, two, want, ref2):
+        n = wi.shape[0]
+        assert torch.equal(oi, wi) and torch.equal(ob, wb) and oi.is_contiguous() and ob.is_contiguous()
+        assert ti.shape == (2 * n, 5) and tb.shape == (2 * n, 6) and torch.equal(ti[:n], wi) and torch.equal(tb[n:], wb)
+        assert torch.equal(ti[n:, 0], wi[:, 0] + B) and torch.equal(ti[n:, 1:], wi[:, 1:])
+        # the duplicated labels give the same ROWS per image in the same relative order (the order the kernels' per-image
+        # sums run in); across images build_targets interleaves them differently
+        for b in range(2 * B):
+            assert torch.equal(ti[ti[:, 0] == b], ri[ri[:, 0] == b]) and torch.equal(tb[ti[:, 0] == b], rb[ri[:, 0] == b])
