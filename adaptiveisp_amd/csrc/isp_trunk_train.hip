@@ -3,7 +3,7 @@
 // train.py:258,282-283 runs them). Through the vendor libraries one pass of one trunk is ~150 launches (layout
 // transposes, im2col-style helpers, per-layer BatchNorm kernels, element-wise backward nodes) of a few microseconds each on
 // tensors of 0.1-1 MB: the RL iteration runs four such passes and is bound by the host's enqueue work. Here one C call
-// enqueues the whole pass — 8 launches forward, 11-13 backward — for up to two trunk instances at once:
+// enqueues the whole pass — 8 launches forward, 11-15 backward — for up to two trunk instances at once:
 //
 //   k_tconv_fwd  the conv as an implicit GEMM D[co][px] = W[co][k] . X[k][px] on v_mfma_f32_16x16x4_f32 (fp32 products and
 //                sums), operands straight from global memory / L2 like the eval kernel (isp_policy.hip), input channels split
@@ -13,7 +13,8 @@
 //   k_tbn_bwd    the same shape backward: LeakyReLU', the two BatchNorm sums, dy (the gradient at the conv output),
 //                dgamma / dbeta / dbias
 //   k_twgrad     dW[co][ci][tap] = sum_px dy[co][px] a_in[ci][px + tap]: a 16 co x 16 tap tile of ONE input channel per
-//                workgroup, pixels split over up to 16 waves
+//                workgroup, pixels split over up to 16 waves; the wide early layers also over up to 8 workgroups, whose
+//                partial tiles k_twgrad_reduce adds in index order
 //   k_tdgrad     da_in[ci][px] = sum_co,tap dy[co][..] W[co][ci][tap] per pixel-parity class (a stride-2 k4 conv reaches an
 //                input pixel through exactly 2 x 2 taps), output channels split over up to 16 waves
 //   k_tplane_sum gradient of the state vector = the sum over its constant planes (first layer, critic only)

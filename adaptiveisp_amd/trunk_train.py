@@ -4,7 +4,7 @@
 reference agent.py:26-60 / value.py:6-44 — is ~13 ATen ops forward and ~20 autograd nodes backward per trunk, each a few
 vendor-library launches on sub-megabyte tensors; the RL iteration (train.py:258,282-283) runs four trunk passes and is
 bound by the host's enqueue work. `trunk_features` runs up to two trunk instances through ONE autograd node: one C call
-forward (8 launches), one backward (11-13), same parameters / buffers / state-dict keys as the module path (the modules stay
+forward (8 launches), one backward (11-15), same parameters / buffers / state-dict keys as the module path (the modules stay
 the owners of every tensor; running statistics and `num_batches_tracked` are updated as nn.BatchNorm2d does).
 
 Results agree with the module path to fp32 rounding (other summation orders; every sum here runs in a fixed order, so two

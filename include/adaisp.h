@@ -276,7 +276,7 @@ size_t adaisp_trunk_train_workspace_bytes(const adaisp_trunk_args* args);
 size_t adaisp_trunk_train_scratch_bytes(const adaisp_trunk_args* args);
 /* `args` is a HOST struct holding DEVICE pointers. 8 launches. */
 int adaisp_trunk_train_fwd(const adaisp_trunk_args* args, void* stream);
-/* After adaisp_trunk_train_fwd with the same args / workspace. 11-13 launches. */
+/* After adaisp_trunk_train_fwd with the same args / workspace. 11-15 launches. */
 int adaisp_trunk_train_bwd(const adaisp_trunk_args* args, void* stream);
 
 /*
