@@ -26,7 +26,7 @@ EXPORTS = ("adaisp_forward", "adaisp_forward_uniform", "adaisp_process", "adaisp
            "adaisp_policy_conv", "adaisp_policy_fc1", "adaisp_policy_finish",
            "adaisp_trunk_train_fwd", "adaisp_trunk_train_bwd", "adaisp_trunk_train_workspace_bytes", "adaisp_trunk_train_scratch_bytes",
            "adaisp_critic_planes_fwd", "adaisp_critic_planes_bwd", "adaisp_td_fwd", "adaisp_td_bwd",
-           "adaisp_policy_tail_fwd", "adaisp_policy_tail_bwd", "adaisp_image_stats",
+           "adaisp_policy_tail_fwd", "adaisp_policy_tail_bwd", "adaisp_image_stats", "adaisp_clip_adam_step",
            "adaisp_strerror", "adaisp_abi_version")
 
 _lib = None
@@ -68,6 +68,8 @@ def load():
         getattr(L, name).argtypes = [vp]
         getattr(L, name).restype = ctypes.c_size_t
     L.adaisp_image_stats.argtypes = [vp, vp, vp, ci, ctypes.c_long, vp]
+    L.adaisp_clip_adam_step.argtypes = [vp, ci, ctypes.c_long, vp, ctypes.c_float] + [ctypes.c_double] * 4 + [vp]
+    L.adaisp_clip_adam_step.restype = ci
     L.adaisp_image_stats.restype = ci
     L.adaisp_num_params.argtypes = [ci]
     L.adaisp_strerror.argtypes = [ci]

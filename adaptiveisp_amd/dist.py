@@ -173,16 +173,37 @@ class GradBucket:
             torch._foreach_copy_(dst, src)
 
 
+def _same_params(model, opt, cached):
+    """The optimizer steps exactly the parameters of `model` that the clip would see (the norm is taken over them)."""
+    key = "_adaisp_same_%d" % id(model)
+    hit = opt.__dict__.get(key)
+    if hit is None:
+        mine = {id(p) for p in (cached.get(id(model)) or [p for p in model.parameters() if p.requires_grad])}
+        theirs = {id(p) for g in opt.param_groups for p in g["params"] if p.requires_grad}
+        hit = opt.__dict__[key] = mine == theirs
+    return hit
+
+
 def synced_step(models, optimizers, buckets, max_grad_norm=1e-5):
     """After loss.backward(): all-reduce(mean) the gradients (one bucket = one collective), clip, step.
     Mirrors train.py:341-351 with the collective inserted before the clip."""
+    optimizers = list(optimizers)
     works = [b.all_reduce_mean(async_op=GradBucket._active()) for b in buckets]
     for b, w in zip(buckets, works):
         b.finish(w)
     cached = {id(m): ps for b in buckets for m, ps in zip(getattr(b, "modules", ()), getattr(b, "per_module", ()))}
-    for m in models:
+    from . import optim as aoptim
+    paired = len(models) == len(optimizers)
+    for i, m in enumerate(models):
+        # clip + Adam of one model as three launches where the kernels serve the optimizer (optim.clip_adam_step), else torch's
+        if paired and _same_params(m, optimizers[i], cached) and aoptim.clip_adam_step(optimizers[i], max_grad_norm):
+            optimizers[i].zero_grad(set_to_none=True)
+            optimizers[i] = None
+            continue
         torch.nn.utils.clip_grad_norm_(cached.get(id(m)) or list(m.parameters()), max_grad_norm)
     for o in optimizers:
+        if o is None:
+            continue
         o.step()
         o.zero_grad(set_to_none=True)       # (the reference's default too: the next backward writes the gradients instead of adding to zeros)
 

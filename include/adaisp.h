@@ -355,6 +355,25 @@ int adaisp_policy_tail_bwd(const adaisp_policy_tail_args* args, void* stream);
  */
 int adaisp_image_stats(const float* img, float* stats, float* workspace, int B, long n, void* stream);
 
+/*
+ * torch.nn.utils.clip_grad_norm_(params, max_norm) followed by torch.optim.Adam.step() (train.py:341-351; amsgrad off, no weight
+ * decay) over a table of fp32 tensors in three launches. `table` is a DEVICE array of `ntensors` entries: parameter, gradient,
+ * first / second moment (updated in place), the tensor's step count AFTER this step (a device float, as torch's fused Adam keeps
+ * it), element count, and `chunk0` = the number of 4096-element chunks of the tensors before it (ascending); `nchunks` their total.
+ * `workspace`: nchunks + 2 floats; afterwards workspace[nchunks] = the clip coefficient, workspace[nchunks + 1] = the total norm.
+ * max_norm <= 0: no clipping. Fixed summation order; the update arithmetic of torch's fused Adam.
+ */
+typedef struct adaisp_adam_tensor {
+    float* p;
+    const float* g;
+    float* m;
+    float* v;
+    const float* step;
+    long n, chunk0;
+} adaisp_adam_tensor;
+int adaisp_clip_adam_step(const adaisp_adam_tensor* table, int ntensors, long nchunks, float* workspace, float max_norm, double lr,
+                          double beta1, double beta2, double eps, void* stream);
+
 /* Number of regressed parameters an op reads per image (0 for ADAISP_OP_ZERO, -1 if unknown). */
 int adaisp_num_params(int op);
 

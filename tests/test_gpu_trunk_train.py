@@ -354,3 +354,46 @@ def test_image_stats(shape):
     keep = [i for i in range(shape[0]) if i != 1]
     close_scaled("trunk_train.image_stats.mean", st[keep, 0], x[keep].double().mean(dim=(1, 2, 3)).float(), frac=2e-6)
     assert torch.equal(torch.nan_to_num(st, nan=-1.0), torch.nan_to_num(_lib.image_stats(x), nan=-1.0))
+
+
+@pytest.mark.parametrize("max_norm", [1e-5, 1e3])
+def test_clip_adam_kernels_match_torch(max_norm):
+    """adaisp_clip_adam_step (optim.clip_adam_step) against torch.nn.utils.clip_grad_norm_ + torch.optim.Adam(fused=True).step()
+    on the same gradients, step after step: parameters, both moments, step counts; tensors of odd sizes, larger than a chunk,
+    one without a gradient. The first step creates the optimizer state through torch on both sides."""
+    from adaptiveisp_amd import optim as aoptim
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(4)
+    shapes = [(128, 4096), (7,), (33, 5, 3), (4099,), (256, 64, 4, 4), (1,), (12289,)]
+
+    def make():
+        ps = [torch.nn.Parameter(torch.randn(s, generator=torch.Generator().manual_seed(i)).to(dev)) for i, s in enumerate(shapes)]
+        ps.append(torch.nn.Parameter(torch.zeros(5, device=dev)))                       # never receives a gradient
+        return ps, torch.optim.Adam(ps, lr=3e-4, fused=True)
+
+    (pa, oa), (pb, ob) = make(), make()
+    for it in range(6):
+        for q, r in zip(pa[:-1], pb[:-1]):
+            gr = (torch.randn(q.shape, generator=g) * (10.0 ** (it % 3 - 1))).to(dev)
+            q.grad, r.grad = gr.clone(), gr.clone()
+        torch.nn.utils.clip_grad_norm_(pa, max_norm)
+        oa.step()
+        handled = aoptim.clip_adam_step(ob, max_norm)
+        assert handled == (it > 0)
+        if not handled:
+            torch.nn.utils.clip_grad_norm_(pb, max_norm)
+            ob.step()
+        for i, (q, r) in enumerate(zip(pa[:-1], pb[:-1])):
+            sa, sb = oa.state[q], ob.state[r]
+            assert torch.equal(sa["step"], sb["step"])
+            close_scaled("trunk_train.adam.param", r, q, frac=2e-6, err_msg=f"step {it} tensor {i}")
+            close_scaled("trunk_train.adam.exp_avg", sb["exp_avg"], sa["exp_avg"], frac=2e-6, floor=1e-12, err_msg=f"step {it} tensor {i}")
+            close_scaled("trunk_train.adam.exp_avg_sq", sb["exp_avg_sq"], sa["exp_avg_sq"], frac=2e-6, floor=1e-20, err_msg=f"step {it} tensor {i}")
+        assert pb[-1].grad is None and len(ob.state.get(pb[-1], {})) == 0
+    ws = ob.__dict__["_adaisp_table"]["ws"]
+    total = torch.sqrt(sum((r.grad.double() ** 2).sum() for r in pb[:-1]))
+    close_scaled("trunk_train.adam.total_norm", ws[-1:], total.float().reshape(1), frac=2e-6)
+    assert abs(float(ws[-2]) - min(1.0, max_norm / (float(total) + 1e-6))) <= 2e-6 * max(1.0, float(ws[-2]))
+    # options the kernels do not serve are left to torch
+    assert not aoptim.clip_adam_step(torch.optim.Adam(pa, lr=1e-3, weight_decay=0.1, fused=True), 1.0)
+    assert not aoptim.clip_adam_step(torch.optim.SGD(pa, lr=1e-3), 1.0)
