@@ -62,9 +62,13 @@ def clip_adam_step(opt, max_norm):
                                                      ws=torch.empty((chunk0 + 2,), dtype=torch.float32, device=dev))
     table = cache["rows"].copy()
     for i, p in enumerate(params):
-        g = p.grad
+        g, st = p.grad, opt.state[p]
         if g.dtype != torch.float32 or not g.is_contiguous() or g.is_sparse:
             return False
+        # load_state_dict (a resumed checkpoint) replaces the state tensors: the cached addresses must still be theirs
+        if st["exp_avg"].data_ptr() != table[i, 2] or st["exp_avg_sq"].data_ptr() != table[i, 3] or st["step"].data_ptr() != table[i, 4]:
+            opt.__dict__.pop("_adaisp_table", None)
+            return clip_adam_step(opt, max_norm)
         table[i, 1] = g.data_ptr()
     L = _lib.load()
     torch._foreach_add_(cache["steps"], 1)

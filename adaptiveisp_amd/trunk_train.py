@@ -165,6 +165,9 @@ class _TrunkFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dfeat):
         L = _lib.load()
+        if ctx.keep is None:
+            raise RuntimeError("trunk_features: a second backward through the same node (retain_graph) is not supported: the "
+                               "saved activations are released by the first")
         args, pargs, (imgs, svecs, raw_states, feat, ws), n_in, share, trunks = ctx.args, ctx.pargs, ctx.keep, ctx.n_in, ctx.share, ctx.trunks
         params = ctx.saved_tensors
         dfeat = dfeat.contiguous()

@@ -397,3 +397,30 @@ def test_clip_adam_kernels_match_torch(max_norm):
     # options the kernels do not serve are left to torch
     assert not aoptim.clip_adam_step(torch.optim.Adam(pa, lr=1e-3, weight_decay=0.1, fused=True), 1.0)
     assert not aoptim.clip_adam_step(torch.optim.SGD(pa, lr=1e-3), 1.0)
+
+
+def test_clip_adam_follows_a_reloaded_optimizer_state():
+    """load_state_dict replaces exp_avg / exp_avg_sq / step: the kernels' cached address table is rebuilt, the update lands in
+    the NEW tensors (what a resumed checkpoint relies on)."""
+    from adaptiveisp_amd import optim as aoptim
+    dev = torch.device("cuda:0")
+    ps = [torch.nn.Parameter(torch.randn(300, 40, device=dev)), torch.nn.Parameter(torch.randn(17, device=dev))]
+    opt = torch.optim.Adam(ps, lr=1e-3, fused=True)
+    for it in range(3):
+        for p in ps:
+            p.grad = torch.randn_like(p)
+        if not aoptim.clip_adam_step(opt, 1.0):
+            torch.nn.utils.clip_grad_norm_(ps, 1.0)
+            opt.step()
+    saved = copy.deepcopy(opt.state_dict())
+    old_m = opt.state[ps[0]]["exp_avg"]
+    opt.load_state_dict(saved)
+    new_m = opt.state[ps[0]]["exp_avg"]
+    assert new_m.data_ptr() != old_m.data_ptr()
+    before_old, before_new = old_m.clone(), new_m.clone()
+    for p in ps:
+        p.grad = torch.randn_like(p)
+    assert aoptim.clip_adam_step(opt, 1.0)
+    torch.cuda.synchronize()
+    assert torch.equal(old_m, before_old) and not torch.equal(new_m, before_new)
+    assert float(opt.state[ps[0]]["step"]) == 4.0
