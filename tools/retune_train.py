@@ -2,7 +2,7 @@
 """Re-measure the kernel choice of every conv of the TRAINING engine at the config-4 per-rank shape (8 x 512 x 512) and write
 the merged table to gpurun_out/mi355x_retuned.json (the committed table is left alone); prints the layers whose choice moved
 and the detector's forward / backward times with both tables. usage: retune_train.py [B=8] [HW=512]"""
-import json, os, shutil, sys
+import os, shutil, sys
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)

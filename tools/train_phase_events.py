@@ -2,7 +2,7 @@
 """GPU time of the phases of one RL iteration (8 x 512 x 512, default configuration) from events recorded between them in an
 UNPROFILED run: where the iteration's wall time goes beyond the summed kernel durations of tools/train_trace.sh.
 usage: train_phase_events.py [iters=30]"""
-import os, random, sys
+import os, sys
 import numpy as np
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
