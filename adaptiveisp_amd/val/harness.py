@@ -62,7 +62,7 @@ def run_eval(agent, detector, batches, cfg, steps=5, conf_thres=0.001, iou_thres
     eval-mode agent, no `param_dir`) — same records, detections and mAP as the eager loop, which stays the default."""
     import collections
     import json
-    from ..util import get_initial_states, get_noise
+    from ..util import get_initial_states, get_noise, to_device_async
     dev = next(agent.parameters()).device
     iouv = torch.linspace(0.5, 0.95, 10, device=dev)
     niou = iouv.numel()
@@ -70,11 +70,15 @@ def run_eval(agent, detector, batches, cfg, steps=5, conf_thres=0.001, iou_thres
     graphs = {}
     filter_names = [f.get_short_name() for f in agent.filters]
     for im, targets, paths, shapes in batches:
-        im = im.to(dev).float()
-        targets = targets.to(dev).clone()
+        # host arrays go up from pinned memory, asynchronously: a copy from pageable memory synchronises the stream, i.e. waits for
+        # the previous batch's NMS / matching launches before this batch's first kernel can even be enqueued
         nb, _, height, width = im.shape
-        noises = torch.from_numpy(np.array([get_noise(nb, cfg.z_type, cfg.z_dim) for _ in range(steps)])).to(dev)
-        states = torch.from_numpy(get_initial_states(nb, cfg.num_state_dim, len(agent.filters))).to(dev)
+        targets = targets.clone()
+        targets[:, 2:] *= torch.tensor((width, height, width, height), dtype=targets.dtype)      # to pixels, on the host
+        im = to_device_async(im, dev).float()
+        targets = to_device_async(targets, dev)
+        noises = to_device_async(np.array([get_noise(nb, cfg.z_type, cfg.z_dim) for _ in range(steps)]), dev)
+        states = to_device_async(get_initial_states(nb, cfg.num_state_dim, len(agent.filters)), dev)
         retouch, ids = im, []
         params = collections.OrderedDict(pipeline=[])
         replayed = False
@@ -115,7 +119,6 @@ def run_eval(agent, detector, batches, cfg, steps=5, conf_thres=0.001, iou_thres
             for i, step_ids in enumerate(ids):
                 row[i] = str(step_ids[b])
             records.append((os.path.split(str(paths[b]))[1], row))
-        targets[:, 2:] *= torch.tensor((width, height, width, height), device=dev)
         preds = non_max_suppression(preds, conf_thres, iou_thres, multi_label=True, agnostic=single_cls,
                                     max_det=max_det, nms_fn=nms_fn)
         for si, pred in enumerate(preds):
