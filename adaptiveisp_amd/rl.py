@@ -149,6 +149,7 @@ def train_iteration(cfg, agent, value, detector, loss_fn, imgs, z, states, label
     from . import dist as adist
     from .yolo.loss import batched_per_sample_loss as per_sample_loss
     from .yolo.loss import assign_labels, assign_labels_packed
+    values = None
     if getattr(detector, "per_sample_loss_pair", None) is not None:
         # HIP training engine, pair form (yolo.YoloTrainPairEngine): ONE detector forward over [input batch; retouched batch],
         # one loss launch for both, the backward over the retouched half only
@@ -158,7 +159,22 @@ def train_iteration(cfg, agent, value, detector, loss_fn, imgs, z, states, label
         stats = retouch_stats(retouch)
         if on_retouch is not None:
             on_retouch(retouch.detach(), stats, new_states.detach())
+        if imgs.is_cuda and hasattr(value, "forward_pair") and os.environ.get("ADAISP_CRITIC_STREAM", "1") == "1":
+            # the critic needs the retouched batch, not the detector: its two calls run on a second stream beside the detector's
+            # forward — and, autograd replaying every node on its forward's stream, its backward beside the detector's: chains of
+            # 5-15 us launches next to launches that fill the chip (7.0 -> 6.7 ms per iteration, four interleaved pairs; the same
+            # arrangement measured nothing while the loop still drained the GPU once per iteration). ADAISP_CRITIC_STREAM=0: one stream
+            cur, side = torch.cuda.current_stream(), _side_stream(imgs.device)
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                values = value.forward_pair(imgs, states, retouch, new_states)
+            for t in (imgs, states, retouch, new_states):
+                t.record_stream(side)
         l_in, l_re = detector.per_sample_loss_pair(loss_fn, imgs, retouch, packed, packed_pair)
+        if values is not None:
+            cur.wait_stream(side)
+            for t in values:
+                t.record_stream(cur)
     elif getattr(detector, "per_sample_loss", None) is not None and os.environ.get("ADAYOLO_FUSED_LOSS", "1") == "1":
         # HIP training engine: detector forward + one loss launch on its bf16 head maps (csrc/yolo_loss.hip), no fp32 copies.
         # The detection loss of the INPUT batch needs nothing the agent computes: it runs on a second stream beside the
@@ -196,7 +212,9 @@ def train_iteration(cfg, agent, value, detector, loss_fn, imgs, z, states, label
             assigned = assign_labels(loss_fn, p_in, labels)      # same labels, same map shapes for both batches
             l_in = per_sample_loss(loss_fn, p_in, labels, assigned)
         l_re = per_sample_loss(loss_fn, detector(retouch), labels, assigned)
-    if hasattr(value, "forward_pair") and os.environ.get("ADAISP_CRITIC_PAIR", "1") == "1":
+    if values is not None:
+        old_value, new_value = values
+    elif hasattr(value, "forward_pair") and os.environ.get("ADAISP_CRITIC_PAIR", "1") == "1":
         old_value, new_value = value.forward_pair(imgs, states, retouch, new_states)     # one node for both trunk passes
     else:
         old_value = value(imgs, states)

@@ -215,3 +215,63 @@ def test_input_batch_loss_on_a_second_stream_changes_nothing():
                 assert torch.isfinite(out["reward"]).all()
         finally:
             del os.environ["ADAISP_TRAIN_OVERLAP"]
+
+
+def test_critic_on_a_second_stream_changes_nothing():
+    """rl.train_iteration with the pair engine runs the critic's two calls (and, through autograd's stream rule, their backward)
+    on a second stream beside the detector (ADAISP_CRITIC_STREAM, default on). Three iterations from the same state with the
+    switch on and off: the same losses, rewards and retouched images bit for bit, the same updated parameters (gradient sums
+    reach the shared leaves in another order: fp32 rounding)."""
+    from _margins import close_scaled
+    from _synth import synth_state_dict, synth_yolo_state_dict, test_image
+    from adaptiveisp_amd.agent import Agent
+    from adaptiveisp_amd.config import cfg
+    from adaptiveisp_amd.rl import train_iteration
+    from adaptiveisp_amd.value import Value
+    from adaptiveisp_amd.yolo import YoloTrainPairEngine, yolov3
+    from adaptiveisp_amd.yolo.loss import DetectionLoss, default_hyp
+    B, H, W = 4, 64, 96
+    det = yolov3()
+    det.load_state_dict(synth_yolo_state_dict(det))
+    det = det.to(DEV).train()
+    for p in det.parameters():
+        p.requires_grad_(False)
+    eng = YoloTrainPairEngine(det, B, H, W, device=DEV)
+    loss_fn = DetectionLoss(det.model[-1].anchors, nc=80, hyp=default_hyp(80, W), device=DEV)
+    runs = {}
+    for sw in ("1", "0"):
+        os.environ["ADAISP_CRITIC_STREAM"] = sw
+        try:
+            torch.manual_seed(0)
+            agent = Agent(cfg, shape=(16, 64, 64), device=DEV)
+            agent.load_state_dict(synth_state_dict(agent, seed=0))
+            agent = agent.to(DEV).train()
+            agent.feature_extractor.droupout.p = agent.action_selection.droupout.p = 0.0
+            value = Value(cfg, shape=(19, 64, 64))
+            value.load_state_dict(synth_state_dict(value, seed=1))
+            value = value.to(DEV).train()
+            # plain SGD: the update is proportional to the (clipped) gradient, so a rounding-level difference between the two
+            # arrangements stays one (Adam's first steps are lr * sign(g): the sign of a conv bias's rounding-noise gradient in
+            # front of a batch-statistics BatchNorm would decide a 1e-3 move)
+            opts = [torch.optim.SGD(agent.parameters(), lr=10.0), torch.optim.SGD(value.parameters(), lr=10.0)]
+            outs = []
+            for i in range(3):
+                imgs = torch.from_numpy(test_image(B, H, W, seed=30 + i, special=False)).to(DEV)
+                z = torch.full((B, cfg.z_dim), 0.2 + 0.25 * i, device=DEV)
+                states = torch.zeros(B, cfg.num_state_dim, device=DEV)
+                labels = [torch.tensor([[0, 1 + b + i, 0.5, 0.5, 0.3, 0.4]]) for b in range(B)]
+                out = train_iteration(cfg, agent, value, eng, loss_fn, imgs, z, states, labels, 0.1, opts)
+                torch.cuda.synchronize()
+                outs.append({k: out[k].detach().clone() for k in ("retouch", "reward", "value_loss", "agent_loss", "detect_loss_input",
+                                                                   "detect_loss_retouch")})
+            runs[sw] = (outs, [p.detach().clone() for p in list(agent.parameters()) + list(value.parameters())])
+        finally:
+            del os.environ["ADAISP_CRITIC_STREAM"]
+    for a, b in zip(runs["1"][0][:1], runs["0"][0][:1]):                    # first iteration: identical state, identical forward
+        for k in a:
+            assert torch.equal(a[k], b[k]), k
+    for i, (a, b) in enumerate(zip(runs["1"][0], runs["0"][0])):
+        for k in a:
+            close_scaled("train.critic_stream." + k, a[k], b[k], 2e-4, err_msg=f"iteration {i}")
+    for pa, pb in zip(runs["1"][1], runs["0"][1]):
+        close_scaled("train.critic_stream.params", pa, pb, 2e-4)

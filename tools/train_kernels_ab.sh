@@ -5,9 +5,9 @@
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd "$R"
 for r in 1 2 3; do
-for m in "1 1 1 1 1 1" "1 1 1 1 1 0" "1 1 1 1 0 0" "0 0 0 0 0 0"; do set -- $m
-echo "== round $r: trunk kernels $1, critic pair $2, TD kernel $3, policy tail $4, detector pair $5, clip + Adam kernels $6"
-ADAISP_TRUNK_KERNELS=$1 ADAISP_CRITIC_PAIR=$2 ADAISP_TD_KERNEL=$3 ADAISP_POLICY_TAIL_KERNEL=$4 ADAYOLO_TRAIN_PAIR=$5 ADAISP_ADAM_KERNEL=$6 TRAIN_BENCH_ONLY=hip \
+for m in "1 1 1 1 1 1 1" "1 1 1 1 1 1 0" "1 1 1 1 1 0 0" "1 1 1 1 0 0 0" "0 0 0 0 0 0 0"; do set -- $m
+echo "== round $r: trunk kernels $1, critic pair $2, TD kernel $3, policy tail $4, detector pair $5, clip + Adam kernels $6, critic on a second stream $7"
+ADAISP_TRUNK_KERNELS=$1 ADAISP_CRITIC_PAIR=$2 ADAISP_TD_KERNEL=$3 ADAISP_POLICY_TAIL_KERNEL=$4 ADAYOLO_TRAIN_PAIR=$5 ADAISP_ADAM_KERNEL=$6 ADAISP_CRITIC_STREAM=$7 TRAIN_BENCH_ONLY=hip \
   python tools/train_bench.py 40 2>&1 | grep -v amdgpu.ids | tail -2
 done; done
 echo "== ATen ops per iteration (default configuration)"
