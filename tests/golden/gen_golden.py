@@ -18,6 +18,7 @@ import torch
 
 sys.dont_write_bytecode = True
 HERE = os.path.dirname(os.path.abspath(__file__))
+OUT = HERE                                   # --out DIR: write the fixtures somewhere else (tools/regen_check.sh)
 sys.path.insert(0, os.path.dirname(HERE))
 from _synth import synth_state_dict, synth_yolo_state_dict, test_image  # noqa: E402
 
@@ -92,7 +93,7 @@ def gen_yolo():
     out = {"x": x, "pred": pred.numpy()}
     for i, r in enumerate(raws):
         out[f"raw{i}"] = r.numpy()
-    np.savez_compressed(os.path.join(HERE, "yolo.npz"), **out)
+    np.savez_compressed(os.path.join(OUT, "yolo.npz"), **out)
     # detection loss (reward signal): the reference's ComputeLossBatch on random head maps + hand-made targets
     from utils.loss import ComputeLossBatch
     m.hyp = dict(box=0.05, cls=0.5, obj=1.0 * (96 / 640) ** 2, anchor_t=4.0, cls_pw=1.0, obj_pw=1.0, fl_gamma=0.0,
@@ -112,15 +113,31 @@ def gen_yolo():
         tb = targets[targets[:, 0] == b].clone(); tb[:, 0] = 0
         l3 = crit([p[b:b + 1].clone() for p in preds], tb)
         lo[f"sample{b}"] = torch.cat(l3).numpy()
-    np.savez_compressed(os.path.join(HERE, "detloss.npz"), **lo)
+    # the same scoring on head maps that are exactly representable in bf16 (what the HIP loss kernels read from the
+    # detector's bf16 buffers), with autograd's gradient of sum_b w_b * loss_b w.r.t. the maps: the direct pin of
+    # adayolo_detloss_fwd / _bwd (tests/test_gpu_yolo_train.py)
+    qs = [p.to(torch.bfloat16).float().requires_grad_(True) for p in preds]
+    wq = torch.tensor([0.7, 1.3])
+    total = 0.0
+    for b in range(2):
+        tb = targets[targets[:, 0] == b].clone(); tb[:, 0] = 0
+        l3 = crit([q[b:b + 1] for q in qs], tb)
+        lo[f"qsample{b}"] = torch.cat(l3).detach().numpy()
+        total = total + wq[b] * torch.cat(l3).sum()
+    total.backward()
+    lo["qweights"] = wq.numpy()
+    for i, q in enumerate(qs):
+        lo[f"q{i}"], lo[f"qgrad{i}"] = q.detach().numpy(), q.grad.numpy()
+    np.savez_compressed(os.path.join(OUT, "detloss.npz"), **lo)
     m.eval()
-    p = os.path.join(HERE, "state_dict_keys.json")
+    p = os.path.join(OUT, "state_dict_keys.json")
     keys = json.load(open(p))
     keys["yolo"] = {k: list(v.shape) for k, v in m.state_dict().items()}
     json.dump(keys, open(p, "w"), indent=0)
 
 
-def main():
+def gen_core():
+    """filters / filters_grad / nlm / pool64 / agent / select fixtures + state_dict_keys.json (agent, value)."""
     import warnings
     warnings.filterwarnings("ignore")
     torch.set_num_threads(4)
@@ -154,7 +171,7 @@ def main():
             out[f"{key}.param"] = param.reshape(2, -1).numpy()
             out[f"{key}.process"] = proc.numpy()
             out[f"{key}.forward"] = fwd.numpy()
-    np.savez_compressed(os.path.join(HERE, "filters.npz"), **out)
+    np.savez_compressed(os.path.join(OUT, "filters.npz"), **out)
 
     # ---------------------------------------------------------------- A2. parameter gradients (autograd of the reference)
     gout = {}
@@ -175,7 +192,7 @@ def main():
                 y = torch.clip(y, 0.0, 1.0)
             (y * T(G)).sum().backward()
             gout[f"{key}.{mode}"] = param.grad.reshape(2, -1).numpy().copy()
-    np.savez_compressed(os.path.join(HERE, "filters_grad.npz"), **gout)
+    np.savez_compressed(os.path.join(OUT, "filters_grad.npz"), **gout)
 
     # ---------------------------------------------------------------- B. NLM wrap-around cases
     out = {}
@@ -189,7 +206,7 @@ def main():
             out[f"{tag}.img"] = x
             out[f"{tag}.h"] = h
             out[f"{tag}.out"] = nlm.process(T(x), T(h)).numpy()
-    np.savez_compressed(os.path.join(HERE, "nlm.npz"), **out)
+    np.savez_compressed(os.path.join(OUT, "nlm.npz"), **out)
 
     # ---------------------------------------------------------------- C. adaptive 64x64 pooling
     out = {}
@@ -198,7 +215,7 @@ def main():
         x = test_image(B, H, W, seed=31 + H, special=False)
         out[f"{tag}.img"] = x
         out[f"{tag}.out"] = pool(T(x)).numpy()
-    np.savez_compressed(os.path.join(HERE, "pool64.npz"), **out)
+    np.savez_compressed(os.path.join(OUT, "pool64.npz"), **out)
 
     # ---------------------------------------------------------------- D. Agent.forward (eval), E. Value.forward
     out = {}
@@ -246,9 +263,9 @@ def main():
         out["value.s0"] = va(T(x), T(s0)).numpy()
         out["value.s1"] = va(T(x), T(s1)).numpy()
         out["value.none"] = value_mod.Value(cfg, shape=(6, 64, 64)).eval()(T(x)).numpy() * 0  # shape check only
-    np.savez_compressed(os.path.join(HERE, "agent.npz"), **out)
+    np.savez_compressed(os.path.join(OUT, "agent.npz"), **out)
     import json
-    with open(os.path.join(HERE, "state_dict_keys.json"), "w") as f:
+    with open(os.path.join(OUT, "state_dict_keys.json"), "w") as f:
         json.dump({"agent": {k: list(v.shape) for k, v in ag.state_dict().items()},
                    "value": {k: list(v.shape) for k, v in va.state_dict().items()}}, f, indent=0)
 
@@ -264,17 +281,8 @@ def main():
     idx = agent_mod.pdf_sample(T(pdf), T(u))
     out["pdf"], out["u"], out["idx"] = pdf, u, idx.numpy().astype(np.int64)
     out["one_hot"] = agent_mod.one_hot(10, idx.to(torch.int64)).numpy()
-    np.savez_compressed(os.path.join(HERE, "select.npz"), **out)
+    np.savez_compressed(os.path.join(OUT, "select.npz"), **out)
 
-    gen_yolo()
-    gen_eval()
-    gen_ckpt()
-    gen_replay()
-    gen_mosaic()
-    gen_value_path()
-    gen_midsize()
-    tot = sum(os.path.getsize(os.path.join(HERE, f)) for f in os.listdir(HERE) if f.endswith(".npz"))
-    print("fixtures written, total bytes:", tot)
 
 
 def gen_nlm_general():
@@ -299,7 +307,7 @@ def gen_nlm_general():
             out[f"{tag}.img"], out[f"{tag}.h"] = x, h.reshape(-1)
             out[f"{tag}.sizes"] = np.asarray([search, patch], np.int32)
             out[f"{tag}.out"] = denoise.NonLocalMeansGray(search, patch)(torch.from_numpy(x), torch.from_numpy(h)).numpy()
-    np.savez_compressed(os.path.join(HERE, "nlm_general.npz"), **out)
+    np.savez_compressed(os.path.join(OUT, "nlm_general.npz"), **out)
 
 
 def gen_value_path():
@@ -327,20 +335,8 @@ def gen_value_path():
         out[f"f{k}.value"] = v.detach().numpy()
         out[f"f{k}.gw"] = flt.fc_filter.weight.grad.numpy().copy()
         out[f"f{k}.gb"] = flt.fc_filter.bias.grad.numpy().copy()
-    np.savez_compressed(os.path.join(HERE, "value_path.npz"), **out)
+    np.savez_compressed(os.path.join(OUT, "value_path.npz"), **out)
     print("value_path.npz:", {k: (v.shape, float(np.abs(v).max())) for k, v in out.items() if k.endswith(".gb")})
-
-
-if __name__ == "__main__" and "--value-path-only" in sys.argv:
-    gen_value_path()
-    sys.exit(0)
-
-if __name__ == "__main__" and "--nlm-general-only" in sys.argv:
-    gen_nlm_general()
-    sys.exit(0)
-
-if __name__ == "__main__" and not any(f in sys.argv for f in ("--eval-only", "--ckpt-only", "--replay-only", "--mosaic-only", "--midsize-only")):
-    main()
 
 
 def _greedy_nms(boxes, scores, iou_thres):
@@ -425,15 +421,8 @@ def gen_eval():
     rec = np.sort(rng.random(40)); prec = np.sort(rng.random(40))[::-1].copy()
     a, mpre, mrec = met.compute_ap(rec, prec)
     out.update(cap_rec=rec, cap_prec=prec, cap_ap=np.float64(a), cap_mpre=mpre, cap_mrec=mrec)
-    np.savez_compressed(os.path.join(HERE, "evalharness.npz"), **out)
+    np.savez_compressed(os.path.join(OUT, "evalharness.npz"), **out)
     print("evalharness.npz written")
-
-
-if __name__ == "__main__" and "--eval-only" in sys.argv:
-    import matplotlib
-    matplotlib.use("Agg")
-    import matplotlib.pyplot  # noqa: F401
-    gen_eval()
 
 
 def gen_ckpt():
@@ -454,28 +443,21 @@ def gen_ckpt():
     m.names = {i: f"c{i}" for i in range(7)}
     ckpt = {"epoch": 3, "best_fitness": np.array([0.5]), "model": copy.deepcopy(m).half(), "ema": None, "updates": 0,
             "optimizer": None, "opt": {"weights": "yolov3.pt", "imgsz": 512}, "date": "2025-01-01T00:00:00"}
-    path = os.path.join(HERE, "yolov3_w0625_refpickle.pt")
+    path = os.path.join(OUT, "yolov3_w0625_refpickle.pt")
     torch.save(ckpt, path)
     ref = torch.load(path, map_location="cpu", weights_only=False)["model"].float().eval()
     x = test_image(1, 64, 96, seed=52, special=False)
     with torch.no_grad():
         pred, raws = ref(torch.from_numpy(x))
     fused = copy.deepcopy(ref).fuse().eval()
-    fpath = os.path.join(HERE, "yolov3_w0625_refpickle_fused.pt")
+    fpath = os.path.join(OUT, "yolov3_w0625_refpickle_fused.pt")
     torch.save({"model": copy.deepcopy(fused).half()}, fpath)
     fused = torch.load(fpath, map_location="cpu", weights_only=False)["model"].float().eval()
     with torch.no_grad():
         pred_f, _ = fused(torch.from_numpy(x))
-    np.savez_compressed(os.path.join(HERE, "ckpt_import.npz"), x=x, pred=pred.numpy(), raw0=raws[0].numpy(),
+    np.savez_compressed(os.path.join(OUT, "ckpt_import.npz"), x=x, pred=pred.numpy(), raw0=raws[0].numpy(),
                         pred_fused_fp32=pred_f.numpy(), nparams=np.int64(sum(p.numel() for p in ref.parameters())))
     print("checkpoint fixtures written:", os.path.getsize(path), os.path.getsize(fpath))
-
-
-if __name__ == "__main__" and "--ckpt-only" in sys.argv:
-    import matplotlib
-    matplotlib.use("Agg")
-    import matplotlib.pyplot  # noqa: F401
-    gen_ckpt()
 
 
 def gen_replay():
@@ -524,18 +506,11 @@ def gen_replay():
         steps_after.append([[float(s[1]), float(s[2])] for s in new_states])
         mem.replace_memory(mem.images_and_states_to_records([i + 100 for i in ims], lbs, paths, shapes, new_states))
         pool_sizes.append(len(mem.image_pool))
-    np.savez_compressed(os.path.join(HERE, "replay.npz"), drawn=np.array(drawn), script=np.array(steps_after),
+    np.savez_compressed(os.path.join(OUT, "replay.npz"), drawn=np.array(drawn), script=np.array(steps_after),
                         pool_sizes=np.array(pool_sizes), final_paths=np.array([int(r.path[3:]) for r in mem.image_pool]),
                         final_im=np.array([float(np.asarray(r.im).reshape(-1)[0]) for r in mem.image_pool]),
                         max_traj=np.int64(cfg.maximum_trajectory_length), keep_prob=np.float64(cfg.over_length_keep_prob))
     print("replay.npz written")
-
-
-if __name__ == "__main__" and "--replay-only" in sys.argv:
-    import matplotlib
-    matplotlib.use("Agg")
-    import matplotlib.pyplot  # noqa: F401
-    gen_replay()
 
 
 def gen_mosaic():
@@ -549,7 +524,7 @@ def gen_mosaic():
     out = {"img": img, "packed": packed}
     for pat in ("rggb", "bggr", "grbg", "gbrg"):
         out[f"plane_{pat}"] = up.reconstruct_bayer(packed, pat)
-    np.savez_compressed(os.path.join(HERE, "mosaic.npz"), **out)
+    np.savez_compressed(os.path.join(OUT, "mosaic.npz"), **out)
     print("mosaic.npz written")
 
 
@@ -577,11 +552,144 @@ def gen_midsize():
         x = test_image(1, 180, 160, seed=48, special=False)
         out["pool.img"] = x
         out["pool.out"] = pool(T(x)).numpy()
-    np.savez_compressed(os.path.join(HERE, "midsize.npz"), **out)
+    np.savez_compressed(os.path.join(OUT, "midsize.npz"), **out)
     print("wrote midsize.npz")
 
 
-if __name__ == "__main__" and "--midsize-only" in sys.argv:
-    gen_midsize()
-elif __name__ == "__main__" and "--mosaic-only" in sys.argv:
-    gen_mosaic()
+
+
+def gen_td():
+    """Reward / TD arithmetic of the RL iteration (train.py:264-305) — the statements of DynamicISP.train themselves, executed
+    on seeded [B, 1] tensors.
+
+    The statements are cut out of the reference's syntax tree at generation time (the two `torch.clip` weightings of the
+    detection losses, then everything from `reward = ...` to `agent_loss = ...`) and run with a stub `self` (cfg / args /
+    max_bri / a `value` that hands back the seeded critic outputs); nothing of the reference's text is stored — the fixture
+    holds inputs, switch settings and the resulting reward, q_value, advantage, both losses and autograd's gradients of each
+    loss w.r.t. the raw retouch detection loss, the penalty, the surrogate and both critic values."""
+    import ast
+    import types
+    import_reference()
+    import util as ref_util
+    from config import cfg as ref_cfg
+    src = open("/root/reference/train.py").read()
+    tree = ast.parse(src)
+    cls = next(n for n in tree.body if isinstance(n, ast.ClassDef) and n.name == "DynamicISP")
+    fn = next(n for n in cls.body if isinstance(n, ast.FunctionDef) and n.name == "train")
+    loop = next(n for n in ast.walk(fn) if isinstance(n, ast.For) and getattr(n.target, "id", "") == "iter")
+
+    def assigns(stmt, name):
+        return isinstance(stmt, ast.Assign) and any(getattr(t, "id", None) == name for t in stmt.targets)
+
+    def is_clip(stmt, name):
+        return (assigns(stmt, name) and isinstance(stmt.value, ast.Call) and
+                ast.unparse(stmt.value.func) == "torch.clip")
+    body = loop.body
+    clips = [s for s in body if is_clip(s, "detect_input_loss") or is_clip(s, "detect_retouch_loss")]
+    first = next(i for i, s in enumerate(body) if assigns(s, "reward"))
+    last = next(i for i, s in enumerate(body) if assigns(s, "agent_loss"))
+    assert len(clips) == 2 and first < last
+    stmts = clips + body[first:last + 1]
+    code = compile(ast.Module(body=stmts, type_ignores=[]), "<train.py:264-305>", "exec")
+    print("gen_td: executing reference statements at lines", [s.lineno for s in stmts])
+
+    B, F = 12, len(ref_cfg["filters"])
+    out = {}
+    T = torch.tensor
+    case_no = 0
+    for use_td in (True, False):
+        for use_truncated in (True, False):
+            for use_penalty in (True, False):
+                g = torch.Generator().manual_seed(100 + case_no)
+                r = lambda *sh: torch.rand(sh, generator=g)          # noqa: E731
+                cfgd = types.SimpleNamespace(**{k: v for k, v in ref_cfg.items() if isinstance(k, str)})
+                cfgd.use_TD, cfgd.use_penalty = use_td, use_penalty
+                if case_no % 2:                                       # exercise the constants away from their defaults too
+                    cfgd.all_reward, cfgd.detect_loss_weight, cfgd.discount_factor = 0.7, 1.5, 0.9
+                    cfgd.critic_logit_multiplier, cfgd.parameter_lr_mul = 50.0, 0.5
+                # states: [reward, stopped, step, usage...]; a stopped sample, steps on both sides of maximum_trajectory_length
+                stopped_col = (r(B, 1) < 0.4).float()
+                stopped_col[0, 0], stopped_col[1, 0] = 1.0, 0.0
+                step_col = (r(B, 1) * 6).floor()
+                step_col[2, 0] = float(cfgd.maximum_trajectory_length)          # == : not cleared (torch.gt)
+                step_col[3, 0] = float(cfgd.maximum_trajectory_length) + 1.0    # > 7-style sample: cleared
+                step_col[4, 0] = 8.0
+                new_states = torch.cat([stopped_col, stopped_col, step_col, (r(B, F) < 0.3).float()], dim=1)
+                means = torch.full((B,), 0.5)
+                means[5], means[6], means[7], means[8] = 0.005, 0.95, 0.01, 0.9     # below / above / on both thresholds
+                means[9:] = r(B - 9) * 0.8 + 0.05
+                retouch = (means.view(B, 1, 1, 1) * torch.ones(B, 3, 4, 4)).contiguous()
+                leaves = dict(l_re=r(B, 1) * 1.3 - 0.1, penalty=r(B, 1) * 0.2, surrogate=-r(B, 1) * 3.0,
+                              old_value=r(B, 1) * 4.0 - 2.0, new_value=r(B, 1) * 4.0 - 2.0)
+                leaves["l_re"][10, 0], leaves["l_re"][11, 0] = 1.7, -0.3           # both sides of the [0, 1] clip
+                leaves = {k: v.requires_grad_(True) for k, v in leaves.items()}
+                l_in = r(B, 1) * 1.3 - 0.1
+                vals = iter([leaves["old_value"], leaves["new_value"]])
+                me = types.SimpleNamespace(cfg=cfgd, args=types.SimpleNamespace(use_truncated=use_truncated), max_bri=0.9,
+                                           value=lambda *a, **k: next(vals), device="cpu")
+                env = dict(torch=torch, self=me, imgs=retouch, states=new_states, retouch=retouch, new_states=new_states,
+                           stopped=new_states[:, ref_util.STATE_STOPPED_DIM:ref_util.STATE_STOPPED_DIM + 1],
+                           penalty=leaves["penalty"], surrogate=leaves["surrogate"], detect_input_loss=l_in.clone(),
+                           detect_retouch_loss=leaves["l_re"], STATE_STEP_DIM=ref_util.STATE_STEP_DIM,
+                           STATE_STOPPED_DIM=ref_util.STATE_STOPPED_DIM, STATE_REWARD_DIM=ref_util.STATE_REWARD_DIM)
+                exec(code, env)
+                tag = f"c{case_no}"
+                out[f"{tag}.switches"] = np.asarray([use_td, use_truncated, use_penalty], np.int64)
+                out[f"{tag}.consts"] = np.asarray([cfgd.detect_loss_weight, cfgd.all_reward, cfgd.critic_logit_multiplier,
+                                                   cfgd.discount_factor, cfgd.parameter_lr_mul,
+                                                   cfgd.maximum_trajectory_length, 0.9], np.float64)
+                out[f"{tag}.l_in"], out[f"{tag}.new_states"] = l_in.numpy(), new_states.numpy()
+                out[f"{tag}.retouch_mean"] = torch.mean(retouch, dim=(1, 2, 3)).unsqueeze(-1).numpy()
+                for k, v in leaves.items():
+                    out[f"{tag}.{k}"] = v.detach().numpy().copy()
+                for k in ("reward", "q_value", "advantage", "value_loss", "agent_loss"):
+                    out[f"{tag}.out.{k}"] = env[k].detach().numpy().copy()
+                for loss in ("value_loss", "agent_loss"):
+                    grads = torch.autograd.grad(env[loss], list(leaves.values()), retain_graph=True, allow_unused=True)
+                    for (k, v), gr in zip(leaves.items(), grads):
+                        out[f"{tag}.d_{loss}.{k}"] = (torch.zeros_like(v) if gr is None else gr).numpy().copy()
+                case_no += 1
+    np.savez_compressed(os.path.join(OUT, "td.npz"), **out)
+    print("td.npz written:", case_no, "switch settings")
+
+
+GENERATORS = dict(core=gen_core, yolo=gen_yolo, eval=gen_eval, ckpt=gen_ckpt, replay=gen_replay, mosaic=gen_mosaic,
+                  nlm_general=gen_nlm_general, value_path=gen_value_path, midsize=gen_midsize, td=gen_td)
+_OLD_FLAGS = {"--eval-only": "eval", "--ckpt-only": "ckpt", "--replay-only": "replay", "--mosaic-only": "mosaic",
+              "--midsize-only": "midsize", "--value-path-only": "value_path", "--nlm-general-only": "nlm_general"}
+
+
+def main(argv):
+    """`gen_golden.py` regenerates everything (each generator in its own process: the two reference trees both own a
+    top-level `utils` / `models` name); `--only NAME[,NAME]` runs those in this process; `--out DIR` writes there."""
+    import subprocess
+    global OUT
+    names = []
+    i = 0
+    while i < len(argv):
+        a = argv[i]
+        if a == "--out":
+            OUT = os.path.abspath(argv[i + 1]); i += 1
+            os.makedirs(OUT, exist_ok=True)
+        elif a == "--only":
+            names += argv[i + 1].split(","); i += 1
+        elif a in _OLD_FLAGS:
+            names.append(_OLD_FLAGS[a])
+        else:
+            raise SystemExit(f"unknown argument {a}; generators: {', '.join(GENERATORS)}")
+        i += 1
+    if names:
+        import matplotlib
+        matplotlib.use("Agg")
+        import matplotlib.pyplot  # noqa: F401
+        for n in names:
+            GENERATORS[n]()
+        return
+    for n in GENERATORS:                       # `core` first: it creates state_dict_keys.json, `yolo` adds to it
+        subprocess.run([sys.executable, os.path.abspath(__file__), "--only", n, "--out", OUT], check=True)
+    tot = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT) if f.endswith(".npz"))
+    print("fixtures written, total bytes:", tot)
+
+
+if __name__ == "__main__":
+    main(sys.argv[1:])

@@ -424,3 +424,27 @@ def test_clip_adam_follows_a_reloaded_optimizer_state():
     torch.cuda.synchronize()
     assert torch.equal(old_m, before_old) and not torch.equal(new_m, before_new)
     assert float(opt.state[ps[0]]["step"]) == 4.0
+
+
+@pytest.mark.parametrize("case", range(8))
+def test_td_kernels_match_the_reference_fixture(case, golden):
+    """a16, reward / TD half, pinned on the reference itself: adaisp_td_fwd / adaisp_td_bwd (through rl.td_losses on the
+    device) against td.npz — the statements of train.py:264-305 executed on seeded tensors by tests/golden/gen_golden.py
+    (gen_td) — for every (use_TD, use_truncated, use_penalty) setting: reward, q_value, both losses, and autograd's
+    gradients of each loss w.r.t. the retouch detection loss, penalty, surrogate and both critic values."""
+    import numpy as np
+    from test_rl_math import td_case, td_run
+    g = golden("td")
+    tag = f"c{case}"
+    c, leaves, fixed, use_truncated, max_bri = td_case(g, tag, device="cuda:0")
+    from adaptiveisp_amd import rl
+    assert rl._td_kernel_serves(fixed["l_in"], *leaves.values(), fixed["retouch_mean"])        # the HIP path is the one that runs
+    out, grads = td_run(c, leaves, fixed, use_truncated, max_bri)
+    for k in ("reward", "q_value", "value_loss", "agent_loss"):
+        np.testing.assert_allclose(out[k].detach().cpu().numpy(), g[f"{tag}.out.{k}"], rtol=2e-6, atol=2e-6, err_msg=f"{tag} {k}")
+    want = -g[f"{tag}.out.advantage"] if g[f"{tag}.switches"][0] else g[f"{tag}.out.q_value"] - g[f"{tag}.old_value"]
+    np.testing.assert_allclose(out["advantage"].detach().cpu().numpy(), want, rtol=2e-6, atol=2e-5, err_msg=f"{tag} advantage")
+    for k, v in grads.items():
+        ref = g[f"{tag}.{k}"]
+        np.testing.assert_allclose(v.cpu().numpy(), ref, rtol=2e-6, atol=2e-6 * max(float(np.abs(ref).max()), 1e-6),
+                                   err_msg=f"{tag} {k}")

@@ -609,3 +609,67 @@ def test_pair_engine_equals_two_single_passes(B, H, W):
         pair.per_sample_loss_pair(loss_fn, imgs, retouch, packed, packed_pair)
     with pytest.raises(RuntimeError):
         stale.sum().backward()
+
+
+def test_detloss_kernels_against_the_reference_fixture_directly(golden):
+    """adayolo_detloss_fwd / _bwd through the C-ABI on head maps that ARE the fixture's: detloss.npz `q*` — bf16-exact maps
+    scored by the reference's ComputeLossBatch one sample at a time (train.py:175-197), with autograd's gradient of
+    sum_b w_b loss_b — laid out as the detector's NHWC bf16 buffers. One hop from the reference to the kernels (the other
+    test of this file goes through yolo/loss.py)."""
+    import ctypes
+    import numpy as np
+    from adaptiveisp_amd.yolo import _lib
+    from adaptiveisp_amd.yolo.loss import DetectionLoss, assign_labels, pack_assigned
+    g = golden("detloss")
+    L = _lib.load()
+    hyp = dict(box=0.05, cls=0.5, obj=1.0 * (96 / 640) ** 2, anchor_t=4.0, cls_pw=1.0, obj_pw=1.0, fl_gamma=0.0,
+               label_smoothing=0.0)
+    loss_fn = DetectionLoss(torch.from_numpy(g["anchors"]), nc=80, hyp=hyp, device=DEV)
+    qs = [torch.from_numpy(g[f"q{i}"]) for i in range(3)]                      # [B, na, ny, nx, no]
+    B, na, no = qs[0].shape[0], qs[0].shape[1], qs[0].shape[4]
+    tg = torch.from_numpy(g["targets"])
+    labels = [tg[tg[:, 0] == b] for b in range(B)]
+    packed = pack_assigned(assign_labels(loss_fn, [q.to(DEV) for q in qs], labels))
+    cs = 256
+    raws, grads, keep = [], [], []
+    a = _lib.LossArgs()
+    for i, (q, (idx, box)) in enumerate(zip(qs, packed)):
+        ny, nx = q.shape[2], q.shape[3]
+        raw = torch.zeros((B, ny, nx, cs), dtype=torch.bfloat16, device=DEV)
+        raw[..., : na * no] = q.permute(0, 2, 3, 1, 4).reshape(B, ny, nx, na * no).to(torch.bfloat16).to(DEV)
+        assert torch.equal(raw[..., : na * no].float().cpu().view(B, ny, nx, na, no).permute(0, 3, 1, 2, 4), q)   # bf16-exact
+        grad = torch.full((B, ny, nx, cs), 7.0, dtype=torch.bfloat16, device=DEV)
+        ws = [torch.empty((B, 3), dtype=torch.float32, device=DEV), torch.empty((B, na, ny, nx), dtype=torch.float32, device=DEV),
+              torch.empty((B,), dtype=torch.float32, device=DEV)]
+        Ly = a.layer[i]
+        Ly.raw, Ly.cs, Ly.ny, Ly.nx, Ly.balance = raw.data_ptr(), cs, ny, nx, float(loss_fn.balance[i])
+        n = int(idx.shape[0])
+        Ly.idx, Ly.box, Ly.n = (idx.data_ptr() if n else None), (box.data_ptr() if n else None), n
+        Ly.part, Ly.tobj, Ly.cnt = ws[0].data_ptr(), ws[1].data_ptr(), ws[2].data_ptr()
+        Ly.grad, Ly.grad_cs = grad.data_ptr(), cs
+        raws.append(raw); grads.append(grad); keep += ws + [idx, box]
+    a.nl, a.B, a.na, a.nc, a.no = 3, B, na, 80, no
+    a.hyp_box, a.hyp_obj, a.hyp_cls = hyp["box"], hyp["obj"], hyp["cls"]
+    a.cp, a.cn, a.cls_pw, a.obj_pw = float(loss_fn.cp), float(loss_fn.cn), 1.0, 1.0
+    loss = torch.empty((B,), dtype=torch.float32, device=DEV)
+    ticket = torch.zeros((B,), dtype=torch.int32, device=DEV)
+    w = torch.from_numpy(g["qweights"]).to(DEV)
+    a.loss, a.ticket, a.grad_loss = loss.data_ptr(), ticket.data_ptr(), w.data_ptr()
+    st = _lib.stream_ptr()
+    _lib.check(L.adayolo_detloss_fwd(ctypes.byref(a), st), "adayolo_detloss_fwd")
+    torch.cuda.synchronize()
+    want = np.array([g[f"qsample{b}"].sum() for b in range(B)], np.float32)
+    np.testing.assert_allclose(loss.cpu().numpy(), want, rtol=2e-5, atol=1e-6)
+    scratch = torch.empty((B,), dtype=torch.float32, device=DEV)
+    a.loss = scratch.data_ptr()
+    _lib.check(L.adayolo_detloss_bwd(ctypes.byref(a), st), "adayolo_detloss_bwd")
+    torch.cuda.synchronize()
+    assert (ticket == 0).all()
+    for i, (gr, q) in enumerate(zip(grads, qs)):
+        ny, nx = q.shape[2], q.shape[3]
+        got = gr[..., : na * no].float().cpu().view(B, ny, nx, na, no).permute(0, 3, 1, 2, 4)
+        assert (gr[..., na * no:] == 0).all()
+        ref = torch.from_numpy(g[f"qgrad{i}"])
+        scale = ref.abs().max().item()
+        # the kernels store the gradient as bf16: one ulp (2^-8 relative) of each element + fp32 ordering noise
+        assert ((got - ref).abs() <= ref.abs() * 2 ** -7 + 2e-6 * scale).all(), (i, (got - ref).abs().max().item(), scale)
