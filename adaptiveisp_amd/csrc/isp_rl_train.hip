@@ -372,7 +372,7 @@ __global__ __launch_bounds__(256) void k_image_stats_partial(const float* __rest
                                                              long n) {
     __shared__ float red[4];
     const int b = blockIdx.y, ch = blockIdx.x;
-    const long per = ((n / 4 + kStatChunks - 1) / kStatChunks) * 4;            // floats per chunk, a multiple of 4
+    const long per = (((n + 3) / 4 + kStatChunks - 1) / kStatChunks) * 4;      // floats per chunk, a multiple of 4; 64 chunks cover n (also n % 4 != 0)
     const long lo = ch * per, hi = lo + per < n ? lo + per : n;
     const float* p = img + (long)b * n;
     float sum = 0.0f, bad = 0.0f;
@@ -445,7 +445,9 @@ __global__ __launch_bounds__(256) void k_gradnorm_finish(float* __restrict__ ws,
     s = block_sum256(s, red);
     if (threadIdx.x == 0) {
         const float total = sqrtf(s);
-        ws[nchunks] = fminf(max_norm / (total + 1e-6f), 1.0f);      // clip_grad_norm_'s coefficient (clamped to 1)
+        // clip_grad_norm_'s coefficient (clamped to 1). A non-finite gradient makes the norm NaN: torch.clamp propagates it and every
+        // gradient turns NaN — fminf alone would return 1 and step the finite elements unclipped
+        ws[nchunks] = (total == total) ? fminf(max_norm / (total + 1e-6f), 1.0f) : total;
         ws[nchunks + 1] = total;
     }
 }

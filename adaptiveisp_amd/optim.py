@@ -25,6 +25,9 @@ def _served(opt):
     if type(opt) is not torch.optim.Adam or len(opt.param_groups) != 1:
         return False
     g = opt.param_groups[0]
+    # registered optimizer-step hooks run inside opt.step(), which the kernel path never calls: leave such an optimizer to torch
+    if getattr(opt, "_optimizer_step_pre_hooks", None) or getattr(opt, "_optimizer_step_post_hooks", None):
+        return False
     return (not g.get("amsgrad") and g.get("weight_decay", 0) == 0 and not g.get("maximize") and not g.get("differentiable")
             and not g.get("capturable") and not isinstance(g["lr"], torch.Tensor)
             and not isinstance(g["betas"][0], torch.Tensor))
@@ -81,5 +84,10 @@ def clip_adam_step(opt, max_norm):
     _lib._check(rc, "adaisp_clip_adam_step")
     for p in params:                                           # written through raw pointers
         _lib._wrote(p)
+    # what Optimizer.step's wrapper would have recorded: LambdaLR warns ("lr_scheduler.step() before optimizer.step()") when the
+    # first step after a resume went through here (the state exists, so the kernels serve it at once)
+    opt._opt_called = True
+    if hasattr(opt, "_step_count"):
+        opt._step_count += 1
     opt.__dict__["_adaisp_keep"] = (dtable, [p.grad for p in params])   # alive until the next step has been enqueued behind this one
     return True

@@ -58,6 +58,6 @@ def to_device_async(array, device, dtype=None):
     block alive until the copy has run) and copied with non_blocking=True. A pageable source makes torch's copy synchronise
     the stream — i.e. wait for every kernel enqueued so far — which costs the RL loop its whole host / device overlap."""
     t = torch.as_tensor(array) if dtype is None else torch.as_tensor(array, dtype=dtype)
-    if torch.device(device).type != "cuda":
+    if torch.device(device).type != "cuda" or t.is_cuda:            # already on a device: nothing to pin
         return t.to(device)
     return t.pin_memory().to(device, non_blocking=True)

@@ -74,7 +74,7 @@ def run_eval(agent, detector, batches, cfg, steps=5, conf_thres=0.001, iou_thres
         # the previous batch's NMS / matching launches before this batch's first kernel can even be enqueued
         nb, _, height, width = im.shape
         targets = targets.clone()
-        targets[:, 2:] *= torch.tensor((width, height, width, height), dtype=targets.dtype)      # to pixels, on the host
+        targets[:, 2:] *= torch.tensor((width, height, width, height), dtype=targets.dtype, device=targets.device)   # to pixels, where the batch lives (the host, for a loader's batches)
         im = to_device_async(im, dev).float()
         targets = to_device_async(targets, dev)
         noises = to_device_async(np.array([get_noise(nb, cfg.z_type, cfg.z_dim) for _ in range(steps)]), dev)

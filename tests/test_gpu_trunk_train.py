@@ -356,6 +356,21 @@ def test_image_stats(shape):
     assert torch.equal(torch.nan_to_num(st, nan=-1.0), torch.nan_to_num(_lib.image_stats(x), nan=-1.0))
 
 
+@pytest.mark.parametrize("hw", [(255, 255), (257, 257)])
+def test_image_stats_tail_elements_of_odd_sizes(hw):
+    """n % 4 != 0 with floor(n / 4) a multiple of the 64 chunks (3 x 255 x 255 = 195075): the last 1 - 3 values of every image
+    are summed and checked for non-finite values too (they were not; the replay guard could miss a NaN there)."""
+    from adaptiveisp_amd import _lib
+    dev = torch.device("cuda:0")
+    x = torch.rand((3, 3) + hw, generator=torch.Generator().manual_seed(4)).to(dev)
+    x[0].view(-1)[-1] = 1000.0                       # a value the mean cannot miss
+    x[1].view(-1)[-1] = float("nan")
+    x[2].view(-1)[-3] = float("inf")
+    st = _lib.image_stats(x)
+    assert st[:, 1].tolist() == [0.0, 1.0, 1.0]
+    assert abs(st[0, 0].item() - x[0].double().mean().item()) < 2e-6 * x[0].double().mean().item()
+
+
 @pytest.mark.parametrize("max_norm", [1e-5, 1e3])
 def test_clip_adam_kernels_match_torch(max_norm):
     """adaisp_clip_adam_step (optim.clip_adam_step) against torch.nn.utils.clip_grad_norm_ + torch.optim.Adam(fused=True).step()
@@ -397,6 +412,49 @@ def test_clip_adam_kernels_match_torch(max_norm):
     # options the kernels do not serve are left to torch
     assert not aoptim.clip_adam_step(torch.optim.Adam(pa, lr=1e-3, weight_decay=0.1, fused=True), 1.0)
     assert not aoptim.clip_adam_step(torch.optim.SGD(pa, lr=1e-3), 1.0)
+
+
+def test_clip_adam_nan_norm_scheduler_bookkeeping_and_hooks():
+    """(1) a non-finite gradient makes the total norm NaN and — like torch's clamp in clip_grad_norm_ — every
+    gradient's coefficient NaN, so ALL parameters go NaN (fminf alone stepped the finite ones unclipped); (2) the kernel path
+    records what Optimizer.step's wrapper records (`_opt_called`, `_step_count`): no LambdaLR warning after a resume;
+    (3) an optimizer with registered step hooks is left to torch (the kernels never call opt.step())."""
+    import warnings
+    from adaptiveisp_amd import optim as aoptim
+    dev = torch.device("cuda:0")
+
+    def make():
+        ps = [torch.nn.Parameter(torch.randn(300, 40, device=dev)), torch.nn.Parameter(torch.randn(17, device=dev))]
+        opt = torch.optim.Adam(ps, lr=1e-3, fused=True)
+        for p in ps:
+            p.grad = torch.randn_like(p)
+        torch.nn.utils.clip_grad_norm_(ps, 1.0)
+        opt.step()                                                   # creates the state: the next step is the kernels'
+        return ps, opt
+    ps, opt = make()
+    fresh = torch.optim.Adam(ps, lr=1e-3, fused=True)               # as after a resume: state loaded, step() never called
+    fresh.load_state_dict(copy.deepcopy(opt.state_dict()))
+    sched = torch.optim.lr_scheduler.LambdaLR(fresh, lambda it: 0.5 ** it)
+    for p in ps:
+        p.grad = torch.randn_like(p)
+    assert aoptim.clip_adam_step(fresh, 1.0)
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        sched.step()                                                 # would warn if optimizer.step() had "not been called"
+    assert fresh._opt_called
+    # (3)
+    hooked = torch.optim.Adam(ps, lr=1e-3, fused=True)
+    hooked.load_state_dict(copy.deepcopy(opt.state_dict()))
+    hooked.register_step_post_hook(lambda o, a, k: None)
+    assert not aoptim.clip_adam_step(hooked, 1.0)
+    # (1)
+    ps, opt = make()
+    for p in ps:
+        p.grad = torch.randn_like(p)
+    ps[1].grad[3] = float("nan")
+    assert aoptim.clip_adam_step(opt, 1e-5)
+    torch.cuda.synchronize()
+    assert all(torch.isnan(p).all() for p in ps)
 
 
 def test_clip_adam_follows_a_reloaded_optimizer_state():
