@@ -1,5 +1,8 @@
 // C-ABI of libadayolo.so (include/adayolo.h): argument checks + launches. No allocation, no sync.
 #include "yolo_internal.h"
+#include <algorithm>
+#include <cstring>
+#include <vector>
 
 using namespace adayolo;
 
@@ -126,6 +129,174 @@ int adayolo_conv_fused1x1_fwd(const void* in, int in_cstride, const void* weight
     a.out2 = static_cast<unsigned short*>(out2); a.out2_cs = out2_cstride;
     a.pre = nullptr; a.pre_cs = 0;
     return launch_conv_pp(a, static_cast<hipStream_t>(stream), 50) == hipSuccess ? ADAYOLO_OK : ADAYOLO_ELAUNCH;
+}
+
+// ---- persistent chain: host-side tables ------------------------------------------------------------------------------------
+namespace {
+struct ChainPlan {
+    std::vector<ConvArgs> layers;
+    std::vector<ChainHead> heads;
+    std::vector<ChainDeps> deps;
+    int ndone = 0;
+    size_t off_layers = 0, off_heads = 0, off_deps = 0, bytes = 0;
+};
+struct Span { const char* lo; const char* hi; };
+inline bool overlap(const Span& x, const Span& y) { return x.lo && y.lo && x.lo < y.hi && y.lo < x.hi; }
+inline size_t up64(size_t v) { return (v + 63) & ~(size_t)63; }
+
+// ADAYOLO_OK and the tables, or the reason this list is not served
+int chain_plan(const adayolo_chain_layer* L, int n, ChainPlan& P, bool tables) {
+    if (!L || n < 1 || n > 64) return ADAYOLO_EINVAL;
+    P.layers.resize(n);
+    std::vector<int> flag_base(n), in_src(n, -1), res_src(n, -1);
+    std::vector<Span> s_in(n), s_res(n), s_out(n), s_out2(n);
+    int total = 0;
+    P.ndone = 0;
+    for (int l = 0; l < n; ++l) {
+        const adayolo_chain_layer& d = L[l];
+        ConvArgs& a = P.layers[l];
+        const int rc = conv_args(a, d.in, d.in_cstride, d.weight, d.bias, d.residual, d.res_cstride, d.out, d.out_cstride, d.B, d.H,
+                                 d.W, d.Cin, d.Cout, d.ksize, d.stride, d.act);
+        if (rc != ADAYOLO_OK) return rc;
+        if (a.Cin % 64 || a.Cout % 256) return ADAYOLO_ESHAPE;
+        if (d.weight2) {
+            if (!d.bias2 || !d.out2) return ADAYOLO_EINVAL;
+            if (a.Cout != 256 || d.Cout2 != 128 || d.out2_cstride % 8 || d.out2_cstride < d.Cout2) return ADAYOLO_ESHAPE;
+            a.w2 = static_cast<const unsigned short*>(d.weight2); a.bias2 = d.bias2;
+            a.out2 = static_cast<unsigned short*>(d.out2); a.out2_cs = d.out2_cstride;
+        }
+        a.mtiles = (a.M + 255) / 256;
+        a.ntiles = a.Cout / 256;
+        // the written-through stores address their tensor with 32-bit byte offsets
+        if ((long)a.M * a.out_cs * 2 >= 0x7FFFFFFFL || (a.out2 && (long)a.M * a.out2_cs * 2 >= 0x7FFFFFFFL)) return ADAYOLO_ESHAPE;
+        s_in[l] = Span{(const char*)a.in, (const char*)a.in + (long)a.B * a.H * a.W * a.in_cs * 2};
+        s_res[l] = Span{(const char*)a.res, a.res ? (const char*)a.res + (long)a.M * a.res_cs * 2 : nullptr};
+        s_out[l] = Span{(const char*)a.out, (const char*)a.out + (long)a.M * a.out_cs * 2};
+        s_out2[l] = Span{(const char*)a.out2, a.out2 ? (const char*)a.out2 + (long)a.M * a.out2_cs * 2 : nullptr};
+        if (overlap(s_out[l], s_in[l]) || overlap(s_out[l], s_res[l]) || overlap(s_out2[l], s_in[l]) || overlap(s_out2[l], s_res[l]) ||
+            overlap(s_out[l], s_out2[l]))
+            return ADAYOLO_ESHAPE;
+        for (int k = l - 1; k >= 0; --k) {
+            const ConvArgs& p = P.layers[k];
+            // a tensor of this layer may meet an earlier layer's OUTPUT only as that layer's exact output (a dependency)
+            auto link = [&](const unsigned short* ptr, int cs, long rows, const Span& sp, int& src) -> bool {
+                if (!ptr) return true;
+                const bool m_out = ptr == p.out && cs == p.out_cs && rows == p.M;
+                const bool m_out2 = p.out2 && ptr == p.out2 && cs == p.out2_cs && rows == p.M;
+                if (m_out || m_out2) { if (src < 0) src = k; return true; }
+                return !(overlap(sp, s_out[k]) || overlap(sp, s_out2[k]));
+            };
+            if (!link(a.in, a.in_cs, (long)a.B * a.H * a.W, s_in[l], in_src[l])) return ADAYOLO_ESHAPE;
+            if (!link(a.res, a.res_cs, a.M, s_res[l], res_src[l])) return ADAYOLO_ESHAPE;
+            // ... and this layer's outputs meet nothing an earlier layer reads or writes
+            for (const Span* o : {&s_out[l], &s_out2[l]})
+                if (overlap(*o, s_in[k]) || overlap(*o, s_res[k]) || overlap(*o, s_out[k]) || overlap(*o, s_out2[k])) return ADAYOLO_ESHAPE;
+        }
+        flag_base[l] = P.ndone;
+        P.ndone += a.mtiles;
+        total += a.mtiles * a.ntiles;
+    }
+    P.off_layers = up64(64 + (size_t)P.ndone * 4);
+    P.off_heads = up64(P.off_layers + (size_t)n * sizeof(ConvArgs));
+    P.off_deps = up64(P.off_heads + (size_t)total * sizeof(ChainHead));
+    P.bytes = up64(P.off_deps + (size_t)total * sizeof(ChainDeps));
+    if (P.bytes >= 0x7FFFFFFFu) return ADAYOLO_ESHAPE;
+    P.heads.clear(); P.deps.clear();
+    if (!tables) { P.heads.resize(total); return ADAYOLO_OK; }      // (only the count is needed)
+    P.heads.reserve(total); P.deps.reserve(total);
+    for (int l = 0; l < n; ++l) {
+        const ConvArgs& a = P.layers[l];
+        for (int lid = 0; lid < a.mtiles * a.ntiles; ++lid) {
+            const int mt = lid / a.ntiles;
+            const int m0 = mt * 256, m1 = std::min(m0 + 255, a.M - 1);
+            ChainDeps dp{0, 0, 0, 0};
+            if (in_src[l] >= 0) {
+                const ConvArgs& p = P.layers[in_src[l]];
+                const int hw = a.Ho * a.Wo;
+                const int b0 = m0 / hw, ho0 = (m0 % hw) / a.Wo, b1 = m1 / hw, ho1 = (m1 % hw) / a.Wo;
+                const int r_lo = std::max(ho0 * a.stride - a.pad, 0), r_hi = std::min(ho1 * a.stride - a.pad + a.ks - 1, a.H - 1);
+                const long px_lo = ((long)b0 * a.H + r_lo) * a.W, px_hi = ((long)b1 * a.H + r_hi) * a.W + a.W - 1;
+                const int t_lo = (int)(px_lo / 256), t_hi = std::min((int)(px_hi / 256), p.mtiles - 1);
+                const int cnt = t_hi - t_lo + 1;
+                if (cnt < 1 || cnt > 32 || p.ntiles > 0xFFFF) return ADAYOLO_ESHAPE;
+                dp.in_lo = flag_base[in_src[l]] + t_lo;
+                dp.in_n_need = (cnt << 16) | p.ntiles;
+            }
+            if (res_src[l] >= 0) {
+                const ConvArgs& p = P.layers[res_src[l]];
+                const int t_lo = m0 / 256, t_hi = std::min(m1 / 256, p.mtiles - 1);
+                dp.res_lo = flag_base[res_src[l]] + t_lo;
+                dp.res_n_need = ((t_hi - t_lo + 1) << 16) | p.ntiles;
+            }
+            P.heads.push_back(ChainHead{l, lid, flag_base[l] + mt, 0});
+            P.deps.push_back(dp);
+        }
+    }
+    return ADAYOLO_OK;
+}
+
+int device_cus() {
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0)
+            v = 256;
+        cus = v;
+    }
+    return cus;
+}
+}  // namespace
+
+size_t adayolo_conv_chain_workspace_bytes(const adayolo_chain_layer* layers, int n) {
+    ChainPlan P;
+    return chain_plan(layers, n, P, true) == ADAYOLO_OK ? P.bytes : 0;
+}
+
+int adayolo_conv_chain_tables(const adayolo_chain_layer* layers, int n, void* host_image, size_t bytes, int32_t* info) {
+    ChainPlan P;
+    const int rc = chain_plan(layers, n, P, true);
+    if (rc != ADAYOLO_OK) return rc;
+    if (!host_image || bytes < P.bytes) return ADAYOLO_EINVAL;
+    unsigned char* img = static_cast<unsigned char*>(host_image);
+    memset(img, 0, P.bytes);
+    memcpy(img + P.off_layers, P.layers.data(), P.layers.size() * sizeof(ConvArgs));
+    memcpy(img + P.off_heads, P.heads.data(), P.heads.size() * sizeof(ChainHead));
+    memcpy(img + P.off_deps, P.deps.data(), P.deps.size() * sizeof(ChainDeps));
+    if (info) {
+        info[0] = (int32_t)P.heads.size(); info[1] = P.ndone; info[2] = (int32_t)P.off_layers; info[3] = (int32_t)P.off_heads;
+        info[4] = (int32_t)P.off_deps; info[5] = (int32_t)sizeof(ConvArgs);
+    }
+    return ADAYOLO_OK;
+}
+
+int adayolo_conv_chain_prepare(const adayolo_chain_layer* layers, int n, void* workspace, size_t workspace_bytes) {
+    ChainPlan P;
+    const int rc = chain_plan(layers, n, P, false);
+    if (rc != ADAYOLO_OK) return rc;
+    if (!workspace || workspace_bytes < P.bytes || ((uintptr_t)workspace & 63)) return ADAYOLO_EINVAL;
+    std::vector<unsigned char> img(P.bytes, 0);
+    const int rc2 = adayolo_conv_chain_tables(layers, n, img.data(), img.size(), nullptr);
+    if (rc2 != ADAYOLO_OK) return rc2;
+    return hipMemcpy(workspace, img.data(), P.bytes, hipMemcpyHostToDevice) == hipSuccess ? ADAYOLO_OK : ADAYOLO_ELAUNCH;
+}
+
+int adayolo_conv_chain_fwd(const adayolo_chain_layer* layers, int n, void* workspace, size_t workspace_bytes, void* stream) {
+    ChainPlan P;
+    const int rc = chain_plan(layers, n, P, false);
+    if (rc != ADAYOLO_OK) return rc;
+    if (!workspace || workspace_bytes < P.bytes || ((uintptr_t)workspace & 63)) return ADAYOLO_EINVAL;
+    ChainArgs c;
+    c.ws = static_cast<unsigned char*>(workspace);
+    c.off_layers = (int)P.off_layers; c.off_heads = (int)P.off_heads; c.off_deps = (int)P.off_deps; c.total = (int)P.heads.size();
+    return launch_conv_chain(c, P.ndone, device_cus(), static_cast<hipStream_t>(stream)) == hipSuccess ? ADAYOLO_OK : ADAYOLO_ELAUNCH;
+}
+
+int adayolo_conv_chain_status(const void* workspace) {
+    if (!workspace) return ADAYOLO_EINVAL;
+    int w[2] = {0, 0};
+    if (hipDeviceSynchronize() != hipSuccess) return ADAYOLO_ELAUNCH;
+    if (hipMemcpy(w, workspace, sizeof(w), hipMemcpyDeviceToHost) != hipSuccess) return ADAYOLO_ELAUNCH;
+    return w[1];
 }
 
 int adayolo_bottleneck256_fwd(const void* x, int x_cstride, const void* weight1, const float* bias1, const void* weight2,

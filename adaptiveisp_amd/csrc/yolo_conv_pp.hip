@@ -118,22 +118,58 @@ struct KPos {
 // operand is read from the tile (pitch 144 B:
 // conflict-free ds_read_b128) — and writes it through its own region again. The second layer sees exactly the bf16 values
 // the unfused kernel would read back from memory.
-template <int ABL, bool FUSE>
-__global__ __launch_bounds__(512) void k_conv_pp(const ConvArgs a) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+// ---- persistent chain (k_conv_chain below): several consecutive layers of this kernel's tiles in ONE launch ------------------
+// One work item = one 256 x 256 tile of one layer. Host-built (yolo_conv_pp.hip::launch_conv_chain's caller, yolo_api.hip):
+// which arrival counters of the PRODUCING layers an item's input window / residual tile needs, and which counter it bumps.
+constexpr int kSchedOff = (kEpi > 2 * kBuf ? kEpi : 2 * kBuf) + BN * 4;    // int[4]: {next item, its inputs are ready, -, -}
+constexpr int kSmemChain = kSchedOff + 16;
+constexpr unsigned kSpinLimit = 1u << 19;                                  // ~1 s of polling before a wait gives up
+
+// what a tile needs from the chain it runs in (CHAIN == false: unused)
+struct ChainCtx {
+    const ChainArgs* c;
+    int pending;                 // done[] index of the previous tile of this workgroup whose arrival is not yet published, or -1
+};
+typedef const __attribute__((address_space(4))) int* cint_p;          // constant address space: uniform loads are scalar loads
+__device__ __forceinline__ int* chain_head(const ChainArgs& c) { return reinterpret_cast<int*>(c.ws); }
+__device__ __forceinline__ int* chain_err(const ChainArgs& c) { return reinterpret_cast<int*>(c.ws) + 1; }
+__device__ __forceinline__ int* chain_done(const ChainArgs& c) { return reinterpret_cast<int*>(c.ws + 64); }
+__device__ __forceinline__ void chain_load4(const ChainArgs& c, int off, int item, int (&r)[4]) {
+    cint_p q = (cint_p)((unsigned long long)c.ws + (unsigned)off + (unsigned long long)(unsigned)item * 16u);
+    r[0] = q[0]; r[1] = q[1]; r[2] = q[2]; r[3] = q[3];
+}
+// lane l < 32: done[in_lo + l], lane 32 + l: done[res_lo + l] -> this lane's counter has arrived (lanes without one: true)
+__device__ __forceinline__ int chain_counter(const ChainArgs& c, const int (&d)[4], int lane) {
+    const int l = lane & 31;
+    const bool act = lane < 32 ? l < (d[1] >> 16) : l < (d[3] >> 16);
+    int v = 0x7fffffff;
+    if (act) v = __hip_atomic_load(chain_done(c) + (lane < 32 ? d[0] : d[2]) + l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return v;
+}
+__device__ __forceinline__ bool chain_arrived(const int (&d)[4], int v, int lane) {
+    return __all(v >= ((lane < 32 ? d[1] : d[3]) & 0xFFFF));
+}
+
+// One 256 x 256 tile. CHAIN: `lid` is handed in, output stores are written through (sc1) and this workgroup's previous tile is
+// published once they are known complete; wave 0 fetches the next item and checks its inputs in the shadow of the epilogue.
+template <int ABL, bool FUSE, bool CHAIN>
+__device__ __forceinline__ void conv_tile(const ConvArgs& a, const int lid, unsigned char* smem, ChainCtx& cx) {
     float* bias_s = reinterpret_cast<float*>(smem + (kEpi > 2 * kBuf ? kEpi : 2 * kBuf));
     PP_STAMP(0);
 #ifdef PP_DEPHASE            // measurement build: every other workgroup of an XCD starts PP_DEPHASE cycles late
-    if ((blockIdx.x >> 3) & 1) {
+    if (!CHAIN && ((blockIdx.x >> 3) & 1)) {
         const unsigned long long t0 = __builtin_readcyclecounter();
         while (__builtin_readcyclecounter() - t0 < (unsigned long long)(PP_DEPHASE)) __builtin_amdgcn_s_sleep(16);
     }
 #endif
 
-    const int tid = threadIdx.x, lane = tid & 63;
+    int tid_ = threadIdx.x;
+    // (CHAIN: opaque per tile, so that nothing derived from the thread index is hoisted out of the persistent loop and then
+    // spilled across the tile — the tile body alone uses 253 of 256 registers; recomputing a dozen integers per tile is free)
+    if (CHAIN) asm volatile("" : "+v"(tid_));
+    const int tid = tid_, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 2, wn = wave & 3;           // wm is also the ping-pong group
-    const int lid = xcd_remap(blockIdx.x, a.mtiles * a.ntiles);
     const int m0 = (lid / a.ntiles) * BM, n0 = (lid % a.ntiles) * BN;
     const unsigned long long zaddr = (unsigned long long)(const void*)g_zero16;
 
@@ -260,8 +296,17 @@ __global__ __launch_bounds__(512) void k_conv_pp(const ConvArgs a) {
     // resident data streams into LDS at 51.6 B/clk/CU for any row stride (tools/dma_pattern.hip) while the k-loop moves 27,
     // and about a quarter of its activation rows are first touches. The k-loop did not move: 44.1k -> 43.9k cycles,
     // prologue + 1.0k. First-touch latency is not what holds it.)
-    wait_vm<4>();                                        // k-tile 0 landed (this wave's share)
-    barrier();
+    if (CHAIN) {
+        // ... and every store of this workgroup's PREVIOUS tile is written through: its arrival can be published (one lane,
+        // behind the barrier: every wave has drained)
+        wait_vm<0>();
+        barrier();
+        if (cx.pending >= 0 && tid == 0) __hip_atomic_fetch_add(chain_done(*cx.c) + cx.pending, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        cx.pending = -1;
+    } else {
+        wait_vm<4>();                                    // k-tile 0 landed (this wave's share)
+        barrier();
+    }
 
     bf16x8 af[2][4], wx[4], wy[4];
     auto read_a = [&](const unsigned char* buf, int half) {
@@ -365,6 +410,50 @@ __global__ __launch_bounds__(512) void k_conv_pp(const ConvArgs a) {
     //      (Storing 8/16-byte pieces straight from the fragment layout was measured 2x slower: 32 rows x 32 B per
     //      instruction instead of 8 rows x 128 B.)
     unsigned char* my = smem + wave * (128 * kEpiPitch);
+    // CHAIN: wave 0 looks ahead while the epilogue runs — four stages, each consuming what the previous one requested a few
+    // microseconds earlier (three dependent round trips: work counter -> item record -> arrival counters), so that the next
+    // tile starts without waiting for any of them:
+    //   0 (epilogue start)  lane 0 draws the next item from the work counter
+    //   1                   the item's record is requested
+    //   2                   the arrival counters its input window / residual tile wait for are requested
+    //   3 (last stores out) all arrived -> ONE buffer_inv sc1 (this CU's L1 may hold lines of those tensors from an earlier
+    //                       forward; the counters have been observed, so the invalidate is the acquire) and {item, ready} go
+    //                       to the workgroup through LDS. Not arrived (rare: the producers are ~200 items ahead): the slow
+    //                       path at the top of the next tile polls.
+    int nx_item = 0x7fffffff, nx_val = 0x7fffffff;
+    int nx_deps[4] = {0, 0, 0, 0};
+    auto sched_stage = [&](int stage) {
+        if (!CHAIN) return;
+        if (wave != 0) return;
+        const ChainArgs& c = *cx.c;
+        if (stage == 0) {
+            int t = 0;
+            if (lane == 0) t = __hip_atomic_fetch_add(chain_head(c), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            nx_item = t;
+        } else if (stage == 1) {
+            nx_item = __builtin_amdgcn_readfirstlane(nx_item);
+            if (nx_item < c.total) chain_load4(c, c.off_deps, nx_item, nx_deps);          // scalar load: four SGPRs
+        } else if (stage == 2) {
+            if (nx_item < c.total) nx_val = chain_counter(c, nx_deps, lane);
+        } else {
+            int ready = 0;
+            if (nx_item < c.total && chain_arrived(nx_deps, nx_val, lane)) {
+                asm volatile("buffer_inv sc1" ::: "memory");
+                ready = 1;
+            }
+            if (lane == 0) *reinterpret_cast<int2*>(smem + kSchedOff) = int2{nx_item, ready};
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+    };
+    // CHAIN: the tile's outputs leave as 16-byte WRITE-THROUGH (sc1) buffer stores — complete, for every other CU and XCD, once
+    // the storing wave's vmcnt reaches 0 (no release fence, i.e. no whole-L2 write-back); byte offsets are 32-bit (the caller
+    // checks the tensors are < 2 GB)
+    constexpr int kSc1 = 16;
+    __amdgpu_buffer_rsrc_t rs_out, rs_out2;
+    if (CHAIN) {
+        rs_out = __builtin_amdgcn_make_buffer_rsrc((void*)a.out, 0, 0x7FFFFFFF, 0x00020000);
+        if (FUSE) rs_out2 = __builtin_amdgcn_make_buffer_rsrc((void*)a.out2, 0, 0x7FFFFFFF, 0x00020000);
+    }
     // The activation and the residual are compile-time copies (no per-element select, no per-chunk branch); bias and
     // row pointers are set up once; per 32-pixel group the four LDS reads, the four residual loads and the four stores
     // are issued back to back (one wait each), not read -> wait -> load -> wait -> store four times over.
@@ -387,8 +476,10 @@ __global__ __launch_bounds__(512) void k_conv_pp(const ConvArgs a) {
         // per-CU streaming rate. Measured and dropped: requesting the rows 2 or 4 groups ahead instead of one — no change, the
         // stream is rate-bound, not latency-bound — and starting the accumulators at the bias to free the registers for
         // that — the k-loop lost 2-3k cycles to the changed register allocation.)
+        const int obyte = CHAIN ? (int)(((long)mrow * a.out_cs + n) * 2) : 0;
 #pragma unroll
         for (int mi = 0; mi < 4; ++mi) {
+            if (mi < 3) sched_stage(mi);                         // (stage 3 follows the tile's last stores)
             u32x4 v[4], r[4];
             bool ok[4];
 #pragma unroll
@@ -424,8 +515,10 @@ __global__ __launch_bounds__(512) void k_conv_pp(const ConvArgs a) {
             }
 #pragma unroll
             for (int it = 0; it < 4; ++it)
-                if (ok[it] && !(ABL == 3 && v[it][0] != 0x12345678u))
-                    ADAYOLO_STORE(v[it], reinterpret_cast<u32x4*>(op + (4 * mi + it) * ostep));
+                if (ok[it] && !(ABL == 3 && v[it][0] != 0x12345678u)) {
+                    if (CHAIN) __builtin_amdgcn_raw_buffer_store_b128(v[it], rs_out, obyte + (4 * mi + it) * (int)(2 * ostep), 0, kSc1);
+                    else ADAYOLO_STORE(v[it], reinterpret_cast<u32x4*>(op + (4 * mi + it) * ostep));
+                }
             if (FUSE) {                                          // the rows the second layer reads: post-residual
 #pragma unroll
                 for (int it = 0; it < 4; ++it)
@@ -513,11 +606,98 @@ __global__ __launch_bounds__(512) void k_conv_pp(const ConvArgs a) {
             u32x4 v2[8];
 #pragma unroll
             for (int it = 0; it < 8; ++it) v2[it] = *reinterpret_cast<const u32x4*>(my + (r0 + 16 * it) * kEpiPitch + c4 * 16);
+            const int obyte2 = CHAIN ? (int)(((long)mrow * a.out2_cs + cq * 32 + c4 * 8) * 2) : 0;
 #pragma unroll
             for (int it = 0; it < 8; ++it)
-                if (mrow + 16 * it < a.M) ADAYOLO_STORE(v2[it], reinterpret_cast<u32x4*>(op2 + (long)(16 * it) * a.out2_cs));
+                if (mrow + 16 * it < a.M) {
+                    if (CHAIN) __builtin_amdgcn_raw_buffer_store_b128(v2[it], rs_out2, obyte2 + 16 * it * a.out2_cs * 2, 0, kSc1);
+                    else ADAYOLO_STORE(v2[it], reinterpret_cast<u32x4*>(op2 + (long)(16 * it) * a.out2_cs));
+                }
         }
         if (ABL == 7) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); PP_STAMP(7); }
+    }
+    if (CHAIN) {
+        sched_stage(3);
+        barrier();                                           // the tile's LDS is free; {next item, ready} is in place
+    }
+}
+
+template <int ABL, bool FUSE>
+__global__ __launch_bounds__(512) void k_conv_pp(const ConvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    ChainCtx none{nullptr, -1};
+    conv_tile<ABL, FUSE, false>(a, xcd_remap(blockIdx.x, a.mtiles * a.ntiles), smem, none);
+}
+
+// Persistent form: one workgroup per CU draws tiles of SEVERAL consecutive layers from one work counter (layer-major order)
+// until none is left. What a launch per layer costs and this does not: the ramp and tail of every launch (~4 us x layers), the
+// 80 - 90 % full last round of every layer (460 tiles on 256 CUs), and every CU being in the same phase at the same time — the
+// workgroups drift apart, so one CU's prologue / residual / store bursts meet other CUs' k-loops instead of 255 other bursts.
+// Dependencies: a tile waits for the m-tiles of the producing layer its input window and its residual rows lie in (arrival
+// counters, bumped when a tile's written-through stores are complete). It only ever waits for items that come before it in
+// the hand-out order, and those are held by workgroups that are running: no deadlock whatever number of workgroups is resident.
+__global__ __launch_bounds__(512) void k_conv_chain(const ChainArgs c) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int* sched = reinterpret_cast<int*>(smem + kSchedOff);
+    if (tid == 0) {
+        sched[0] = __hip_atomic_fetch_add(chain_head(c), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        sched[1] = 0;
+    }
+    __syncthreads();
+    int item = __builtin_amdgcn_readfirstlane(sched[0]), ready = 0;
+    ChainCtx cx{&c, -1};
+    while (item < c.total) {
+        int hd[4];
+        chain_load4(c, c.off_heads, item, hd);               // {layer, tile, arrival counter, -}
+        if (!ready) {
+            // slow path (a workgroup's first item, or the look-ahead found a counter short): publish what this workgroup still
+            // holds back — a waiting workgroup must not sit on a finished tile others may need — then poll, bounded
+            if (cx.pending >= 0) {
+                wait_vm<0>();
+                barrier();
+                if (tid == 0) __hip_atomic_fetch_add(chain_done(c) + cx.pending, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                cx.pending = -1;
+            }
+            if (wave == 0) {
+                int d[4];
+                chain_load4(c, c.off_deps, item, d);
+                // bounded: a wait that gives up records its item; once ANY wait of the launch has given up no other one spins (the
+                // launch then finishes within one limit, wrong — adayolo_conv_chain_status tells)
+                unsigned spins = 0;
+                while (!chain_arrived(d, chain_counter(c, d, lane), lane)) {
+                    const int e = __hip_atomic_load(chain_err(c), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (e != 0) break;
+                    if (++spins > kSpinLimit) {
+                        if (lane == 0) __hip_atomic_store(chain_err(c), item + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(32);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            }
+            __syncthreads();
+        }
+        // the layer's arguments through the scalar path (uniform index, constant table): SGPRs, as kernel arguments would be
+        ConvArgs a;
+        {
+            cint_p q = (cint_p)((unsigned long long)c.ws + (unsigned)c.off_layers + (unsigned long long)(unsigned)hd[0] * sizeof(ConvArgs));
+            int w[sizeof(ConvArgs) / 4];
+#pragma unroll
+            for (int i = 0; i < (int)(sizeof(ConvArgs) / 4); ++i) w[i] = q[i];
+            __builtin_memcpy(&a, w, sizeof(ConvArgs));
+        }
+        if (a.w2) conv_tile<0, true, true>(a, hd[1], smem, cx);
+        else conv_tile<0, false, true>(a, hd[1], smem, cx);
+        cx.pending = hd[2];
+        item = __builtin_amdgcn_readfirstlane(sched[0]);
+        ready = __builtin_amdgcn_readfirstlane(sched[1]);
+    }
+    if (cx.pending >= 0) {
+        wait_vm<0>();
+        barrier();
+        if (tid == 0) __hip_atomic_fetch_add(chain_done(c) + cx.pending, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -538,7 +718,29 @@ static hipError_t launch(ConvArgs a, hipStream_t s) {
     return hipGetLastError();
 }
 
+static hipError_t launch_chain(const ChainArgs& c, int grid, hipStream_t s) {
+    static_assert(kSmemChain <= 160 * 1024, "LDS budget");
+    static bool configured = false;
+    if (!configured) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv_chain), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           kSmemChain);
+        if (e != hipSuccess) return e;
+        configured = true;
+    }
+    hipLaunchKernelGGL(k_conv_chain, dim3(grid), dim3(512), kSmemChain, s, c);
+    return hipGetLastError();
+}
+
 }  // namespace pp
+
+// Persistent chain of 256 x 256-tile layers (k_conv_chain). The counters at the head of the workspace are zeroed here, on the
+// stream, ahead of the launch (a memset node under graph capture: replayed first, every replay).
+hipError_t launch_conv_chain(const ChainArgs& c, int ndone, int grid, hipStream_t s) {
+    if (!c.ws || c.total <= 0 || grid <= 0 || ndone < 0) return hipErrorInvalidValue;
+    hipError_t e = hipMemsetAsync(c.ws, 0, 64 + (size_t)ndone * sizeof(int), s);
+    if (e != hipSuccess) return e;
+    return pp::launch_chain(c, grid < c.total ? grid : c.total, s);
+}
 
 // variant 50 = the kernel; with -DADAYOLO_MEASURE 51..57 = the measurement builds (ABL above). hipErrorInvalidValue ->
 // the shape is not served (the caller falls back to the default kernel).

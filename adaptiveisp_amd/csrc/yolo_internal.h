@@ -92,6 +92,25 @@ __device__ __forceinline__ void bias_act_pack4(float a0, float a1, float a2, flo
     hi = __builtin_bit_cast(unsigned, __builtin_convertvector(x1, bf16x2_pk));
 }
 
+// ---- persistent chain (yolo_conv_pp.hip: k_conv_chain): several consecutive layers of the 256 x 256 kernel's tiles in ONE launch.
+// One work item = one tile of one layer; the tables are built on the host (yolo_api.hip: adayolo_conv_chain_prepare).
+// Workspace (device, caller-owned; the byte offsets are multiples of 64):
+//   [0, 64)            int head (next item to hand out), int err (!= 0: a bounded wait gave up: item + 1), padding
+//   [64, ...)          int done[ndone]: arrival counters, one per (layer, m-tile)
+//   [off_layers, ...)  ConvArgs[nlayers]
+//   [off_heads, ...)   ChainHead[total]   layer-major: an item only ever waits for items BEFORE it in this order
+//   [off_deps, ...)    ChainDeps[total]
+// Everything behind the counters is constant during a launch and read through the SCALAR path (uniform indices).
+struct ChainHead { int layer, lid, flag, pad; };   // tile `lid` (m-tile * ntiles + n-tile) of `layer`; done[flag] += 1 when it is stored
+struct ChainDeps {                                 // done[lo .. lo + n) each >= need before the input window / the residual rows are read
+    int in_lo, in_n_need;                          // (n << 16) | need; n = 0: produced before the launch
+    int res_lo, res_n_need;
+};
+struct ChainArgs {
+    unsigned char* ws;
+    int off_layers, off_heads, off_deps, total;
+};
+hipError_t launch_conv_chain(const ChainArgs& c, int ndone, int grid, hipStream_t s);
 hipError_t launch_conv_dma(ConvArgs a, hipStream_t s, int variant);   // LDS-DMA ring (yolo_conv_dma.hip)
 hipError_t launch_conv_dma2(ConvArgs a, hipStream_t s, int variant);  // lean-address 32x32 MFMA ring (yolo_conv_dma2.hip)
 hipError_t launch_conv_small(ConvArgs a, hipStream_t s, int variant); // 3x3, Cin 32/64, whole K resident (yolo_conv_small.hip)

@@ -7,9 +7,9 @@ import torch
 _HERE = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 # ADAYOLO_LIB: another BUILD of the same library (measurement builds of tools/build_variant.py); never a fallback
 LIB_PATH = os.environ.get("ADAYOLO_LIB") or os.path.join(_HERE, "csrc", "libadayolo.so")
-ABI_VERSION = 7
+ABI_VERSION = 8
 ACT_NONE, ACT_SILU = 0, 1
-EXPORTS = ("adayolo_conv_fwd", "adayolo_conv_fwd_variant", "adayolo_conv_fused1x1_fwd", "adayolo_bottleneck256_fwd", "adayolo_conv_keep_fwd", "adayolo_conv_splitk_fwd", "adayolo_conv_dsilu_fwd", "adayolo_conv_s2grad_fwd", "adayolo_conv_splitk_workspace_bytes", "adayolo_stem_fwd", "adayolo_upsample2x", "adayolo_detect_decode", "adayolo_nms", "adayolo_nms_workspace_bytes", "adayolo_stem_fwd_act", "adayolo_stem_keep_fwd", "adayolo_stem_down_fwd", "adayolo_letterbox_pack", "adayolo_silu_fwd", "adayolo_silu_bwd",
+EXPORTS = ("adayolo_conv_fwd", "adayolo_conv_fwd_variant", "adayolo_conv_fused1x1_fwd", "adayolo_bottleneck256_fwd", "adayolo_conv_keep_fwd", "adayolo_conv_splitk_fwd", "adayolo_conv_dsilu_fwd", "adayolo_conv_s2grad_fwd", "adayolo_conv_splitk_workspace_bytes", "adayolo_conv_chain_workspace_bytes", "adayolo_conv_chain_prepare", "adayolo_conv_chain_fwd", "adayolo_conv_chain_status", "adayolo_conv_chain_tables", "adayolo_stem_fwd", "adayolo_upsample2x", "adayolo_detect_decode", "adayolo_nms", "adayolo_nms_workspace_bytes", "adayolo_stem_fwd_act", "adayolo_stem_keep_fwd", "adayolo_stem_down_fwd", "adayolo_letterbox_pack", "adayolo_silu_fwd", "adayolo_silu_bwd",
            "adayolo_zero_insert2x", "adayolo_upsample2x_bwd", "adayolo_image_grad", "adayolo_detloss_fwd", "adayolo_detloss_bwd",
            "adayolo_strerror",
            "adayolo_abi_version")
@@ -25,6 +25,14 @@ class LossLayer(ctypes.Structure):                 # adayolo_loss_layer (include
                 ("balance", ctypes.c_float), ("idx", ctypes.c_void_p), ("box", ctypes.c_void_p), ("n", ctypes.c_int),
                 ("part", ctypes.c_void_p), ("tobj", ctypes.c_void_p), ("cnt", ctypes.c_void_p),
                 ("grad", ctypes.c_void_p), ("grad_cs", ctypes.c_int)]
+
+
+class ChainLayer(ctypes.Structure):                # adayolo_chain_layer
+    _fields_ = [("in_", ctypes.c_void_p), ("in_cstride", ctypes.c_int), ("weight", ctypes.c_void_p), ("bias", ctypes.c_void_p),
+                ("residual", ctypes.c_void_p), ("res_cstride", ctypes.c_int), ("out", ctypes.c_void_p), ("out_cstride", ctypes.c_int),
+                ("B", ctypes.c_int), ("H", ctypes.c_int), ("W", ctypes.c_int), ("Cin", ctypes.c_int), ("Cout", ctypes.c_int),
+                ("ksize", ctypes.c_int), ("stride", ctypes.c_int), ("act", ctypes.c_int), ("weight2", ctypes.c_void_p),
+                ("bias2", ctypes.c_void_p), ("out2", ctypes.c_void_p), ("out2_cstride", ctypes.c_int), ("Cout2", ctypes.c_int)]
 
 
 class LossArgs(ctypes.Structure):                  # adayolo_loss_args
@@ -86,6 +94,16 @@ def load():
     L.adayolo_conv_dsilu_fwd.restype = ci
     L.adayolo_conv_s2grad_fwd.argtypes = [vp, ci, vp, vp, vp, ci, vp, ci, vp, ci, vp, ci, ci, ci, ci, ci, ci, ci, vp, ctypes.c_size_t, vp]
     L.adayolo_conv_s2grad_fwd.restype = ci
+    L.adayolo_conv_chain_workspace_bytes.argtypes = [ctypes.POINTER(ChainLayer), ci]
+    L.adayolo_conv_chain_workspace_bytes.restype = ctypes.c_size_t
+    L.adayolo_conv_chain_prepare.argtypes = [ctypes.POINTER(ChainLayer), ci, vp, ctypes.c_size_t]
+    L.adayolo_conv_chain_prepare.restype = ci
+    L.adayolo_conv_chain_fwd.argtypes = [ctypes.POINTER(ChainLayer), ci, vp, ctypes.c_size_t, vp]
+    L.adayolo_conv_chain_fwd.restype = ci
+    L.adayolo_conv_chain_tables.argtypes = [ctypes.POINTER(ChainLayer), ci, vp, ctypes.c_size_t, ctypes.POINTER(ctypes.c_int32)]
+    L.adayolo_conv_chain_tables.restype = ci
+    L.adayolo_conv_chain_status.argtypes = [vp]
+    L.adayolo_conv_chain_status.restype = ci
     L.adayolo_nms_workspace_bytes.argtypes = [ci]
     L.adayolo_nms_workspace_bytes.restype = ctypes.c_size_t
     L.adayolo_strerror.argtypes = [ci]

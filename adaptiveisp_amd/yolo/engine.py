@@ -399,7 +399,68 @@ class YoloEngine:
             i += 1
         self.plan = out
         self.fused_pairs += n
+        self.fuse_chains()
         return n
+
+    CHAIN_MIN = 2                                        # launches a run must replace to become a chain
+
+    def fuse_chains(self):
+        """Runs of consecutive launches of the 256 x 256 kernel (variant 50, alone or with the next block's 1x1 fused: the whole
+        C = 256 stage of the backbone, the 92 x 160 head blocks, ...) as ONE persistent launch each (adayolo_conv_chain_fwd,
+        csrc/yolo_conv_pp.hip: k_conv_chain): tiles of all the run's layers drawn from one work counter, a tile waiting only for
+        the producer tiles its input window / residual rows lie in. Bit-identical to the separate launches (same tile code).
+        ADAYOLO_CHAIN=0 keeps the launches separate. Returns the number of chains."""
+        self.chains = getattr(self, "chains", [])
+        if os.environ.get("ADAYOLO_CHAIN", "1") != "1":
+            return 0
+        P, out, i, made = self.plan, [], 0, 0
+        first_free = 3 if self._head_next is not None else 2
+
+        def eligible(j):
+            kind, _, a = P[j]
+            if j < first_free:
+                return False
+            if kind == "conv2":
+                return True
+            return kind == "conv" and a[16] == 50 and a[11] % 64 == 0 and a[12] % 256 == 0
+
+        while i < len(P):
+            j = i
+            while j < len(P) and eligible(j):
+                j += 1
+            if j - i >= self.CHAIN_MIN:
+                n = j - i
+                layers = (_lib.ChainLayer * n)()
+                flops = 0.0
+                for k in range(n):
+                    kind, _, a = P[i + k]
+                    ly = layers[k]
+                    ly.in_, ly.in_cstride, ly.weight, ly.bias = a[0], a[1], a[2], a[3]
+                    ly.residual, ly.res_cstride, ly.out, ly.out_cstride = a[4], a[5], a[6], a[7]
+                    ly.B, ly.H, ly.W, ly.Cin, ly.Cout, ly.ksize, ly.stride, ly.act = a[8:16]
+                    Ho, Wo = (a[9] - 1) // a[14] + 1, (a[10] - 1) // a[14] + 1
+                    flops += 2.0 * a[8] * Ho * Wo * a[12] * a[13] * a[13] * a[11]
+                    if kind == "conv2":
+                        ly.weight2, ly.bias2, ly.out2, ly.out2_cstride, ly.Cout2 = a[16], a[17], a[18], a[19], a[20]
+                        flops += 2.0 * a[8] * Ho * Wo * a[12] * a[20]
+                nbytes = int(self.L.adayolo_conv_chain_workspace_bytes(layers, n))
+                if nbytes:
+                    ws = torch.empty((nbytes,), dtype=torch.uint8, device=self.dev)
+                    _lib.check(self.L.adayolo_conv_chain_prepare(layers, n, ctypes.c_void_p(ws.data_ptr()), nbytes), "adayolo_conv_chain_prepare")
+                    self._keep += [ws, layers]
+                    self.chains.append(dict(layers=n, flops=flops, ws=ws, first=i, entries=P[i:j]))
+                    out.append(("chain", self.L.adayolo_conv_chain_fwd, [layers, n, ctypes.c_void_p(ws.data_ptr()), nbytes]))
+                    made += 1
+                    i = j
+                    continue
+            out.extend(P[i:max(j, i + 1)])
+            i = max(j, i + 1)
+        self.plan = out
+        return made
+
+    def chain_status(self):
+        """0 when every dependency wait of every chain's last forward saw its counters arrive (blocks: a test hook)."""
+        return max([int(self.L.adayolo_conv_chain_status(ctypes.c_void_p(c["ws"].data_ptr()))) for c in getattr(self, "chains", [])] + [0])
 
     def fuse_bottlenecks(self):
         """A whole Bottleneck of the C = 256 stage — cv1 (1x1 256 -> 128 + SiLU) and cv2 (3x3 128 -> 256 + SiLU, + the block's

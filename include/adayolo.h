@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define ADAYOLO_ABI_VERSION 7
+#define ADAYOLO_ABI_VERSION 8
 
 #define ADAYOLO_ACT_NONE 0
 #define ADAYOLO_ACT_SILU 1
@@ -48,6 +48,42 @@ int adayolo_conv_fwd(const void* in, int in_cstride,
                      void* out, int out_cstride,
                      int B, int H, int W, int Cin, int Cout,
                      int ksize, int stride, int act, void* stream);
+
+/*
+ * A CHAIN of consecutive conv layers in ONE persistent launch (csrc/yolo_conv_pp.hip: k_conv_chain). Each layer is what
+ * adayolo_conv_fwd (weight2 == NULL) or adayolo_conv_fused1x1_fwd computes — Conv/Bottleneck of yolov3/models/common.py:45-59,
+ * 110-120 — on the 256 px x 256 ch kernel (Cin % 64 == 0, Cout % 256 == 0; fused: Cout == 256, Cout2 == 128, weight2
+ * fragment-major as below). One workgroup per CU draws 256 x 256 tiles of ALL the layers from a work counter in layer
+ * order; a tile waits, through per-m-tile arrival counters, for exactly the tiles of the producing layer that its input
+ * window and its residual rows lie in. The results are bit-identical to launching the layers one by one (same tile code);
+ * what is saved is the ramp / tail of every launch, the partly empty last round of every layer and the lock-step of the
+ * CUs' memory phases. Rules (ADAYOLO_ESHAPE otherwise): a layer's `in` / `residual` is either EXACTLY the `out` / `out2` of
+ * an earlier layer of the chain (same pointer and stride, M equal) or a tensor no layer of the chain writes (complete
+ * before the launch); no output overlaps any other tensor of the chain; every output tensor is < 2 GB; n <= 64.
+ *   workspace_bytes  size of the device workspace for this chain (0: not served)
+ *   prepare          builds the work-item tables in `workspace` (host work + one blocking copy: a SET-UP call, not
+ *                    capturable); again whenever the layer list changes
+ *   fwd              one forward of the chain on `stream` (a memset node + one kernel: capturable; no allocation, no sync)
+ *   status           (test hook, blocks) 0 = every wait of the last forward saw its counters arrive
+ */
+typedef struct adayolo_chain_layer {
+    const void* in; int in_cstride;
+    const void* weight; const float* bias;
+    const void* residual; int res_cstride;
+    void* out; int out_cstride;
+    int B, H, W, Cin, Cout, ksize, stride, act;
+    const void* weight2; const float* bias2; void* out2; int out2_cstride; int Cout2;     /* weight2 == NULL: not fused */
+} adayolo_chain_layer;
+size_t adayolo_conv_chain_workspace_bytes(const adayolo_chain_layer* layers, int n);
+int adayolo_conv_chain_prepare(const adayolo_chain_layer* layers, int n, void* workspace, size_t workspace_bytes);
+int adayolo_conv_chain_fwd(const adayolo_chain_layer* layers, int n, void* workspace, size_t workspace_bytes, void* stream);
+int adayolo_conv_chain_status(const void* workspace);
+/* The workspace image `prepare` uploads, written to HOST memory instead (no device needed: how the -m "not gpu" tests check the
+ * work-item order and every tile's dependency window). Layout: 64 bytes of counters (head, err), int done[ndone], then at the
+ * 64-byte-aligned offsets returned in info = {items, ndone, off_layers, off_items, off_deps, sizeof(layer record)}: the
+ * per-layer argument records, items {layer, tile, arrival counter, 0} and dependencies {in_lo, (in_n << 16) | in_need, res_lo,
+ * (res_n << 16) | res_need} (indices into done[]). */
+int adayolo_conv_chain_tables(const adayolo_chain_layer* layers, int n, void* host_image, size_t bytes, int32_t* info);
 
 /*
  * Two layers in one launch: Conv(Cin -> 256, k, stride) + bias + act (+ residual) -> `out`, and on that output tile, while

@@ -135,3 +135,86 @@ def test_detloss_argument_checks_without_gpu():
     assert L.adayolo_detloss_bwd(ctypes.byref(a), None) == -2  # no gradient map
     lay.grad, lay.grad_cs = p, 252                             # not a multiple of 8
     assert L.adayolo_detloss_bwd(ctypes.byref(a), None) == -2
+
+
+def test_chain_tables_without_gpu():
+    """adayolo_conv_chain_tables (the workspace image adayolo_conv_chain_prepare uploads) for a 4-layer chain with fake device
+    addresses: layer-major item order, one arrival counter per (layer, m-tile), and for EVERY tile the dependency window checked
+    against a brute-force model — the set of producer m-tiles that hold a pixel one of the tile's taps reads (3x3 halo across
+    image rows and image boundaries, stride 2 at the end) must be inside [in_lo, in_lo + in_n), and the residual rows' tile too."""
+    import ctypes
+    import numpy as np
+    from adaptiveisp_amd.yolo import _lib
+    L = _lib.load()
+    B, H, W = 3, 21, 13                                       # M = 819: 4 m-tiles, images straddle tiles
+    base = 0x10000000
+    MB = 1 << 24
+    x, w, b = base, base + 1 * MB, base + 2 * MB
+    x0, h0, x1, h1, x2, y = (base + k * MB for k in range(3, 9))
+    w2 = base + 10 * MB
+
+    def layer(inp, cin, res, out, cout, s, out2=None, Hi=H, Wi=W):
+        c = _lib.ChainLayer()
+        c.in_, c.in_cstride, c.weight, c.bias, c.residual, c.res_cstride = inp, cin, w, b, res, 256 if res else 0
+        c.out, c.out_cstride, c.B, c.H, c.W, c.Cin, c.Cout, c.ksize, c.stride, c.act = out, cout, B, Hi, Wi, cin, cout, 3, s, 1
+        if out2:
+            c.weight2, c.bias2, c.out2, c.out2_cstride, c.Cout2 = w2, b, out2, 128, 128
+        return c
+    specs = [layer(x, 64, None, x0, 256, 1, h0), layer(h0, 128, x0, x1, 256, 1, h1), layer(h1, 128, x1, x2, 256, 1),
+             layer(x2, 256, None, y, 512, 2)]
+    arr = (_lib.ChainLayer * 4)(*specs)
+    nbytes = L.adayolo_conv_chain_workspace_bytes(arr, 4)
+    assert nbytes > 0
+    img = np.zeros(nbytes, np.uint8)
+    info = (ctypes.c_int32 * 6)()
+    assert L.adayolo_conv_chain_tables(arr, 4, img.ctypes.data_as(ctypes.c_void_p), nbytes, info) == 0
+    total, ndone, off_layers, off_items, off_deps, _ = list(info)
+    M = B * H * W
+    mt = (M + 255) // 256
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    M3 = B * Ho * Wo
+    mt3 = (M3 + 255) // 256
+    assert total == 3 * mt + mt3 * 2 and ndone == 3 * mt + mt3
+    items = img[off_items:off_items + 16 * total].view(np.int32).reshape(total, 4)
+    deps = img[off_deps:off_deps + 16 * total].view(np.int32).reshape(total, 4)
+    assert (img[:64 + 4 * ndone] == 0).all()
+    # layer-major order, tiles ascending; counters: one per (layer, m-tile)
+    want_items = [(l, t, l * mt + t) for l in range(3) for t in range(mt)] + [(3, t, 3 * mt + t // 2) for t in range(mt3 * 2)]
+    assert [tuple(r[:3]) for r in items.tolist()] == want_items
+    src_in, src_res = [None, 0, 1, 2], [None, 0, 1, None]
+    for (l, lid, flag, _), (in_lo, inn, res_lo, rnn) in zip(items.tolist(), deps.tolist()):
+        s, (Hq, Wq, Mq) = (2, (Ho, Wo, M3)) if l == 3 else (1, (H, W, M))
+        m_tile = lid // (2 if l == 3 else 1)
+        need = set()
+        for m in range(m_tile * 256, min(m_tile * 256 + 256, Mq)):
+            bb, rem = divmod(m, Hq * Wq)
+            ho, wo = divmod(rem, Wq)
+            for kh in range(3):
+                for kw in range(3):
+                    hi, wi = ho * s - 1 + kh, wo * s - 1 + kw
+                    if 0 <= hi < H and 0 <= wi < W:
+                        need.add(((bb * H + hi) * W + wi) // 256)
+        if src_in[l] is None:
+            assert inn == 0
+        else:
+            n_in, need_in = inn >> 16, inn & 0xFFFF
+            lo = in_lo - src_in[l] * mt
+            assert need_in == 1 and 1 <= n_in <= 32 and 0 <= lo and lo + n_in <= mt
+            assert need <= set(range(lo, lo + n_in)), (l, lid, sorted(need), lo, n_in)
+            assert n_in <= len(need) + 2                     # a window, not "everything"
+        if src_res[l] is None:
+            assert rnn == 0
+        else:
+            assert res_lo == src_res[l] * mt + m_tile and rnn == (1 << 16) | 1
+    # an item only ever waits for counters of EARLIER layers (deadlock freedom of the hand-out order)
+    for (l, _, flag, _), (in_lo, inn, res_lo, rnn) in zip(items.tolist(), deps.tolist()):
+        if inn:
+            assert in_lo + (inn >> 16) <= l * mt
+        if rnn:
+            assert res_lo < l * mt
+    # argument checks
+    assert L.adayolo_conv_chain_fwd(arr, 4, None, 0, None) == -1
+    assert L.adayolo_conv_chain_prepare(arr, 4, None, 0) == -1
+    bad = (_lib.ChainLayer * 4)(*specs)
+    bad[2].out = x0                                           # writes what layer 1 reads
+    assert L.adayolo_conv_chain_workspace_bytes(bad, 4) == 0
