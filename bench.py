@@ -37,6 +37,15 @@ CONV_KERNEL_NAMES = {2: "dma::k_conv_igemm_dma<128,128,2,2,2>", 5: "dma2::k_conv
                      50: "pp::k_conv_pp<0, false>", 57: "pp::k_conv_chain", 58: "pp::k_conv_pp<0, true>", 59: "bnk::k_bneck<0>", 60: "pp128::k_conv_pp128<0, false>", 80: "pq::k_conv_pq<0, 4>", 85: "pq::k_conv_pq<0, 2>", 90: "ws::k_conv_ws<...>"}
 
 
+_T0 = time.perf_counter()
+
+
+def mark(what):
+    """Progress on stderr (never on stdout: that is the ONE JSON line): which phase a slow or hung run is in."""
+    if os.environ.get("RANK", "0") == "0":
+        print(f"[bench +{time.perf_counter() - _T0:6.1f}s] {what}", file=sys.stderr, flush=True)
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -59,6 +68,7 @@ def parse():
     ap.add_argument("--no-detail", action="store_true", help="skip the per-kernel roofline passes")
     ap.add_argument("--no-extras", action="store_true", help="skip the extra keys for BASELINE configs 3, 4, 5 (train_iteration, "
                     "eval_config3, config5: ~1 minute, outside the timed region)")
+    ap.add_argument("--cpu-probe", type=int, default=0, help=argparse.SUPPRESS)      # child of cpu_baseline (all-cores figure)
     ap.add_argument("--raw", action="store_true", help="start every step from a uint16 RGGB Bayer plane in HBM (adaisp_demosaic, "
                     "an extension: the reference's pipeline starts from RGB) instead of the fp32 RGB batch")
     return ap.parse_args()
@@ -551,6 +561,32 @@ def _timed(fn, repeats=3):
     return ts[0], ts[len(ts) // 2]
 
 
+ALL_CORES_LIMIT_S = 90
+
+
+def cpu_probe(a, threads):
+    """Child of cpu_baseline: the reference-faithful ISP step and the fp32 detector on ONE image with `threads` torch threads,
+    1 warm-up + 1 repeat each -> one JSON line. No GPU is touched."""
+    import numpy as np
+    from oracle import torch_ref
+    from adaptiveisp_amd.yolo import yolov3
+    torch.set_num_threads(threads)
+    sched = SCHEDULES[a.schedule]
+    rng = np.random.default_rng(1235)
+    x = torch.from_numpy((rng.random((1, 3, a.height, a.width)) ** 2.2 * 0.5).astype(np.float32))
+    params = [torch.from_numpy((rng.random((1, torch_ref.NUM_PARAMS[op])) * 0.8 + 0.6).astype(np.float32)) for op in range(10)]
+    params[4] = torch.full((1, 1), 0.2)
+    sel = torch.tensor([sched[2 % len(sched)]])
+    torch.manual_seed(1)
+    det = yolov3().eval()
+    Hp = (a.height + 31) // 32 * 32
+    boxed = torch.full((1, 3, Hp, a.width), 114 / 255)
+    with torch.no_grad():
+        sa, _ = _timed(lambda: torch_ref.policy_step(x, params, sel), repeats=1)
+        da, _ = _timed(lambda: det(boxed), repeats=1)
+    print(json.dumps({"threads": threads, "isp_step_s": sa, "detector_s": da}), flush=True)
+
+
 def cpu_baseline(a, sched):
     """The hot path on the host cores of this box, on a BOUNDED sample: ONE image of the batch. Three ISP figures, each
     1 warm-up + 3 repeats (min / median):
@@ -626,20 +662,27 @@ def cpu_baseline(a, sched):
         batch_check = {"error": f"{type(e).__name__}: {e}"}
     # BASELINE.md 3 says "all host cores": the same two timings once more with every hardware thread (1 warm-up + 1 repeat),
     # so that the 64-thread choice above is evidence in the line, not an assertion
+    # (in a CHILD process with a time limit: with more OpenMP threads than the box's CPU quota allows, every parallel region of
+    # the ~2000-op reference step degenerates into spin-waits — the probe then reports the limit instead of stalling the bench)
     all_cores = None
     if ncpu > threads:
+        import subprocess
+        mark(f"cpu_baseline: all-cores probe ({ncpu} threads, child process, {ALL_CORES_LIMIT_S} s limit)")
         try:
-            torch.set_num_threads(ncpu)
-            with torch.no_grad():
-                sa, _ = _timed(lambda: torch_ref.policy_step(x, params, sel), repeats=1)
-                da, _ = _timed(lambda: det(boxed), repeats=1)
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-probe", str(ncpu), "--height", str(a.height),
+                                "--width", str(a.width), "--schedule", a.schedule], capture_output=True, text=True,
+                               timeout=ALL_CORES_LIMIT_S, cwd=ROOT)
+            rec = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+            sa, da = rec["isp_step_s"], rec["detector_s"]
             all_cores = {"threads": ncpu, "isp_step_s": round(sa, 3), "detector_s": round(da, 3),
                          "images_per_sec": round(1.0 / (nsteps * sa + da), 4), "repeats": 1,
                          "vs_value": round((1.0 / (nsteps * sa + da)) / (1.0 / (isp_ref + d_med)), 3)}
+        except subprocess.TimeoutExpired:
+            all_cores = {"threads": ncpu, "timeout_s": ALL_CORES_LIMIT_S,
+                         "note": f"1 warm-up + 1 repeat of the reference step and the detector did not finish within the limit with {ncpu} "
+                                 f"threads (the {threads}-thread figure above takes ~{2 * (step_med + d_med):.0f} s for the same work)"}
         except Exception as e:                               # noqa: BLE001
             all_cores = {"error": f"{type(e).__name__}: {e}"}
-        finally:
-            torch.set_num_threads(threads)
     r3 = lambda v: round(v, 3)  # noqa: E731
     return {"all_cores": all_cores, "value": round(1.0 / (isp_ref + d_med), 4), "value_from": "medians", "value_min_times": round(1.0 / (nsteps * step_min + d_min), 4),
             "unit": "images/sec", "cores": threads, "kind": "port",
@@ -891,6 +934,7 @@ def run_extras(dev, line):
     for key, fn in (("train_iteration", extra_train_iteration), ("eval_config3", extra_eval_config3), ("config5", extra_config5),
                     ("batch16", extra_batch16), ("raw", extra_raw)):
         t0 = time.perf_counter()
+        mark(f"extra: {key}")
         try:
             line[key] = fn(dev)
         except Exception as e:                               # noqa: BLE001
@@ -944,6 +988,8 @@ def prepare_gpu_run(a, dev):
 
 def main():
     a = parse()
+    if a.cpu_probe:
+        return cpu_probe(a, a.cpu_probe)
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # `python bench.py --gpus N` (how the driver calls it): this process has not touched the GPU and never will — it
         # starts one rank per GPU under torch.distributed.run as a CHILD, relays rank 0's JSON line (inherited stdout) and
@@ -996,6 +1042,7 @@ def main():
     else:
         run, single_run, graphed, pipelined, engine, x0, sched, step = prepare_gpu_run(a, dev)
         Hp = engine.Hp
+    mark("workload built; warm-up")
     for _ in range(a.warmup):
         run()
     barrier()
@@ -1004,6 +1051,7 @@ def main():
         run()
     barrier()
     dt = time.perf_counter() - t0
+    mark(f"timed region done: {dt / a.steps * 1e3:.3f} ms per step")
     if dist is not None:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -1071,7 +1119,9 @@ def main():
             mprime()
             runner(); runner()
             torch.cuda.synchronize()
+        mark("per-kernel conv timing")
         d = time_conv_kernels(engine, x0, runner=runner)
+        mark("per-kernel conv timing done")
 
         at_baseline = (a.batch, a.height, a.width) == (8, 720, 1280)
 
@@ -1126,10 +1176,13 @@ def main():
                        "kernels": time_isp_kernels(x0, sched)}
     if rank == 0 and world == 1 and not dry and not a.no_extras and not a.no_detail and \
             (a.batch, a.height, a.width, a.schedule) == (8, 720, 1280, "mixed"):
+        mark("h2d")
         line["h2d"] = measure_h2d(a, dev, run, dt / a.steps * 1e3)
+        mark("extras")
         del run, single_run, step, engine, x0
         run_extras(dev, line)
     if rank == 0 and not a.no_cpu_baseline and world == 1:
+        mark("cpu_baseline")
         try:
             line["cpu_baseline"] = cpu_baseline(a, sched)
         except Exception as e:
@@ -1138,6 +1191,7 @@ def main():
         line["data"] = ("synthetic (DRY REHEARSAL: no device, the step is a host sleep; not a measurement)" if dry else
                         "synthetic (REHEARSAL: all ranks share one device; not a measurement)")
     if rank == 0:
+        mark("done")
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()
