@@ -331,11 +331,41 @@ __global__ __launch_bounds__(kThreads) void k_pointwise(const float* __restrict_
 #ifndef ISP_POOL_PIPE
 #define ISP_POOL_PIPE 0
 #endif
+// The walk's shape per op CLASS (round 5): "light" ops (a handful of VALU per value: E, G, W, CCM, Ct, BW, zero) have the
+// registers for the double-buffered walk — the loads of the next row group are in flight while this one is computed and stored
+// — the "heavy" ones (T, C: an LDS table look-up per value; S+: HSV round trip) need the occupancy more (round 4's measurement:
+// one form for all ops cost E / CCM 3-4 us or T / S+ 10-30). ISP_POOL_{ROWS,PIPE}_{LIGHT,HEAVY} override per class.
+#ifndef ISP_POOL_ROWS_LIGHT
+#define ISP_POOL_ROWS_LIGHT ISP_POOL_ROWS
+#endif
+#ifndef ISP_POOL_PIPE_LIGHT
+#define ISP_POOL_PIPE_LIGHT ISP_POOL_PIPE
+#endif
+#ifndef ISP_POOL_ROWS_HEAVY
+#define ISP_POOL_ROWS_HEAVY ISP_POOL_ROWS
+#endif
+#ifndef ISP_POOL_PIPE_HEAVY
+#define ISP_POOL_PIPE_HEAVY ISP_POOL_PIPE
+#endif
+#ifndef ISP_POOL_ROWS_MEDIUM
+#define ISP_POOL_ROWS_MEDIUM ISP_POOL_ROWS
+#endif
+#ifndef ISP_POOL_PIPE_MEDIUM
+#define ISP_POOL_PIPE_MEDIUM ISP_POOL_PIPE
+#endif
+template <class OP> struct PoolWalk { static constexpr int rows = ISP_POOL_ROWS_LIGHT; static constexpr bool pipe = ISP_POOL_PIPE_LIGHT != 0; };
+// (CCM holds 15 more registers than exposure — the three-row double buffer spills at the 128-register cap, two rows fit; contrast
+// spills in every double-buffered form and keeps the plain walk)
+template <> struct PoolWalk<OpCCM> { static constexpr int rows = ISP_POOL_ROWS_MEDIUM; static constexpr bool pipe = ISP_POOL_PIPE_MEDIUM != 0; };
+template <> struct PoolWalk<OpContrast> { static constexpr int rows = ISP_POOL_ROWS; static constexpr bool pipe = ISP_POOL_PIPE != 0; };
+template <> struct PoolWalk<OpTone> { static constexpr int rows = ISP_POOL_ROWS_HEAVY; static constexpr bool pipe = ISP_POOL_PIPE_HEAVY != 0; };
+template <> struct PoolWalk<OpColor> { static constexpr int rows = ISP_POOL_ROWS_HEAVY; static constexpr bool pipe = ISP_POOL_PIPE_HEAVY != 0; };
+template <> struct PoolWalk<OpSatPlus> { static constexpr int rows = ISP_POOL_ROWS_HEAVY; static constexpr bool pipe = ISP_POOL_PIPE_HEAVY != 0; };
 template <class OP>
 __device__ __forceinline__ void stream_pool(const OP& op, const float* __restrict__ in, float* __restrict__ out,
                                             int H, int W, int ys, int ye, int y_own_end,
                                             int x, bool active, const Clip clip, float4 (&acc)[3]) {
-    constexpr int R = ISP_POOL_ROWS;
+    constexpr int R = PoolWalk<OP>::rows;
     const long plane = (long)H * W;
     const int xs = active ? x : 0;                      // inactive lanes (beyond a ragged right edge) read a valid quad and drop it
     // the loads of the NEXT group of R rows are issued before the current group is computed and stored (two register sets,
@@ -370,24 +400,24 @@ __device__ __forceinline__ void stream_pool(const OP& op, const float* __restric
             }
         }
     };
-#if ISP_POOL_PIPE
-    float4 ra[R], ga[R], ba[R], rb[R], gb[R], bb[R];
-    load(ra, ga, ba, ys);
-    for (int y0 = ys; y0 < ye; y0 += 2 * R) {
-        if (y0 + R < ye) load(rb, gb, bb, y0 + R);
-        work(ra, ga, ba, y0);
-        if (y0 + R < ye) {
-            if (y0 + 2 * R < ye) load(ra, ga, ba, y0 + 2 * R);
-            work(rb, gb, bb, y0 + R);
+    if constexpr (PoolWalk<OP>::pipe) {
+        float4 ra[R], ga[R], ba[R], rb[R], gb[R], bb[R];
+        load(ra, ga, ba, ys);
+        for (int y0 = ys; y0 < ye; y0 += 2 * R) {
+            if (y0 + R < ye) load(rb, gb, bb, y0 + R);
+            work(ra, ga, ba, y0);
+            if (y0 + R < ye) {
+                if (y0 + 2 * R < ye) load(ra, ga, ba, y0 + 2 * R);
+                work(rb, gb, bb, y0 + R);
+            }
+        }
+    } else {
+        float4 r[R], g[R], b[R];
+        for (int y0 = ys; y0 < ye; y0 += R) {
+            load(r, g, b, y0);
+            work(r, g, b, y0);
         }
     }
-#else
-    float4 r[R], g[R], b[R];
-    for (int y0 = ys; y0 < ye; y0 += R) {
-        load(r, g, b, y0);
-        work(r, g, b, y0);
-    }
-#endif
 }
 
 // At most 8 waves per workgroup; rows wider than 2048 px give a wave a second 256-px strip (wave, wave + 8, ...).

@@ -288,7 +288,8 @@ int adayolo_conv_chain_fwd(const adayolo_chain_layer* layers, int n, void* works
     ChainArgs c;
     c.ws = static_cast<unsigned char*>(workspace);
     c.off_layers = (int)P.off_layers; c.off_heads = (int)P.off_heads; c.off_deps = (int)P.off_deps; c.total = (int)P.heads.size();
-    return launch_conv_chain(c, P.ndone, device_cus(), static_cast<hipStream_t>(stream)) == hipSuccess ? ADAYOLO_OK : ADAYOLO_ELAUNCH;
+    c.ndone = P.ndone;
+    return launch_conv_chain(c, device_cus(), static_cast<hipStream_t>(stream)) == hipSuccess ? ADAYOLO_OK : ADAYOLO_ELAUNCH;
 }
 
 int adayolo_conv_chain_status(const void* workspace) {

@@ -133,6 +133,7 @@ struct ChainCtx {
 typedef const __attribute__((address_space(4))) int* cint_p;          // constant address space: uniform loads are scalar loads
 __device__ __forceinline__ int* chain_head(const ChainArgs& c) { return reinterpret_cast<int*>(c.ws); }
 __device__ __forceinline__ int* chain_err(const ChainArgs& c) { return reinterpret_cast<int*>(c.ws) + 1; }
+__device__ __forceinline__ int* chain_exit(const ChainArgs& c) { return reinterpret_cast<int*>(c.ws) + 2; }
 __device__ __forceinline__ int* chain_done(const ChainArgs& c) { return reinterpret_cast<int*>(c.ws + 64); }
 __device__ __forceinline__ void chain_load4(const ChainArgs& c, int off, int item, int (&r)[4]) {
     cint_p q = (cint_p)((unsigned long long)c.ws + (unsigned)off + (unsigned long long)(unsigned)item * 16u);
@@ -699,6 +700,22 @@ __global__ __launch_bounds__(512) void k_conv_chain(const ChainArgs c) {
         barrier();
         if (tid == 0) __hip_atomic_fetch_add(chain_done(c) + cx.pending, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    // The counters are left ZERO for the next launch by the workgroup that leaves last (adayolo_conv_chain_prepare zeroes them
+    // once). Not a memset ahead of the launch: captured into a hipGraph, a memset node came out WITHOUT its dependency on the
+    // preceding nodes (round 5: the replayed chain ran beside the kernels in front of it). A workgroup's own arrivals are
+    // complete (vmcnt) before it signs off, so nothing can land on a counter after the last one has zeroed it.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) sched[2] = __hip_atomic_fetch_add(chain_exit(c), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (sched[2] == (int)gridDim.x - 1) {
+        int* done = chain_done(c);
+        for (int i = tid; i < c.ndone; i += 512) __hip_atomic_store(done + i, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid == 0) {
+            __hip_atomic_store(chain_head(c), 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(chain_exit(c), 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
 }
 
 template <int ABL, bool FUSE = false>
@@ -733,12 +750,10 @@ static hipError_t launch_chain(const ChainArgs& c, int grid, hipStream_t s) {
 
 }  // namespace pp
 
-// Persistent chain of 256 x 256-tile layers (k_conv_chain). The counters at the head of the workspace are zeroed here, on the
-// stream, ahead of the launch (a memset node under graph capture: replayed first, every replay).
-hipError_t launch_conv_chain(const ChainArgs& c, int ndone, int grid, hipStream_t s) {
-    if (!c.ws || c.total <= 0 || grid <= 0 || ndone < 0) return hipErrorInvalidValue;
-    hipError_t e = hipMemsetAsync(c.ws, 0, 64 + (size_t)ndone * sizeof(int), s);
-    if (e != hipSuccess) return e;
+// Persistent chain of 256 x 256-tile layers (k_conv_chain): ONE kernel node; the counters at the head of the workspace are zero
+// when it starts (adayolo_conv_chain_prepare, then every launch's last workgroup).
+hipError_t launch_conv_chain(const ChainArgs& c, int grid, hipStream_t s) {
+    if (!c.ws || c.total <= 0 || grid <= 0 || c.ndone < 0) return hipErrorInvalidValue;
     return pp::launch_chain(c, grid < c.total ? grid : c.total, s);
 }
 

@@ -95,7 +95,8 @@ __device__ __forceinline__ void bias_act_pack4(float a0, float a1, float a2, flo
 // ---- persistent chain (yolo_conv_pp.hip: k_conv_chain): several consecutive layers of the 256 x 256 kernel's tiles in ONE launch.
 // One work item = one tile of one layer; the tables are built on the host (yolo_api.hip: adayolo_conv_chain_prepare).
 // Workspace (device, caller-owned; the byte offsets are multiples of 64):
-//   [0, 64)            int head (next item to hand out), int err (!= 0: a bounded wait gave up: item + 1), padding
+//   [0, 64)            int head (next item to hand out), int err (!= 0: a bounded wait gave up: item + 1; sticky until the next
+//                      prepare), int exit (workgroups that have left), padding — head, exit and done[] are ZERO between launches
 //   [64, ...)          int done[ndone]: arrival counters, one per (layer, m-tile)
 //   [off_layers, ...)  ConvArgs[nlayers]
 //   [off_heads, ...)   ChainHead[total]   layer-major: an item only ever waits for items BEFORE it in this order
@@ -108,9 +109,9 @@ struct ChainDeps {                                 // done[lo .. lo + n) each >=
 };
 struct ChainArgs {
     unsigned char* ws;
-    int off_layers, off_heads, off_deps, total;
+    int off_layers, off_heads, off_deps, total, ndone;
 };
-hipError_t launch_conv_chain(const ChainArgs& c, int ndone, int grid, hipStream_t s);
+hipError_t launch_conv_chain(const ChainArgs& c, int grid, hipStream_t s);
 hipError_t launch_conv_dma(ConvArgs a, hipStream_t s, int variant);   // LDS-DMA ring (yolo_conv_dma.hip)
 hipError_t launch_conv_dma2(ConvArgs a, hipStream_t s, int variant);  // lean-address 32x32 MFMA ring (yolo_conv_dma2.hip)
 hipError_t launch_conv_small(ConvArgs a, hipStream_t s, int variant); // 3x3, Cin 32/64, whole K resident (yolo_conv_small.hip)

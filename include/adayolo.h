@@ -63,8 +63,9 @@ int adayolo_conv_fwd(const void* in, int in_cstride,
  *   workspace_bytes  size of the device workspace for this chain (0: not served)
  *   prepare          builds the work-item tables in `workspace` (host work + one blocking copy: a SET-UP call, not
  *                    capturable); again whenever the layer list changes
- *   fwd              one forward of the chain on `stream` (a memset node + one kernel: capturable; no allocation, no sync)
- *   status           (test hook, blocks) 0 = every wait of the last forward saw its counters arrive
+ *   fwd              one forward of the chain on `stream` (ONE kernel: capturable; no allocation, no sync). The counters in the
+ *                    workspace are zero between launches: `prepare` zeroes them, every launch's last workgroup leaves them zero
+ *   status           (test hook, blocks) 0 = every wait of every forward since `prepare` saw its counters arrive
  */
 typedef struct adayolo_chain_layer {
     const void* in; int in_cstride;
@@ -79,7 +80,7 @@ int adayolo_conv_chain_prepare(const adayolo_chain_layer* layers, int n, void* w
 int adayolo_conv_chain_fwd(const adayolo_chain_layer* layers, int n, void* workspace, size_t workspace_bytes, void* stream);
 int adayolo_conv_chain_status(const void* workspace);
 /* The workspace image `prepare` uploads, written to HOST memory instead (no device needed: how the -m "not gpu" tests check the
- * work-item order and every tile's dependency window). Layout: 64 bytes of counters (head, err), int done[ndone], then at the
+ * work-item order and every tile's dependency window). Layout: 64 bytes of counters (head, err, exit), int done[ndone], then at the
  * 64-byte-aligned offsets returned in info = {items, ndone, off_layers, off_items, off_deps, sizeof(layer record)}: the
  * per-layer argument records, items {layer, tile, arrival counter, 0} and dependencies {in_lo, (in_n << 16) | in_need, res_lo,
  * (res_n << 16) | res_need} (indices into done[]). */

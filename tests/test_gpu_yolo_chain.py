@@ -137,24 +137,57 @@ def test_chain_sees_fresh_data_when_the_input_changes():
             assert torch.equal(got, ref), (rep, i)
 
 
-def test_chain_under_uneven_load_and_graph_replay():
+def _check(net, run, want, tag):
+    torch.cuda.synchronize()
+    st = run.status()
+    head = run.keep[1][:64].view(torch.int32).tolist()
+    assert st == 0, (tag, st, head)
+    for i, (got, ref) in enumerate(zip(net.outputs(), want)):
+        assert torch.equal(got, ref), (tag, i, head)
+
+
+def test_chain_under_uneven_load():
     """A second stream keeps part of the chip busy with unrelated work of varying length while the chain runs (fewer resident
-    workgroups, uneven progress — the conditions under which a placement- or timing-dependent hand-off fails), eagerly and as a
-    replayed hipGraph (the counter reset is a memset node that must replay too)."""
+    workgroups, uneven progress — the conditions under which a placement- or timing-dependent hand-off fails)."""
+    net = _Net(8, 92, 160, 128, 5, seed=9)
+    net.run_separately()
+    torch.cuda.synchronize()
+    want = [t.clone() for t in net.outputs()]
+    run = net.chain()
+    side = torch.cuda.Stream()
+    junk = torch.randn(4096, 4096, device=DEV)
+    for rep in range(6):
+        net.poison()
+        torch.cuda.synchronize()
+        with torch.cuda.stream(side):
+            for _ in range(1 + rep % 3):
+                junk = torch.tanh(junk @ junk * 1e-3)
+        run()
+        _check(net, run, want, f"eager under load, rep {rep}")
+
+
+def test_chain_graph_replay():
+    """The chain as a replayed hipGraph: the counter reset is a memset node that must replay, ahead of the kernel, every time;
+    then the same under a loaded second stream, alternating with eager launches."""
     net = _Net(8, 92, 160, 128, 5, seed=9)
     net.run_separately()
     torch.cuda.synchronize()
     want = [t.clone() for t in net.outputs()]
     run = net.chain()
     run()
-    torch.cuda.synchronize()
-    side = torch.cuda.Stream()
-    junk = torch.randn(4096, 4096, device=DEV)
+    _check(net, run, want, "eager warm-up")
     g = torch.cuda.CUDAGraph()
     with torch.cuda.graph(g):
         run()
+    for rep in range(4):
+        net.poison()
+        g.replay()
+        _check(net, run, want, f"replay, idle chip, rep {rep}")
+    side = torch.cuda.Stream()
+    junk = torch.randn(4096, 4096, device=DEV)
     for rep in range(6):
         net.poison()
+        torch.cuda.synchronize()
         with torch.cuda.stream(side):
             for _ in range(1 + rep % 3):
                 junk = torch.tanh(junk @ junk * 1e-3)
@@ -162,10 +195,34 @@ def test_chain_under_uneven_load_and_graph_replay():
             g.replay()
         else:
             run()
+        _check(net, run, want, f"{'replay' if rep % 2 else 'eager'} under load, rep {rep}")
+
+
+def test_chain_in_a_graph_is_ordered_behind_its_producers():
+    """[copy a new input into the chain's input tensor; the chain] captured into ONE graph: every replay must see the input the
+    copy node of THAT replay wrote (round 5: with the counter reset as a memset node in front of the kernel, the captured chain
+    lost its dependency on the nodes before it and ran beside them — results of the PREVIOUS replay's input)."""
+    net = _Net(4, 46, 80, 128, 3, seed=21)
+    src = torch.empty_like(net.x)
+    run = net.chain()
+    src.copy_(_bf(*net.x.shape, seed=300))
+    net.x.copy_(src)
+    run()
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        net.x.copy_(src)
+        run()
+    for rep in range(5):
+        src.copy_(_bf(*net.x.shape, seed=301 + rep))
+        net.x.copy_(src)
+        net.run_separately()
         torch.cuda.synchronize()
-        assert run.status() == 0
-        for i, (got, ref) in enumerate(zip(net.outputs(), want)):
-            assert torch.equal(got, ref), (rep, i)
+        want = [t.clone() for t in net.outputs()]
+        net.poison()
+        net.x.fill_(0)
+        g.replay()
+        _check(net, run, want, f"graph [copy, chain], rep {rep}")
 
 
 def test_chain_refuses_what_it_does_not_serve():
