@@ -54,7 +54,16 @@ __device__ unsigned long long g_stamp[4096 * 8];     // ABL 7: per-workgroup s_m
 #else
 __device__ unsigned long long g_stamp[8];
 #endif
+#ifdef ADAYOLO_CHAIN_STAMPS
+// measurement build of the persistent chain: thread 0 adds the cycles since its previous stamp to slot k of 16 LDS accumulators
+// (behind the scheduler words); the kernel adds them to g_chain_acc[slot] / counts tiles when the workgroup leaves
+__device__ unsigned long long g_chain_acc[16];
+#define PP_STAMP(k) do { if (ABL == 7 && threadIdx.x == 0 && blockIdx.x < 4096) g_stamp[blockIdx.x * 8 + (k)] = __builtin_readcyclecounter(); \
+                         if (CHAIN && threadIdx.x == 0) { unsigned long long* acc_ = reinterpret_cast<unsigned long long*>(smem + kSchedOff + 16); \
+                             const unsigned long long now_ = __builtin_readcyclecounter(); acc_[(k)] += now_ - acc_[15]; acc_[15] = now_; } } while (0)
+#else
 #define PP_STAMP(k) do { if (ABL == 7 && threadIdx.x == 0 && blockIdx.x < 4096) g_stamp[blockIdx.x * 8 + (k)] = __builtin_readcyclecounter(); } while (0)
+#endif
 
 __device__ __forceinline__ float bf16_to_f32(unsigned short h) { return __uint_as_float(((unsigned)h) << 16); }
 __device__ __forceinline__ unsigned short f32_to_bf16(float f) {
@@ -122,7 +131,11 @@ struct KPos {
 // One work item = one 256 x 256 tile of one layer. Host-built (yolo_conv_pp.hip::launch_conv_chain's caller, yolo_api.hip):
 // which arrival counters of the PRODUCING layers an item's input window / residual tile needs, and which counter it bumps.
 constexpr int kSchedOff = (kEpi > 2 * kBuf ? kEpi : 2 * kBuf) + BN * 4;    // int[4]: {next item, its inputs are ready, -, -}
+#ifdef ADAYOLO_CHAIN_STAMPS
+constexpr int kSmemChain = kSchedOff + 16 + 128;
+#else
 constexpr int kSmemChain = kSchedOff + 16;
+#endif
 constexpr unsigned kSpinLimit = 1u << 19;                                  // ~1 s of polling before a wait gives up
 
 // what a tile needs from the chain it runs in (CHAIN == false: unused)
@@ -618,8 +631,10 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int lid, unsi
         if (ABL == 7) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); PP_STAMP(7); }
     }
     if (CHAIN) {
+        PP_STAMP(8);                                         // (chain stamps: 6/5 -> here = the tile's last stores issued)
         sched_stage(3);
         barrier();                                           // the tile's LDS is free; {next item, ready} is in place
+        PP_STAMP(9);
     }
 }
 
@@ -649,7 +664,18 @@ __global__ __launch_bounds__(512) void k_conv_chain(const ChainArgs c) {
     __syncthreads();
     int item = __builtin_amdgcn_readfirstlane(sched[0]), ready = 0;
     ChainCtx cx{&c, -1};
+#ifdef ADAYOLO_CHAIN_STAMPS
+    constexpr bool CHAIN = true; constexpr int ABL = 0;
+    if (tid == 0) {
+        unsigned long long* acc_ = reinterpret_cast<unsigned long long*>(smem + kSchedOff + 16);
+        for (int i = 0; i < 15; ++i) acc_[i] = 0;
+        acc_[15] = __builtin_readcyclecounter();
+    }
+#endif
     while (item < c.total) {
+#ifdef ADAYOLO_CHAIN_STAMPS
+        if (tid == 0) reinterpret_cast<unsigned long long*>(smem + kSchedOff + 16)[14] += 1;      // tiles
+#endif
         int hd[4];
         chain_load4(c, c.off_heads, item, hd);               // {layer, tile, arrival counter, -}
         if (!ready) {
@@ -689,6 +715,9 @@ __global__ __launch_bounds__(512) void k_conv_chain(const ChainArgs c) {
             for (int i = 0; i < (int)(sizeof(ConvArgs) / 4); ++i) w[i] = q[i];
             __builtin_memcpy(&a, w, sizeof(ConvArgs));
         }
+#ifdef ADAYOLO_CHAIN_STAMPS
+        PP_STAMP(10);                                        // loop top: item record, slow path, layer arguments
+#endif
         if (a.w2) conv_tile<0, true, true>(a, hd[1], smem, cx);
         else conv_tile<0, false, true>(a, hd[1], smem, cx);
         cx.pending = hd[2];
@@ -704,6 +733,12 @@ __global__ __launch_bounds__(512) void k_conv_chain(const ChainArgs c) {
     // once). Not a memset ahead of the launch: captured into a hipGraph, a memset node came out WITHOUT its dependency on the
     // preceding nodes (round 5: the replayed chain ran beside the kernels in front of it). A workgroup's own arrivals are
     // complete (vmcnt) before it signs off, so nothing can land on a counter after the last one has zeroed it.
+#ifdef ADAYOLO_CHAIN_STAMPS
+    if (tid == 0) {
+        const unsigned long long* acc_ = reinterpret_cast<const unsigned long long*>(smem + kSchedOff + 16);
+        for (int i = 0; i < 15; ++i) atomicAdd(&g_chain_acc[i], acc_[i]);
+    }
+#endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid == 0) sched[2] = __hip_atomic_fetch_add(chain_exit(c), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -782,6 +817,15 @@ hipError_t launch_conv_pp(ConvArgs a, hipStream_t s, int variant) {
     }
     return pp::launch<0>(a, s);
 }
+
+#ifdef ADAYOLO_CHAIN_STAMPS
+// measurement helper (not part of the ABI): reads and clears the chain kernels' phase accumulators
+extern "C" int adayolo_debug_chain_stamps(unsigned long long* dst) {
+    unsigned long long z[16] = {0};
+    if (hipMemcpyFromSymbol(dst, HIP_SYMBOL(pp::g_chain_acc), sizeof(z)) != hipSuccess) return -1;
+    return hipMemcpyToSymbol(HIP_SYMBOL(pp::g_chain_acc), z, sizeof(z)) == hipSuccess ? 0 : -1;
+}
+#endif
 
 #ifdef ADAYOLO_MEASURE
 // measurement helper (not part of the ABI): copies the stamps of the last variant-57 launch
