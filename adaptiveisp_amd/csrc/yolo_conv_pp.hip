@@ -59,7 +59,7 @@ __device__ unsigned long long g_stamp[8];
 // (behind the scheduler words); the kernel adds them to g_chain_acc[slot] / counts tiles when the workgroup leaves
 __device__ unsigned long long g_chain_acc[16];
 #define PP_STAMP(k) do { if (ABL == 7 && threadIdx.x == 0 && blockIdx.x < 4096) g_stamp[blockIdx.x * 8 + (k)] = __builtin_readcyclecounter(); \
-                         if (CHAIN && threadIdx.x == 0) { unsigned long long* acc_ = reinterpret_cast<unsigned long long*>(smem + kSchedOff + 16); \
+                         if (CHAIN && threadIdx.x == 0) { unsigned long long* acc_ = reinterpret_cast<unsigned long long*>(smem + kSchedOff + 32); \
                              const unsigned long long now_ = __builtin_readcyclecounter(); acc_[(k)] += now_ - acc_[15]; acc_[15] = now_; } } while (0)
 #else
 #define PP_STAMP(k) do { if (ABL == 7 && threadIdx.x == 0 && blockIdx.x < 4096) g_stamp[blockIdx.x * 8 + (k)] = __builtin_readcyclecounter(); } while (0)
@@ -130,11 +130,11 @@ struct KPos {
 // ---- persistent chain (k_conv_chain below): several consecutive layers of this kernel's tiles in ONE launch ------------------
 // One work item = one 256 x 256 tile of one layer. Host-built (yolo_conv_pp.hip::launch_conv_chain's caller, yolo_api.hip):
 // which arrival counters of the PRODUCING layers an item's input window / residual tile needs, and which counter it bumps.
-constexpr int kSchedOff = (kEpi > 2 * kBuf ? kEpi : 2 * kBuf) + BN * 4;    // int[4]: {next item, its inputs are ready, -, -}
+constexpr int kSchedOff = (kEpi > 2 * kBuf ? kEpi : 2 * kBuf) + BN * 4;    // int[8]: {next item, its inputs are ready, layer, tile, arrival counter, exit ticket, -, -}
 #ifdef ADAYOLO_CHAIN_STAMPS
-constexpr int kSmemChain = kSchedOff + 16 + 128;
+constexpr int kSmemChain = kSchedOff + 32 + 128;
 #else
-constexpr int kSmemChain = kSchedOff + 16;
+constexpr int kSmemChain = kSchedOff + 32;
 #endif
 constexpr unsigned kSpinLimit = 1u << 19;                                  // ~1 s of polling before a wait gives up
 
@@ -435,7 +435,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int lid, unsi
     //                       to the workgroup through LDS. Not arrived (rare: the producers are ~200 items ahead): the slow
     //                       path at the top of the next tile polls.
     int nx_item = 0x7fffffff, nx_val = 0x7fffffff;
-    int nx_deps[4] = {0, 0, 0, 0};
+    int nx_deps[4] = {0, 0, 0, 0}, nx_head[4] = {0, 0, 0, 0};
     auto sched_stage = [&](int stage) {
         if (!CHAIN) return;
         if (wave != 0) return;
@@ -446,7 +446,10 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int lid, unsi
             nx_item = t;
         } else if (stage == 1) {
             nx_item = __builtin_amdgcn_readfirstlane(nx_item);
-            if (nx_item < c.total) chain_load4(c, c.off_deps, nx_item, nx_deps);          // scalar load: four SGPRs
+            if (nx_item < c.total) {                                                      // scalar loads: eight SGPRs
+                chain_load4(c, c.off_deps, nx_item, nx_deps);
+                chain_load4(c, c.off_heads, nx_item, nx_head);
+            }
         } else if (stage == 2) {
             if (nx_item < c.total) nx_val = chain_counter(c, nx_deps, lane);
         } else {
@@ -455,7 +458,10 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int lid, unsi
                 asm volatile("buffer_inv sc1" ::: "memory");
                 ready = 1;
             }
-            if (lane == 0) *reinterpret_cast<int2*>(smem + kSchedOff) = int2{nx_item, ready};
+            if (lane == 0) {
+                *reinterpret_cast<int4*>(smem + kSchedOff) = int4{nx_item, ready, nx_head[0], nx_head[1]};
+                *reinterpret_cast<int*>(smem + kSchedOff + 16) = nx_head[2];
+            }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
     };
@@ -664,20 +670,24 @@ __global__ __launch_bounds__(512) void k_conv_chain(const ChainArgs c) {
     __syncthreads();
     int item = __builtin_amdgcn_readfirstlane(sched[0]), ready = 0;
     ChainCtx cx{&c, -1};
+    // {layer, tile, arrival counter} of the item: read here for a workgroup's first item, handed over through LDS by the
+    // look-ahead afterwards; the layer's arguments stay in their SGPRs while consecutive items belong to the same layer
+    int hd[4] = {0, 0, 0, 0};
+    if (item < c.total) chain_load4(c, c.off_heads, item, hd);
+    ConvArgs a;
+    int cur_layer = -1;
 #ifdef ADAYOLO_CHAIN_STAMPS
     constexpr bool CHAIN = true; constexpr int ABL = 0;
     if (tid == 0) {
-        unsigned long long* acc_ = reinterpret_cast<unsigned long long*>(smem + kSchedOff + 16);
+        unsigned long long* acc_ = reinterpret_cast<unsigned long long*>(smem + kSchedOff + 32);
         for (int i = 0; i < 15; ++i) acc_[i] = 0;
         acc_[15] = __builtin_readcyclecounter();
     }
 #endif
     while (item < c.total) {
 #ifdef ADAYOLO_CHAIN_STAMPS
-        if (tid == 0) reinterpret_cast<unsigned long long*>(smem + kSchedOff + 16)[14] += 1;      // tiles
+        if (tid == 0) reinterpret_cast<unsigned long long*>(smem + kSchedOff + 32)[14] += 1;      // tiles
 #endif
-        int hd[4];
-        chain_load4(c, c.off_heads, item, hd);               // {layer, tile, arrival counter, -}
         if (!ready) {
             // slow path (a workgroup's first item, or the look-ahead found a counter short): publish what this workgroup still
             // holds back — a waiting workgroup must not sit on a finished tile others may need — then poll, bounded
@@ -707,8 +717,8 @@ __global__ __launch_bounds__(512) void k_conv_chain(const ChainArgs c) {
             __syncthreads();
         }
         // the layer's arguments through the scalar path (uniform index, constant table): SGPRs, as kernel arguments would be
-        ConvArgs a;
-        {
+        if (hd[0] != cur_layer) {
+            cur_layer = hd[0];
             cint_p q = (cint_p)((unsigned long long)c.ws + (unsigned)c.off_layers + (unsigned long long)(unsigned)hd[0] * sizeof(ConvArgs));
             int w[sizeof(ConvArgs) / 4];
 #pragma unroll
@@ -723,6 +733,9 @@ __global__ __launch_bounds__(512) void k_conv_chain(const ChainArgs c) {
         cx.pending = hd[2];
         item = __builtin_amdgcn_readfirstlane(sched[0]);
         ready = __builtin_amdgcn_readfirstlane(sched[1]);
+        hd[0] = __builtin_amdgcn_readfirstlane(sched[2]);
+        hd[1] = __builtin_amdgcn_readfirstlane(sched[3]);
+        hd[2] = __builtin_amdgcn_readfirstlane(sched[4]);
     }
     if (cx.pending >= 0) {
         wait_vm<0>();
@@ -735,15 +748,15 @@ __global__ __launch_bounds__(512) void k_conv_chain(const ChainArgs c) {
     // complete (vmcnt) before it signs off, so nothing can land on a counter after the last one has zeroed it.
 #ifdef ADAYOLO_CHAIN_STAMPS
     if (tid == 0) {
-        const unsigned long long* acc_ = reinterpret_cast<const unsigned long long*>(smem + kSchedOff + 16);
+        const unsigned long long* acc_ = reinterpret_cast<const unsigned long long*>(smem + kSchedOff + 32);
         for (int i = 0; i < 15; ++i) atomicAdd(&g_chain_acc[i], acc_[i]);
     }
 #endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (tid == 0) sched[2] = __hip_atomic_fetch_add(chain_exit(c), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid == 0) sched[5] = __hip_atomic_fetch_add(chain_exit(c), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
-    if (sched[2] == (int)gridDim.x - 1) {
+    if (sched[5] == (int)gridDim.x - 1) {
         int* done = chain_done(c);
         for (int i = tid; i < c.ndone; i += 512) __hip_atomic_store(done + i, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (tid == 0) {
