@@ -1,6 +1,7 @@
 // C-ABI of libadayolo.so (include/adayolo.h): argument checks + launches. No allocation, no sync.
 #include "yolo_internal.h"
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -158,15 +159,19 @@ int chain_plan(const adayolo_chain_layer* L, int n, ChainPlan& P, bool tables) {
         const int rc = conv_args(a, d.in, d.in_cstride, d.weight, d.bias, d.residual, d.res_cstride, d.out, d.out_cstride, d.B, d.H,
                                  d.W, d.Cin, d.Cout, d.ksize, d.stride, d.act);
         if (rc != ADAYOLO_OK) return rc;
-        if (a.Cin % 64 || a.Cout % 256) return ADAYOLO_ESHAPE;
+        if (d.tile != 0 && d.tile != 1) return ADAYOLO_EINVAL;
+        const int bn = d.tile == 1 ? 128 : 256;
+        if (a.Cin % 64 || a.Cout % bn) return ADAYOLO_ESHAPE;
+        a.chain_tile = d.tile;
         if (d.weight2) {
+            if (d.tile != 0) return ADAYOLO_ESHAPE;
             if (!d.bias2 || !d.out2) return ADAYOLO_EINVAL;
             if (a.Cout != 256 || d.Cout2 != 128 || d.out2_cstride % 8 || d.out2_cstride < d.Cout2) return ADAYOLO_ESHAPE;
             a.w2 = static_cast<const unsigned short*>(d.weight2); a.bias2 = d.bias2;
             a.out2 = static_cast<unsigned short*>(d.out2); a.out2_cs = d.out2_cstride;
         }
         a.mtiles = (a.M + 255) / 256;
-        a.ntiles = a.Cout / 256;
+        a.ntiles = a.Cout / bn;
         // the written-through stores address their tensor with 32-bit byte offsets
         if ((long)a.M * a.out_cs * 2 >= 0x7FFFFFFFL || (a.out2 && (long)a.M * a.out2_cs * 2 >= 0x7FFFFFFFL)) return ADAYOLO_ESHAPE;
         s_in[l] = Span{(const char*)a.in, (const char*)a.in + (long)a.B * a.H * a.W * a.in_cs * 2};
@@ -213,9 +218,16 @@ int chain_plan(const adayolo_chain_layer* L, int n, ChainPlan& P, bool tables) {
             if (in_src[l] >= 0) {
                 const ConvArgs& p = P.layers[in_src[l]];
                 const int hw = a.Ho * a.Wo;
-                const int b0 = m0 / hw, ho0 = (m0 % hw) / a.Wo, b1 = m1 / hw, ho1 = (m1 % hw) / a.Wo;
-                const int r_lo = std::max(ho0 * a.stride - a.pad, 0), r_hi = std::min(ho1 * a.stride - a.pad + a.ks - 1, a.H - 1);
-                const long px_lo = ((long)b0 * a.H + r_lo) * a.W, px_hi = ((long)b1 * a.H + r_hi) * a.W + a.W - 1;
+                const int b0 = m0 / hw, ho0 = (m0 % hw) / a.Wo, wo0 = m0 % a.Wo, b1 = m1 / hw, ho1 = (m1 % hw) / a.Wo, wo1 = m1 % a.Wo;
+                // the lowest / highest input pixel (flat index) any tap of the tile reads: the first pixel's top-left tap and the
+                // last pixel's bottom-right tap — later output rows only reach further down, earlier ones further up — unless that
+                // tap's row is outside the image (clamped): then a neighbouring output row's taps on the border row may reach
+                // further along it, and the whole border row is taken
+                const int top = ho0 * a.stride - a.pad, bot = ho1 * a.stride - a.pad + a.ks - 1;
+                const int r_lo = std::max(top, 0), r_hi = std::min(bot, a.H - 1);
+                const int c_lo = top >= 0 ? std::max(wo0 * a.stride - a.pad, 0) : 0;
+                const int c_hi = bot <= a.H - 1 ? std::min(wo1 * a.stride - a.pad + a.ks - 1, a.W - 1) : a.W - 1;
+                const long px_lo = ((long)b0 * a.H + r_lo) * a.W + c_lo, px_hi = ((long)b1 * a.H + r_hi) * a.W + c_hi;
                 const int t_lo = (int)(px_lo / 256), t_hi = std::min((int)(px_hi / 256), p.mtiles - 1);
                 const int cnt = t_hi - t_lo + 1;
                 if (cnt < 1 || cnt > 32 || p.ntiles > 0xFFFF) return ADAYOLO_ESHAPE;
@@ -289,6 +301,8 @@ int adayolo_conv_chain_fwd(const adayolo_chain_layer* layers, int n, void* works
     c.ws = static_cast<unsigned char*>(workspace);
     c.off_layers = (int)P.off_layers; c.off_heads = (int)P.off_heads; c.off_deps = (int)P.off_deps; c.total = (int)P.heads.size();
     c.ndone = P.ndone;
+    static const int stagger = [] { const char* e = getenv("ADAYOLO_CHAIN_STAGGER"); return e ? atoi(e) : 0; }();
+    c.stagger = stagger;
     return launch_conv_chain(c, device_cus(), static_cast<hipStream_t>(stream)) == hipSuccess ? ADAYOLO_OK : ADAYOLO_ELAUNCH;
 }
 

@@ -28,6 +28,7 @@
 // (w+4)-th, a scalar compare + branch per slot) instead of all behind the 1st and the 4th: 78 vs 70 us — the extra states between
 // MFMAs cost more than the texture-address queue they were meant to spare.
 #include "yolo_internal.h"
+#include "yolo_chain.h"
 #include <type_traits>
 #include <cstdlib>
 #ifdef ADAYOLO_PLAIN_STORES   // A/B switch (measurement): keep the output lines in the XCD L2 instead of streaming them
@@ -56,10 +57,9 @@ __device__ unsigned long long g_stamp[8];
 #endif
 #ifdef ADAYOLO_CHAIN_STAMPS
 // measurement build of the persistent chain: thread 0 adds the cycles since its previous stamp to slot k of 16 LDS accumulators
-// (behind the scheduler words); the kernel adds them to g_chain_acc[slot] / counts tiles when the workgroup leaves
-__device__ unsigned long long g_chain_acc[16];
+// (behind the scheduler words); the chain kernel adds them to its global accumulators when the workgroup leaves
 #define PP_STAMP(k) do { if (ABL == 7 && threadIdx.x == 0 && blockIdx.x < 4096) g_stamp[blockIdx.x * 8 + (k)] = __builtin_readcyclecounter(); \
-                         if (CHAIN && threadIdx.x == 0) { unsigned long long* acc_ = reinterpret_cast<unsigned long long*>(smem + kSchedOff + 32); \
+                         if (CHAIN && threadIdx.x == 0) { unsigned long long* acc_ = reinterpret_cast<unsigned long long*>(smem + kChainSchedOff + 32); \
                              const unsigned long long now_ = __builtin_readcyclecounter(); acc_[(k)] += now_ - acc_[15]; acc_[15] = now_; } } while (0)
 #else
 #define PP_STAMP(k) do { if (ABL == 7 && threadIdx.x == 0 && blockIdx.x < 4096) g_stamp[blockIdx.x * 8 + (k)] = __builtin_readcyclecounter(); } while (0)
@@ -127,43 +127,6 @@ struct KPos {
 // operand is read from the tile (pitch 144 B:
 // conflict-free ds_read_b128) — and writes it through its own region again. The second layer sees exactly the bf16 values
 // the unfused kernel would read back from memory.
-// ---- persistent chain (k_conv_chain below): several consecutive layers of this kernel's tiles in ONE launch ------------------
-// One work item = one 256 x 256 tile of one layer. Host-built (yolo_conv_pp.hip::launch_conv_chain's caller, yolo_api.hip):
-// which arrival counters of the PRODUCING layers an item's input window / residual tile needs, and which counter it bumps.
-constexpr int kSchedOff = (kEpi > 2 * kBuf ? kEpi : 2 * kBuf) + BN * 4;    // int[8]: {next item, its inputs are ready, layer, tile, arrival counter, exit ticket, -, -}
-#ifdef ADAYOLO_CHAIN_STAMPS
-constexpr int kSmemChain = kSchedOff + 32 + 128;
-#else
-constexpr int kSmemChain = kSchedOff + 32;
-#endif
-constexpr unsigned kSpinLimit = 1u << 19;                                  // ~1 s of polling before a wait gives up
-
-// what a tile needs from the chain it runs in (CHAIN == false: unused)
-struct ChainCtx {
-    const ChainArgs* c;
-    int pending;                 // done[] index of the previous tile of this workgroup whose arrival is not yet published, or -1
-};
-typedef const __attribute__((address_space(4))) int* cint_p;          // constant address space: uniform loads are scalar loads
-__device__ __forceinline__ int* chain_head(const ChainArgs& c) { return reinterpret_cast<int*>(c.ws); }
-__device__ __forceinline__ int* chain_err(const ChainArgs& c) { return reinterpret_cast<int*>(c.ws) + 1; }
-__device__ __forceinline__ int* chain_exit(const ChainArgs& c) { return reinterpret_cast<int*>(c.ws) + 2; }
-__device__ __forceinline__ int* chain_done(const ChainArgs& c) { return reinterpret_cast<int*>(c.ws + 64); }
-__device__ __forceinline__ void chain_load4(const ChainArgs& c, int off, int item, int (&r)[4]) {
-    cint_p q = (cint_p)((unsigned long long)c.ws + (unsigned)off + (unsigned long long)(unsigned)item * 16u);
-    r[0] = q[0]; r[1] = q[1]; r[2] = q[2]; r[3] = q[3];
-}
-// lane l < 32: done[in_lo + l], lane 32 + l: done[res_lo + l] -> this lane's counter has arrived (lanes without one: true)
-__device__ __forceinline__ int chain_counter(const ChainArgs& c, const int (&d)[4], int lane) {
-    const int l = lane & 31;
-    const bool act = lane < 32 ? l < (d[1] >> 16) : l < (d[3] >> 16);
-    int v = 0x7fffffff;
-    if (act) v = __hip_atomic_load(chain_done(c) + (lane < 32 ? d[0] : d[2]) + l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return v;
-}
-__device__ __forceinline__ bool chain_arrived(const int (&d)[4], int v, int lane) {
-    return __all(v >= ((lane < 32 ? d[1] : d[3]) & 0xFFFF));
-}
-
 // One 256 x 256 tile. CHAIN: `lid` is handed in, output stores are written through (sc1) and this workgroup's previous tile is
 // published once they are known complete; wave 0 fetches the next item and checks its inputs in the shadow of the epilogue.
 template <int ABL, bool FUSE, bool CHAIN>
@@ -185,6 +148,11 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int lid, unsi
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 2, wn = wave & 3;           // wm is also the ping-pong group
     const int m0 = (lid / a.ntiles) * BM, n0 = (lid % a.ntiles) * BN;
+    // CHAIN: wave 0 looks ahead while the tile runs (yolo_chain.h: ChainLook)
+    ChainLook look;
+    auto sched_stage = [&](int stage) {
+        if (CHAIN && wave == 0) look.stage(stage, *cx.c, smem + kChainSchedOff, lane);
+    };
     const unsigned long long zaddr = (unsigned long long)(const void*)g_zero16;
 
     // ---- per-row DMA state: one DMA instruction moves 8 tile rows (64 lanes x 16 B); a half-tile is 16 of them,
@@ -315,8 +283,8 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int lid, unsi
         // behind the barrier: every wave has drained)
         wait_vm<0>();
         barrier();
-        if (cx.pending >= 0 && tid == 0) __hip_atomic_fetch_add(chain_done(*cx.c) + cx.pending, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        cx.pending = -1;
+        chain_publish(cx, tid);
+        sched_stage(0);
     } else {
         wait_vm<4>();                                    // k-tile 0 landed (this wave's share)
         barrier();
@@ -424,47 +392,6 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int lid, unsi
     //      (Storing 8/16-byte pieces straight from the fragment layout was measured 2x slower: 32 rows x 32 B per
     //      instruction instead of 8 rows x 128 B.)
     unsigned char* my = smem + wave * (128 * kEpiPitch);
-    // CHAIN: wave 0 looks ahead while the epilogue runs — four stages, each consuming what the previous one requested a few
-    // microseconds earlier (three dependent round trips: work counter -> item record -> arrival counters), so that the next
-    // tile starts without waiting for any of them:
-    //   0 (epilogue start)  lane 0 draws the next item from the work counter
-    //   1                   the item's record is requested
-    //   2                   the arrival counters its input window / residual tile wait for are requested
-    //   3 (last stores out) all arrived -> ONE buffer_inv sc1 (this CU's L1 may hold lines of those tensors from an earlier
-    //                       forward; the counters have been observed, so the invalidate is the acquire) and {item, ready} go
-    //                       to the workgroup through LDS. Not arrived (rare: the producers are ~200 items ahead): the slow
-    //                       path at the top of the next tile polls.
-    int nx_item = 0x7fffffff, nx_val = 0x7fffffff;
-    int nx_deps[4] = {0, 0, 0, 0}, nx_head[4] = {0, 0, 0, 0};
-    auto sched_stage = [&](int stage) {
-        if (!CHAIN) return;
-        if (wave != 0) return;
-        const ChainArgs& c = *cx.c;
-        if (stage == 0) {
-            int t = 0;
-            if (lane == 0) t = __hip_atomic_fetch_add(chain_head(c), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            nx_item = t;
-        } else if (stage == 1) {
-            nx_item = __builtin_amdgcn_readfirstlane(nx_item);
-            if (nx_item < c.total) {                                                      // scalar loads: eight SGPRs
-                chain_load4(c, c.off_deps, nx_item, nx_deps);
-                chain_load4(c, c.off_heads, nx_item, nx_head);
-            }
-        } else if (stage == 2) {
-            if (nx_item < c.total) nx_val = chain_counter(c, nx_deps, lane);
-        } else {
-            int ready = 0;
-            if (nx_item < c.total && chain_arrived(nx_deps, nx_val, lane)) {
-                asm volatile("buffer_inv sc1" ::: "memory");
-                ready = 1;
-            }
-            if (lane == 0) {
-                *reinterpret_cast<int4*>(smem + kSchedOff) = int4{nx_item, ready, nx_head[0], nx_head[1]};
-                *reinterpret_cast<int*>(smem + kSchedOff + 16) = nx_head[2];
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        }
-    };
     // CHAIN: the tile's outputs leave as 16-byte WRITE-THROUGH (sc1) buffer stores — complete, for every other CU and XCD, once
     // the storing wave's vmcnt reaches 0 (no release fence, i.e. no whole-L2 write-back); byte offsets are 32-bit (the caller
     // checks the tensors are < 2 GB)
@@ -499,7 +426,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int lid, unsi
         const int obyte = CHAIN ? (int)(((long)mrow * a.out_cs + n) * 2) : 0;
 #pragma unroll
         for (int mi = 0; mi < 4; ++mi) {
-            if (mi < 3) sched_stage(mi);                         // (stage 3 follows the tile's last stores)
+            if (mi == 1 || mi == 2) sched_stage(mi);             // (stage 0: behind the prologue; 3: after the tile's last stores)
             u32x4 v[4], r[4];
             bool ok[4];
 #pragma unroll
@@ -639,6 +566,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int lid, unsi
     if (CHAIN) {
         PP_STAMP(8);                                         // (chain stamps: 6/5 -> here = the tile's last stores issued)
         sched_stage(3);
+        PP_STAMP(11);
         barrier();                                           // the tile's LDS is free; {next item, ready} is in place
         PP_STAMP(9);
     }
@@ -651,121 +579,7 @@ __global__ __launch_bounds__(512) void k_conv_pp(const ConvArgs a) {
     conv_tile<ABL, FUSE, false>(a, xcd_remap(blockIdx.x, a.mtiles * a.ntiles), smem, none);
 }
 
-// Persistent form: one workgroup per CU draws tiles of SEVERAL consecutive layers from one work counter (layer-major order)
-// until none is left. What a launch per layer costs and this does not: the ramp and tail of every launch (~4 us x layers), the
-// 80 - 90 % full last round of every layer (460 tiles on 256 CUs), and every CU being in the same phase at the same time — the
-// workgroups drift apart, so one CU's prologue / residual / store bursts meet other CUs' k-loops instead of 255 other bursts.
-// Dependencies: a tile waits for the m-tiles of the producing layer its input window and its residual rows lie in (arrival
-// counters, bumped when a tile's written-through stores are complete). It only ever waits for items that come before it in
-// the hand-out order, and those are held by workgroups that are running: no deadlock whatever number of workgroups is resident.
-__global__ __launch_bounds__(512) void k_conv_chain(const ChainArgs c) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    int* sched = reinterpret_cast<int*>(smem + kSchedOff);
-    if (tid == 0) {
-        sched[0] = __hip_atomic_fetch_add(chain_head(c), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        sched[1] = 0;
-    }
-    __syncthreads();
-    int item = __builtin_amdgcn_readfirstlane(sched[0]), ready = 0;
-    ChainCtx cx{&c, -1};
-    // {layer, tile, arrival counter} of the item: read here for a workgroup's first item, handed over through LDS by the
-    // look-ahead afterwards; the layer's arguments stay in their SGPRs while consecutive items belong to the same layer
-    int hd[4] = {0, 0, 0, 0};
-    if (item < c.total) chain_load4(c, c.off_heads, item, hd);
-    ConvArgs a;
-    int cur_layer = -1;
-#ifdef ADAYOLO_CHAIN_STAMPS
-    constexpr bool CHAIN = true; constexpr int ABL = 0;
-    if (tid == 0) {
-        unsigned long long* acc_ = reinterpret_cast<unsigned long long*>(smem + kSchedOff + 32);
-        for (int i = 0; i < 15; ++i) acc_[i] = 0;
-        acc_[15] = __builtin_readcyclecounter();
-    }
-#endif
-    while (item < c.total) {
-#ifdef ADAYOLO_CHAIN_STAMPS
-        if (tid == 0) reinterpret_cast<unsigned long long*>(smem + kSchedOff + 32)[14] += 1;      // tiles
-#endif
-        if (!ready) {
-            // slow path (a workgroup's first item, or the look-ahead found a counter short): publish what this workgroup still
-            // holds back — a waiting workgroup must not sit on a finished tile others may need — then poll, bounded
-            if (cx.pending >= 0) {
-                wait_vm<0>();
-                barrier();
-                if (tid == 0) __hip_atomic_fetch_add(chain_done(c) + cx.pending, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                cx.pending = -1;
-            }
-            if (wave == 0) {
-                int d[4];
-                chain_load4(c, c.off_deps, item, d);
-                // bounded: a wait that gives up records its item; once ANY wait of the launch has given up no other one spins (the
-                // launch then finishes within one limit, wrong — adayolo_conv_chain_status tells)
-                unsigned spins = 0;
-                while (!chain_arrived(d, chain_counter(c, d, lane), lane)) {
-                    const int e = __hip_atomic_load(chain_err(c), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (e != 0) break;
-                    if (++spins > kSpinLimit) {
-                        if (lane == 0) __hip_atomic_store(chain_err(c), item + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        break;
-                    }
-                    __builtin_amdgcn_s_sleep(32);
-                }
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            }
-            __syncthreads();
-        }
-        // the layer's arguments through the scalar path (uniform index, constant table): SGPRs, as kernel arguments would be
-        if (hd[0] != cur_layer) {
-            cur_layer = hd[0];
-            cint_p q = (cint_p)((unsigned long long)c.ws + (unsigned)c.off_layers + (unsigned long long)(unsigned)hd[0] * sizeof(ConvArgs));
-            int w[sizeof(ConvArgs) / 4];
-#pragma unroll
-            for (int i = 0; i < (int)(sizeof(ConvArgs) / 4); ++i) w[i] = q[i];
-            __builtin_memcpy(&a, w, sizeof(ConvArgs));
-        }
-#ifdef ADAYOLO_CHAIN_STAMPS
-        PP_STAMP(10);                                        // loop top: item record, slow path, layer arguments
-#endif
-        if (a.w2) conv_tile<0, true, true>(a, hd[1], smem, cx);
-        else conv_tile<0, false, true>(a, hd[1], smem, cx);
-        cx.pending = hd[2];
-        item = __builtin_amdgcn_readfirstlane(sched[0]);
-        ready = __builtin_amdgcn_readfirstlane(sched[1]);
-        hd[0] = __builtin_amdgcn_readfirstlane(sched[2]);
-        hd[1] = __builtin_amdgcn_readfirstlane(sched[3]);
-        hd[2] = __builtin_amdgcn_readfirstlane(sched[4]);
-    }
-    if (cx.pending >= 0) {
-        wait_vm<0>();
-        barrier();
-        if (tid == 0) __hip_atomic_fetch_add(chain_done(c) + cx.pending, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    // The counters are left ZERO for the next launch by the workgroup that leaves last (adayolo_conv_chain_prepare zeroes them
-    // once). Not a memset ahead of the launch: captured into a hipGraph, a memset node came out WITHOUT its dependency on the
-    // preceding nodes (round 5: the replayed chain ran beside the kernels in front of it). A workgroup's own arrivals are
-    // complete (vmcnt) before it signs off, so nothing can land on a counter after the last one has zeroed it.
-#ifdef ADAYOLO_CHAIN_STAMPS
-    if (tid == 0) {
-        const unsigned long long* acc_ = reinterpret_cast<const unsigned long long*>(smem + kSchedOff + 32);
-        for (int i = 0; i < 15; ++i) atomicAdd(&g_chain_acc[i], acc_[i]);
-    }
-#endif
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (tid == 0) sched[5] = __hip_atomic_fetch_add(chain_exit(c), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __syncthreads();
-    if (sched[5] == (int)gridDim.x - 1) {
-        int* done = chain_done(c);
-        for (int i = tid; i < c.ndone; i += 512) __hip_atomic_store(done + i, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (tid == 0) {
-            __hip_atomic_store(chain_head(c), 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(chain_exit(c), 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    }
-}
-
+#ifndef ADAYOLO_TILE_ONLY
 template <int ABL, bool FUSE = false>
 static hipError_t launch(ConvArgs a, hipStream_t s) {
     static_assert(kSmem <= 160 * 1024, "LDS budget");
@@ -783,27 +597,11 @@ static hipError_t launch(ConvArgs a, hipStream_t s) {
     return hipGetLastError();
 }
 
-static hipError_t launch_chain(const ChainArgs& c, int grid, hipStream_t s) {
-    static_assert(kSmemChain <= 160 * 1024, "LDS budget");
-    static bool configured = false;
-    if (!configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv_chain), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           kSmemChain);
-        if (e != hipSuccess) return e;
-        configured = true;
-    }
-    hipLaunchKernelGGL(k_conv_chain, dim3(grid), dim3(512), kSmemChain, s, c);
-    return hipGetLastError();
-}
+#endif  // ADAYOLO_TILE_ONLY
 
 }  // namespace pp
 
-// Persistent chain of 256 x 256-tile layers (k_conv_chain): ONE kernel node; the counters at the head of the workspace are zero
-// when it starts (adayolo_conv_chain_prepare, then every launch's last workgroup).
-hipError_t launch_conv_chain(const ChainArgs& c, int grid, hipStream_t s) {
-    if (!c.ws || c.total <= 0 || grid <= 0 || c.ndone < 0) return hipErrorInvalidValue;
-    return pp::launch_chain(c, grid < c.total ? grid : c.total, s);
-}
+#ifndef ADAYOLO_TILE_ONLY
 
 // variant 50 = the kernel; with -DADAYOLO_MEASURE 51..57 = the measurement builds (ABL above). hipErrorInvalidValue ->
 // the shape is not served (the caller falls back to the default kernel).
@@ -831,20 +629,13 @@ hipError_t launch_conv_pp(ConvArgs a, hipStream_t s, int variant) {
     return pp::launch<0>(a, s);
 }
 
-#ifdef ADAYOLO_CHAIN_STAMPS
-// measurement helper (not part of the ABI): reads and clears the chain kernels' phase accumulators
-extern "C" int adayolo_debug_chain_stamps(unsigned long long* dst) {
-    unsigned long long z[16] = {0};
-    if (hipMemcpyFromSymbol(dst, HIP_SYMBOL(pp::g_chain_acc), sizeof(z)) != hipSuccess) return -1;
-    return hipMemcpyToSymbol(HIP_SYMBOL(pp::g_chain_acc), z, sizeof(z)) == hipSuccess ? 0 : -1;
-}
-#endif
-
 #ifdef ADAYOLO_MEASURE
 // measurement helper (not part of the ABI): copies the stamps of the last variant-57 launch
 extern "C" int adayolo_debug_stamps(unsigned long long* dst, int n) {
     return hipMemcpyFromSymbol(dst, HIP_SYMBOL(pp::g_stamp), sizeof(unsigned long long) * n) == hipSuccess ? 0 : -1;
 }
 #endif
+
+#endif  // ADAYOLO_TILE_ONLY
 
 }  // namespace adayolo

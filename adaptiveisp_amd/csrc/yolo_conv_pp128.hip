@@ -25,6 +25,7 @@
 // wave ~150 cycles there, four waves at once). The barriers are not what holds this kernel; the operand stream is
 // (profiles/round2_conv_pp_ablation.txt).
 #include "yolo_internal.h"
+#include "yolo_chain.h"
 #include <type_traits>
 
 namespace adayolo {
@@ -96,18 +97,24 @@ struct KPos {                                 // wave-uniform position of a k-ti
 // ticket 97; with sc1 accesses instead 27.8, + the last workgroup's S x 128 KB read-back and epilogue 43).
 // Workgroup -> (tile, range) with the range varying fastest: the S workgroups of a tile are neighbours on one XCD
 // (2-4 us better than tile-fastest).
-template <int ABL, bool SPLIT>
-__global__ __launch_bounds__(512) void k_conv_pp128(const ConvArgs a) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+// CHAIN (yolo_chain.h): the tile is a work item of the persistent chain kernel — `gid` is handed in, the outputs leave as
+// written-through stores, the previous tile of the workgroup is published behind the prologue, wave 0 looks ahead.
+template <int ABL, bool SPLIT, bool CHAIN>
+__device__ __forceinline__ void conv_tile(const ConvArgs& a, const int gid, unsigned char* smem, ChainCtx& cx) {
+    static_assert(!(SPLIT && CHAIN), "the chain runs whole tiles");
     float* bias_s = reinterpret_cast<float*>(smem + kRing);
     int* ticket_s = reinterpret_cast<int*>(smem + kRing + BN * 4);
 
-    const int tid = threadIdx.x, lane = tid & 63;
+    int tid_ = threadIdx.x;
+    if (CHAIN) asm volatile("" : "+v"(tid_));            // (nothing derived from the thread index is hoisted out of the chain's loop)
+    const int tid = tid_, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave & 3, wn = wave >> 2;             // wn is also the ping-pong group
-    const int ntile = a.mtiles * a.ntiles;
-    const int gid = xcd_remap(blockIdx.x, SPLIT ? ntile * a.ksplit : ntile);
     const int lid = SPLIT ? gid / a.ksplit : gid, kpart = SPLIT ? gid - lid * a.ksplit : 0;   // the ranges of a tile are neighbours
+    ChainLook look;
+    auto sched_stage = [&](int stage) {
+        if (CHAIN && wave == 0) look.stage(stage, *cx.c, smem + kChainSchedOff, lane);
+    };
     const int m0 = (lid / a.ntiles) * BM, n0 = (lid % a.ntiles) * BN;
     const unsigned long long zaddr = (unsigned long long)(const void*)g_zero16;
 
@@ -199,8 +206,15 @@ __global__ __launch_bounds__(512) void k_conv_pp128(const ConvArgs a) {
     stage_w1(1, smem + kBuf, q1, 1 < nK);
     stage_w1(0, smem + 2 * kBuf, q2, 2 < nK);
     stage_a(smem + 2 * kBuf, q2, 2 < nK);
-    wait_vm<10>();                                       // W0(0), A(0), W1(0), W0(1) landed (this wave's share)
-    barrier();
+    if (CHAIN) {
+        wait_vm<0>();                                    // ... and the previous tile's written-through stores are complete
+        barrier();
+        chain_publish(cx, tid);
+        sched_stage(0);
+    } else {
+        wait_vm<10>();                                   // W0(0), A(0), W1(0), W0(1) landed (this wave's share)
+        barrier();
+    }
 
     f32x16 acc[2][2];                                    // [channel frag][pixel frag]
 #pragma unroll
@@ -370,6 +384,8 @@ __global__ __launch_bounds__(512) void k_conv_pp128(const ConvArgs a) {
 
     // ---- epilogue: wave-private LDS transpose (see yolo_conv_pp.hip), 32 px x 64 ch at a time, 128-byte row segments
     unsigned char* my = smem + wave * (64 * kEpiPitch);
+    __amdgpu_buffer_rsrc_t rs_out;                       // CHAIN: written-through (sc1) stores, 32-bit byte offsets
+    if (CHAIN) rs_out = __builtin_amdgcn_make_buffer_rsrc((void*)a.out, 0, 0x7FFFFFFF, 0x00020000);
     // see yolo_conv_pp.hip: compile-time activation / residual copies, bias and pointers hoisted, batched reads and stores
     auto epilogue = [&](auto silu_tag, auto res_tag, auto keep_tag, auto ds_tag, auto d2s_tag) {
         // kKeep: the tile goes through LDS as the bf16 PRE-activation (kSilu off), is stored to a.pre, then activated
@@ -392,8 +408,10 @@ __global__ __launch_bounds__(512) void k_conv_pp128(const ConvArgs a) {
         const long ostep = 8L * a.out_cs, rstep = kRes ? 8L * a.res_cs : 0;
         unsigned char* const wr = my + (lane & 31) * kEpiPitch + 8 * (lane >> 5);
         const unsigned char* const rd = my + r0 * kEpiPitch + chunk * 16;
+        const int obyte = CHAIN ? (int)(((long)mrow * a.out_cs + n) * 2) : 0;
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi) {
+            sched_stage(mi + 1);                                 // CHAIN look-ahead: records, then arrival counters
             u32x4 v[4], r[4];
             bool ok[4];
 #pragma unroll
@@ -471,14 +489,19 @@ __global__ __launch_bounds__(512) void k_conv_pp128(const ConvArgs a) {
             }
 #pragma unroll
             for (int it = 0; it < 4; ++it)
-                if (ok[it])
-                    __builtin_nontemporal_store(v[it], reinterpret_cast<u32x4*>(kD2s ? a.out + px[it] * a.out_cs + nn
-                                                                                     : op + (4 * mi + it) * ostep));
+                if (ok[it]) {
+                    if (CHAIN) __builtin_amdgcn_raw_buffer_store_b128(v[it], rs_out, obyte + (4 * mi + it) * (int)(2 * ostep), 0, 16);
+                    else __builtin_nontemporal_store(v[it], reinterpret_cast<u32x4*>(kD2s ? a.out + px[it] * a.out_cs + nn
+                                                                                          : op + (4 * mi + it) * ostep));
+                }
         }
     };
     const std::false_type no{};
     const std::true_type yes{};
-    if (a.d2s_c) {                                       // stride-2 data gradient (act none, no kept pre-activation)
+    if constexpr (CHAIN) {                               // the chain runs the plain forward forms only (yolo_api.hip checks)
+        if (a.act == ADAYOLO_ACT_SILU) { if (a.res) epilogue(yes, yes, no, no, no); else epilogue(yes, no, no, no, no); }
+        else { if (a.res) epilogue(no, yes, no, no, no); else epilogue(no, no, no, no, no); }
+    } else if (a.d2s_c) {                                // stride-2 data gradient (act none, no kept pre-activation)
         if (a.gpre) { if (a.res) epilogue(no, yes, no, yes, yes); else epilogue(no, no, no, yes, yes); }
         else { if (a.res) epilogue(no, yes, no, no, yes); else epilogue(no, no, no, no, yes); }
     } else if (a.gpre) {
@@ -491,7 +514,21 @@ __global__ __launch_bounds__(512) void k_conv_pp128(const ConvArgs a) {
     } else {
         if (a.res) epilogue(no, yes, no, no, no); else epilogue(no, no, no, no, no);
     }
+    if (CHAIN) {
+        sched_stage(3);
+        barrier();                                       // the tile's LDS is free; {next item, ready, ...} is in place
+    }
 }
+
+template <int ABL, bool SPLIT>
+__global__ __launch_bounds__(512) void k_conv_pp128(const ConvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    ChainCtx none{nullptr, -1};
+    const int ntile = a.mtiles * a.ntiles;
+    conv_tile<ABL, SPLIT, false>(a, xcd_remap(blockIdx.x, SPLIT ? ntile * a.ksplit : ntile), smem, none);
+}
+
+#ifndef ADAYOLO_TILE_ONLY
 
 template <int ABL, bool SPLIT = false>
 static hipError_t launch(ConvArgs a, hipStream_t s) {
@@ -510,7 +547,11 @@ static hipError_t launch(ConvArgs a, hipStream_t s) {
     return hipGetLastError();
 }
 
+#endif  // ADAYOLO_TILE_ONLY
+
 }  // namespace pp128
+
+#ifndef ADAYOLO_TILE_ONLY
 
 // Split-K form: S ranges of k-tiles per output tile. Served when the k-tiles divide evenly into ranges of at least
 // kMinRange, and the tile count leaves CUs free (otherwise the plain kernel is the better one anyway). Returns the bytes of
@@ -546,5 +587,7 @@ hipError_t launch_conv_pp128(ConvArgs a, hipStream_t s, int variant) {
     (void)variant;
     return pp128::launch<0>(a, s);
 }
+
+#endif  // ADAYOLO_TILE_ONLY
 
 }  // namespace adayolo

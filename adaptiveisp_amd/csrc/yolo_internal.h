@@ -35,6 +35,9 @@ struct ConvArgs {
     // are the four pixel parities of the (large) input-gradient tensor: d2s_c = C > 0 makes the epilogue address out / res /
     // pre / gpre depth-to-space — channel group p of pixel (b, i, j) is pixel (b, 2i + p/2, 2j + p%2) of [B, 2Ho, 2Wo, C]
     int d2s_c = 0;
+    // persistent chain (yolo_conv_chain.hip): which tile body runs this layer's items — 0: 256 x 256 (yolo_conv_pp.hip),
+    // 1: 256 x 128 (yolo_conv_pp128.hip)
+    int chain_tile = 0;
 };
 
 // (pixel, channel) of an epilogue element in the tensors it addresses: the identity, or the depth-to-space map above
@@ -110,6 +113,7 @@ struct ChainDeps {                                 // done[lo .. lo + n) each >=
 struct ChainArgs {
     unsigned char* ws;
     int off_layers, off_heads, off_deps, total, ndone;
+    int stagger;                 // cycles: workgroup b starts ((b >> 3) & 7) * stagger late (0: all at once). ADAYOLO_CHAIN_STAGGER
 };
 hipError_t launch_conv_chain(const ChainArgs& c, int grid, hipStream_t s);
 hipError_t launch_conv_dma(ConvArgs a, hipStream_t s, int variant);   // LDS-DMA ring (yolo_conv_dma.hip)

@@ -32,7 +32,8 @@ class ChainLayer(ctypes.Structure):                # adayolo_chain_layer
                 ("residual", ctypes.c_void_p), ("res_cstride", ctypes.c_int), ("out", ctypes.c_void_p), ("out_cstride", ctypes.c_int),
                 ("B", ctypes.c_int), ("H", ctypes.c_int), ("W", ctypes.c_int), ("Cin", ctypes.c_int), ("Cout", ctypes.c_int),
                 ("ksize", ctypes.c_int), ("stride", ctypes.c_int), ("act", ctypes.c_int), ("weight2", ctypes.c_void_p),
-                ("bias2", ctypes.c_void_p), ("out2", ctypes.c_void_p), ("out2_cstride", ctypes.c_int), ("Cout2", ctypes.c_int)]
+                ("bias2", ctypes.c_void_p), ("out2", ctypes.c_void_p), ("out2_cstride", ctypes.c_int), ("Cout2", ctypes.c_int),
+                ("tile", ctypes.c_int)]
 
 
 class LossArgs(ctypes.Structure):                  # adayolo_loss_args

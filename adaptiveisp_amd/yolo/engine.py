@@ -405,8 +405,9 @@ class YoloEngine:
     CHAIN_MIN = 2                                        # launches a run must replace to become a chain
 
     def fuse_chains(self):
-        """Runs of consecutive launches of the 256 x 256 kernel (variant 50, alone or with the next block's 1x1 fused: the whole
-        C = 256 stage of the backbone, the 92 x 160 head blocks, ...) as ONE persistent launch each (adayolo_conv_chain_fwd,
+        """Runs of consecutive launches of the 256 x 256 kernel (variant 50, alone or with the next block's 1x1 fused) and the
+        256 x 128 kernel (variant 60) — the backbone from its C = 256 stage through the C = 512 stage, the head's blocks — as ONE
+        persistent launch each (adayolo_conv_chain_fwd,
         csrc/yolo_conv_pp.hip: k_conv_chain): tiles of all the run's layers drawn from one work counter, a tile waiting only for
         the producer tiles its input window / residual rows lie in. Bit-identical to the separate launches (same tile code).
         ADAYOLO_CHAIN=0 keeps the launches separate. Returns the number of chains."""
@@ -422,7 +423,9 @@ class YoloEngine:
                 return False
             if kind == "conv2":
                 return True
-            return kind == "conv" and a[16] == 50 and a[11] % 64 == 0 and a[12] % 256 == 0
+            if kind != "conv" or a[11] % 64:
+                return False
+            return (a[16] == 50 and a[12] % 256 == 0) or (a[16] == 60 and a[12] % 128 == 0)
 
         while i < len(P):
             j = i
@@ -438,6 +441,7 @@ class YoloEngine:
                     ly.in_, ly.in_cstride, ly.weight, ly.bias = a[0], a[1], a[2], a[3]
                     ly.residual, ly.res_cstride, ly.out, ly.out_cstride = a[4], a[5], a[6], a[7]
                     ly.B, ly.H, ly.W, ly.Cin, ly.Cout, ly.ksize, ly.stride, ly.act = a[8:16]
+                    ly.tile = 1 if (kind == "conv" and a[16] == 60) else 0
                     Ho, Wo = (a[9] - 1) // a[14] + 1, (a[10] - 1) // a[14] + 1
                     flops += 2.0 * a[8] * Ho * Wo * a[12] * a[13] * a[13] * a[11]
                     if kind == "conv2":

@@ -52,9 +52,9 @@ int adayolo_conv_fwd(const void* in, int in_cstride,
 /*
  * A CHAIN of consecutive conv layers in ONE persistent launch (csrc/yolo_conv_pp.hip: k_conv_chain). Each layer is what
  * adayolo_conv_fwd (weight2 == NULL) or adayolo_conv_fused1x1_fwd computes — Conv/Bottleneck of yolov3/models/common.py:45-59,
- * 110-120 — on the 256 px x 256 ch kernel (Cin % 64 == 0, Cout % 256 == 0; fused: Cout == 256, Cout2 == 128, weight2
- * fragment-major as below). One workgroup per CU draws 256 x 256 tiles of ALL the layers from a work counter in layer
- * order; a tile waits, through per-m-tile arrival counters, for exactly the tiles of the producing layer that its input
+ * 110-120 — on the 256 px x 256 ch kernel (tile 0: Cin % 64 == 0, Cout % 256 == 0; fused: Cout == 256, Cout2 == 128, weight2
+ * fragment-major as below) or the 256 px x 128 ch kernel (tile 1: Cin % 64 == 0, Cout % 128 == 0, not fused). One workgroup per
+ * CU draws tiles of ALL the layers from a work counter in layer order; a tile waits, through per-m-tile arrival counters, for exactly the tiles of the producing layer that its input
  * window and its residual rows lie in. The results are bit-identical to launching the layers one by one (same tile code);
  * what is saved is the ramp / tail of every launch, the partly empty last round of every layer and the lock-step of the
  * CUs' memory phases. Rules (ADAYOLO_ESHAPE otherwise): a layer's `in` / `residual` is either EXACTLY the `out` / `out2` of
@@ -74,6 +74,8 @@ typedef struct adayolo_chain_layer {
     void* out; int out_cstride;
     int B, H, W, Cin, Cout, ksize, stride, act;
     const void* weight2; const float* bias2; void* out2; int out2_cstride; int Cout2;     /* weight2 == NULL: not fused */
+    int tile;       /* which kernel's tile runs the layer: 0 = 256 px x 256 ch (variant 50; the only one that fuses), 1 = 256 px x
+                       128 ch (variant 60: Cin % 64 == 0, Cout % 128 == 0) — the results are those kernels' bit for bit */
 } adayolo_chain_layer;
 size_t adayolo_conv_chain_workspace_bytes(const adayolo_chain_layer* layers, int n);
 int adayolo_conv_chain_prepare(const adayolo_chain_layer* layers, int n, void* workspace, size_t workspace_bytes);

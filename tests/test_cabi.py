@@ -218,3 +218,63 @@ def test_chain_tables_without_gpu():
     bad = (_lib.ChainLayer * 4)(*specs)
     bad[2].out = x0                                           # writes what layer 1 reads
     assert L.adayolo_conv_chain_workspace_bytes(bad, 4) == 0
+
+
+def test_chain_tables_mixed_tiles_without_gpu():
+    """A chain that mixes the two tile kinds, as the detector's C = 512 stage does: 3x3 128 -> 512 on 256 x 256 tiles (two n-tiles
+    per m-tile), Bottleneck.cv1 1x1 512 -> 256 on 256 x 128 tiles (two n-tiles), Bottleneck.cv2 3x3 256 -> 512 + shortcut on
+    256 x 256 tiles. Counters are per (layer, m-tile) and count n-tiles: a consumer needs ALL n-tiles of every producer m-tile
+    in its window (need = the producer's n-tile count); a 1x1 layer's window is its own pixels."""
+    import ctypes
+    import numpy as np
+    from adaptiveisp_amd.yolo import _lib
+    L = _lib.load()
+    B, H, W = 2, 19, 27                                       # M = 1026: 5 m-tiles, the last one 2 pixels
+    base, MB = 0x20000000, 1 << 24
+    x, w, b, y0, h, y1 = (base + k * MB for k in range(6))
+
+    def layer(inp, cin, res, out, cout, k, tile):
+        c = _lib.ChainLayer()
+        c.in_, c.in_cstride, c.weight, c.bias, c.residual, c.res_cstride = inp, cin, w, b, res, cout if res else 0
+        c.out, c.out_cstride, c.B, c.H, c.W, c.Cin, c.Cout, c.ksize, c.stride, c.act, c.tile = out, cout, B, H, W, cin, cout, k, 1, 1, tile
+        return c
+    specs = [layer(x, 128, None, y0, 512, 3, 0), layer(y0, 512, None, h, 256, 1, 1), layer(h, 256, y0, y1, 512, 3, 0)]
+    arr = (_lib.ChainLayer * 3)(*specs)
+    nbytes = L.adayolo_conv_chain_workspace_bytes(arr, 3)
+    assert nbytes > 0
+    img = np.zeros(nbytes, np.uint8)
+    info = (ctypes.c_int32 * 6)()
+    assert L.adayolo_conv_chain_tables(arr, 3, img.ctypes.data_as(ctypes.c_void_p), nbytes, info) == 0
+    total, ndone, off_layers, off_items, off_deps, _ = list(info)
+    mt = (B * H * W + 255) // 256
+    assert (total, ndone) == (mt * 2 * 3, mt * 3)
+    items = img[off_items:off_items + 16 * total].view(np.int32).reshape(total, 4).tolist()
+    deps = img[off_deps:off_deps + 16 * total].view(np.int32).reshape(total, 4).tolist()
+    assert [tuple(r[:3]) for r in items] == [(l, t, l * mt + t // 2) for l in range(3) for t in range(2 * mt)]
+    for (l, lid, flag, _), (in_lo, inn, res_lo, rnn) in zip(items, deps):
+        m_tile = lid // 2
+        if l == 0:
+            assert inn == 0 and rnn == 0
+            continue
+        n_in, need_in = inn >> 16, inn & 0xFFFF
+        assert need_in == 2                                   # both n-tiles of every producer m-tile
+        lo = in_lo - (l - 1) * mt
+        if l == 1:                                            # 1x1: exactly its own m-tile
+            assert (lo, n_in) == (m_tile, 1) and rnn == 0
+        else:
+            need = set()
+            for m in range(m_tile * 256, min(m_tile * 256 + 256, B * H * W)):
+                bb, rem = divmod(m, H * W)
+                ho, wo = divmod(rem, W)
+                need |= {((bb * H + hi) * W + wi) // 256 for hi in range(ho - 1, ho + 2) for wi in range(wo - 1, wo + 2)
+                         if 0 <= hi < H and 0 <= wi < W}
+            assert need <= set(range(lo, lo + n_in)) and n_in <= len(need) + 2
+            assert (res_lo, rnn) == (m_tile, (1 << 16) | 2)    # the shortcut: layer 0's m-tile, both its n-tiles
+    # a fused layer must be on the 256 x 256 tile; the 256 x 128 tile takes Cout % 128
+    bad = (_lib.ChainLayer * 3)(*specs)
+    bad[1].tile = 0                                           # Cout 256 on 256 x 256 tiles is fine ...
+    assert L.adayolo_conv_chain_workspace_bytes(bad, 3) > 0
+    bad[1].tile = 2
+    assert L.adayolo_conv_chain_workspace_bytes(bad, 3) == 0
+    bad[1].tile, bad[1].Cout, bad[1].out_cstride = 1, 192, 192
+    assert L.adayolo_conv_chain_workspace_bytes(bad, 3) == 0

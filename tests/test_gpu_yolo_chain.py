@@ -23,6 +23,15 @@ def _pack_w2(w2):                       # [128][256] -> fragment-major (include/
     return w2.reshape(4, 32, 16, 2, 8).permute(0, 2, 3, 1, 4).contiguous()
 
 
+def _check(net, run, want, tag):
+    torch.cuda.synchronize()
+    st = run.status()
+    head = run.keep[1][:64].view(torch.int32).tolist()
+    assert st == 0, (tag, st, head)
+    for i, (got, ref) in enumerate(zip(net.outputs(), want)):
+        assert torch.equal(got, ref), (tag, i, head)
+
+
 class _Net:
     """x -(3x3 s1 c0->256, +1x1)-> x0,h0 -(3x3 128->256 + x0, +1x1)-> x1,h1 ... -(3x3 128->256 + x_{n-1})-> x_n -(3x3 s2 256->512)-> y"""
 
@@ -63,12 +72,12 @@ class _Net:
         for ly in self.layers:
             Bq, Hq, Wq, _ = ly["inp"].shape
             common = (vp(ly["inp"].data_ptr()), ly["cin"], vp(ly["w"].data_ptr()), vp(ly["b"].data_ptr()),
-                      vp(ly["res"].data_ptr()) if ly["res"] is not None else None, 256 if ly["res"] is not None else 0,
+                      vp(ly["res"].data_ptr()) if ly["res"] is not None else None, ly["cout"] if ly["res"] is not None else 0,
                       vp(ly["out"].data_ptr()), ly["cout"], Bq, Hq, Wq, ly["cin"], ly["cout"], ly["k"], ly["s"], _lib.ACT_SILU)
             if "w2" in ly:
                 rc = L.adayolo_conv_fused1x1_fwd(*common, vp(ly["w2p"].data_ptr()), vp(ly["b2"].data_ptr()), vp(ly["out2"].data_ptr()), 128, 128, st)
             else:
-                rc = L.adayolo_conv_fwd_variant(*common, 50, st)
+                rc = L.adayolo_conv_fwd_variant(*common, 60 if ly.get("tile") else 50, st)
             _lib.check(rc, "separate launch")
 
     def chain(self):
@@ -79,9 +88,10 @@ class _Net:
         for c, ly in zip(arr, self.layers):
             Bq, Hq, Wq, _ = ly["inp"].shape
             c.in_, c.in_cstride, c.weight, c.bias = ly["inp"].data_ptr(), ly["cin"], ly["w"].data_ptr(), ly["b"].data_ptr()
-            c.residual, c.res_cstride = (ly["res"].data_ptr(), 256) if ly["res"] is not None else (None, 0)
+            c.residual, c.res_cstride = (ly["res"].data_ptr(), ly["cout"]) if ly["res"] is not None else (None, 0)
             c.out, c.out_cstride = ly["out"].data_ptr(), ly["cout"]
             c.B, c.H, c.W, c.Cin, c.Cout, c.ksize, c.stride, c.act = Bq, Hq, Wq, ly["cin"], ly["cout"], ly["k"], ly["s"], _lib.ACT_SILU
+            c.tile = ly.get("tile", 0)
             if "w2" in ly:
                 c.weight2, c.bias2, c.out2, c.out2_cstride, c.Cout2 = ly["w2p"].data_ptr(), ly["b2"].data_ptr(), ly["out2"].data_ptr(), 128, 128
         nbytes = int(L.adayolo_conv_chain_workspace_bytes(arr, n))
@@ -94,6 +104,31 @@ class _Net:
         run.status = lambda: int(L.adayolo_conv_chain_status(vp(ws.data_ptr())))
         run.keep = (arr, ws)
         return run
+
+
+class _Net512(_Net):
+    """The detector's C = 512 stage in small: x -(3x3 s2 c0->512, tile 0)-> y0, then blocks of
+    [1x1 512->256 (256 x 128 tile), 3x3 256->512 + shortcut (256 x 256 tile, two n-tiles)], then 3x3 s2 512->1024 on 256 x 128 tiles."""
+
+    def __init__(self, B, H, W, c0=256, blocks=2, seed=0):
+        self.B, self.H, self.W = B, H, W
+        self.x = _bf(B, H, W, c0, seed=seed)
+        Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+        rnd = lambda n, sd: torch.randn(n, generator=torch.Generator().manual_seed(sd)).to(DEV) * 0.1     # noqa: E731
+        mk = lambda shape: torch.empty(shape, dtype=torch.bfloat16, device=DEV)                            # noqa: E731
+        self.layers = [dict(inp=self.x, w=_bf(512, 3, 3, c0, seed=seed + 1, scale=(9 * c0) ** -0.5), b=rnd(512, seed + 2), res=None,
+                            out=mk((B, Ho, Wo, 512)), k=3, s=2, cin=c0, cout=512, tile=0)]
+        cur = self.layers[0]["out"]
+        for i in range(blocks):
+            hid = dict(inp=cur, w=_bf(256, 1, 1, 512, seed=seed + 10 + i, scale=512 ** -0.5), b=rnd(256, seed + 20 + i), res=None,
+                       out=mk((B, Ho, Wo, 256)), k=1, s=1, cin=512, cout=256, tile=1)
+            blk = dict(inp=hid["out"], w=_bf(512, 3, 3, 256, seed=seed + 30 + i, scale=(9 * 256) ** -0.5), b=rnd(512, seed + 40 + i),
+                       res=cur, out=mk((B, Ho, Wo, 512)), k=3, s=1, cin=256, cout=512, tile=0)
+            self.layers += [hid, blk]
+            cur = blk["out"]
+        H2, W2 = (Ho - 1) // 2 + 1, (Wo - 1) // 2 + 1
+        self.layers.append(dict(inp=cur, w=_bf(1024, 3, 3, 512, seed=seed + 60, scale=(9 * 512) ** -0.5), b=rnd(1024, seed + 61), res=None,
+                                out=mk((B, H2, W2, 1024)), k=3, s=2, cin=512, cout=1024, tile=1))
 
 
 # (B, H, W, first Cin, blocks): one tile per layer; partial last tile + several images per tile; many tiles (two rounds of 256
@@ -116,6 +151,36 @@ def test_chain_is_bit_identical_to_separate_launches(B, H, W, c0, blocks):
             assert torch.equal(got, ref), (rep, i, (got.float() - ref.float()).abs().max().item())
 
 
+@pytest.mark.parametrize("B,H,W,blocks", [(1, 20, 24, 1), (3, 30, 22, 2), (8, 92, 160, 3)])
+def test_mixed_tile_chain_is_bit_identical_to_separate_launches(B, H, W, blocks):
+    """256 x 256 and 256 x 128 tiles in one chain (the C = 512 stage's shape: 1x1 on the narrow tile, 3x3 + shortcut on the wide
+    one with two n-tiles per m-tile, stride-2 convs at both ends) against variants 50 / 60 launched one by one."""
+    net = _Net512(B, H, W, 256, blocks, seed=B * 10 + H)
+    net.poison()
+    net.run_separately()
+    torch.cuda.synchronize()
+    want = [t.clone() for t in net.outputs()]
+    assert all(torch.isfinite(t.float()).all() for t in want)
+    run = net.chain()
+    for rep in range(4):
+        net.poison()
+        run()
+        _check(net, run, want, f"mixed tiles, rep {rep}")
+    side = torch.cuda.Stream()
+    junk = torch.randn(4096, 4096, device=DEV)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        run()
+    for rep in range(4):
+        net.poison()
+        torch.cuda.synchronize()
+        with torch.cuda.stream(side):
+            for _ in range(1 + rep % 3):
+                junk = torch.tanh(junk @ junk * 1e-3)
+        g.replay()
+        _check(net, run, want, f"mixed tiles, replay under load, rep {rep}")
+
+
 def test_chain_sees_fresh_data_when_the_input_changes():
     """The same buffers, new contents, no poison in between: a CU (or an XCD's L2) that served a line of an intermediate tensor
     during the previous launch must not serve it again — the arrival counter + the L1 invalidate are the only things between a
@@ -135,15 +200,6 @@ def test_chain_sees_fresh_data_when_the_input_changes():
         assert run.status() == 0
         for i, (got, ref) in enumerate(zip(net.outputs(), want)):
             assert torch.equal(got, ref), (rep, i)
-
-
-def _check(net, run, want, tag):
-    torch.cuda.synchronize()
-    st = run.status()
-    head = run.keep[1][:64].view(torch.int32).tolist()
-    assert st == 0, (tag, st, head)
-    for i, (got, ref) in enumerate(zip(net.outputs(), want)):
-        assert torch.equal(got, ref), (tag, i, head)
 
 
 def test_chain_under_uneven_load():

@@ -26,8 +26,8 @@ eng.autotune(cache=os.path.join(ROOT, "adaptiveisp_amd", "yolo", "tuning", "mi35
 x = torch.from_numpy(test_image(8, 720, 1280, seed=3, special=False)).to(dev)
 NAMES = {0: "-> tile start", 1: "arguments, row decode, W/A DMA issue (0->1)", 2: "prologue landed + publish of the previous tile (1->2)",
          3: "k-loop (2->3)", 6: "tail + epilogue (3->6)", 4: "fused: wait + barrier (6->4)", 5: "fused: 1x1 GEMM (4->5)",
-         8: "fused: out2 epilogue / last stores issued (5|6->8)", 9: "look-ahead stage 3 + end barrier (8->9)",
-         10: "loop top: next item, record, slow path, layer arguments (9->10)"}
+         8: "fused: out2 epilogue / last stores issued (5|6->8)", 11: "look-ahead stage 3 (8->11)", 9: "end barrier: waiting for the slowest wave (11->9)",
+         12: "loop top, slow path taken: publish, poll, acquire (9->12)", 10: "loop top: hand-over through LDS, layer arguments (9|12->10)"}
 st = _lib.stream_ptr()
 buf = np.zeros(16, np.uint64)
 for ci, c in enumerate(eng.chains):
@@ -44,7 +44,8 @@ for ci, c in enumerate(eng.chains):
     tiles = float(buf[14])
     print(f"chain {ci}: {c['layers']} layers, {tiles / reps:.0f} tiles per launch; cycles per tile (thread 0 of each workgroup):")
     tot = 0.0
-    for k in (10, 0, 1, 2, 3, 6, 4, 5, 8, 9):
+    print(f"   slow path taken for {float(buf[13]) / max(tiles, 1) * 100:.1f} % of the tiles")
+    for k in (12, 10, 0, 1, 2, 3, 6, 4, 5, 8, 11, 9):
         v = float(buf[k]) / max(tiles, 1)
         tot += v
         print(f"   {NAMES[k]:72s} {v:9.0f}")
