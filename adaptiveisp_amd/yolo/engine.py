@@ -402,7 +402,7 @@ class YoloEngine:
         self.fuse_chains()
         return n
 
-    CHAIN_MIN = 2                                        # launches a run must replace to become a chain
+    CHAIN_MIN = 4                                        # launches a run must replace to become a chain
 
     def fuse_chains(self):
         """Runs of consecutive launches of the 256 x 256 kernel (variant 50, alone or with the next block's 1x1 fused) and the
@@ -427,9 +427,26 @@ class YoloEngine:
                 return False
             return (a[16] == 50 and a[12] % 256 == 0) or (a[16] == 60 and a[12] % 128 == 0)
 
+        # What a chain can win is the partly empty LAST round of every layer (460 tiles on 256 CUs: the next layer's tiles fill it)
+        # and the launch boundaries; a layer with FEWER tiles than CUs has no second round to fill, and its successor cannot start
+        # before (nearly) all of it is done — measured (round 5, profiles/round5_chain_ab.txt): the C = 512 stage's 16 layers of 230
+        # tiles inside a chain run exactly as fast as their 16 launches, the head's short runs slower. So: a run is made of
+        # layers with more tiles than CUs, plus at most ONE trailing layer below that (it fills the run's own tail).
+        cus = torch.cuda.get_device_properties(self.dev).multi_processor_count
+
+        def tiles(j):
+            kind, _, a = P[j]
+            Ho, Wo = (a[9] - 1) // a[14] + 1, (a[10] - 1) // a[14] + 1
+            bn = 128 if (kind == "conv" and a[16] == 60) else 256
+            return ((a[8] * Ho * Wo + 255) // 256) * (a[12] // bn)
+
+        if os.environ.get("ADAYOLO_CHAIN_ALL", "0") == "1":      # measurement: every eligible run, whatever its tile counts
+            cus = 0
         while i < len(P):
             j = i
-            while j < len(P) and eligible(j):
+            while j < len(P) and eligible(j) and tiles(j) > cus:
+                j += 1
+            if j > i and j < len(P) and eligible(j):
                 j += 1
             if j - i >= self.CHAIN_MIN:
                 n = j - i
