@@ -8,8 +8,11 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out
 mkdir -p "$OUT"
 # 1) tune once (writes the cache into this checkout and a copy into gpurun_out so it can be committed), 2) official line
-python3 "$R/bench.py" --retune --no-cpu-baseline --no-detail --no-extras > /dev/null 2>&1
-cp "$R/adaptiveisp_amd/yolo/tuning/mi355x.json" "$OUT/${TAG}_tuning_mi355x.json"
+# (RETUNE=1 re-measures the per-layer kernel table first; by default the committed table is used as it is)
+if [ "${RETUNE:-0}" = "1" ]; then
+  python3 "$R/bench.py" --retune --no-cpu-baseline --no-detail --no-extras > /dev/null 2>&1
+  cp "$R/adaptiveisp_amd/yolo/tuning/mi355x.json" "$OUT/${TAG}_tuning_mi355x.json"
+fi
 python3 "$R/bench.py" > "$OUT/${TAG}_bench.json" 2> "$OUT/${TAG}_bench.err"
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/${TAG}_stats" -o bench -- python3 "$R/bench.py" --no-cpu-baseline --no-extras > "$OUT/${TAG}_stats.log" 2>&1
