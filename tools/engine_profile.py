@@ -26,6 +26,9 @@ for kind, fn, args in eng.plan:
         Ho, Wo = (H - 1) // s + 1, (W - 1) // s + 1
         fl = 2.0 * B * Ho * Wo * cout * (k * k * cin + args[20])
         rows.append((t, f"conv {H}x{W} {cin}->{cout} k{k}s{s} + 1x1 {cout}->{args[20]} fused: {t:7.1f} us {fl / t / 1e6:7.1f} TF"))
+    elif kind == "chain":                                 # a run of layers as one persistent launch (YoloEngine.fuse_chains)
+        c = next(c for c in eng.chains if c["ws"].data_ptr() == args[2].value)
+        rows.append((t, f"chain of {c['layers']} layers ({c['flops'] / 1e9:.0f} GFLOP): {t:7.1f} us {c['flops'] / t / 1e6:7.1f} TF"))
     elif kind == "conv":
         B, H, W, cin, cout, k, s, act, v = args[8:17]
         Ho, Wo = (H - 1) // s + 1, (W - 1) // s + 1

@@ -1,0 +1,13 @@
+#!/bin/bash
+# Runs ON THE GPU BOX: the maintained tools once each with short settings, against the in-tree libraries — "does it still run
+# against this ABI". One line per tool (ok / FAILED + the last lines of its output).  usage: gpurun -- 'bash tools/selfcheck.sh'
+cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}"
+run() { name=$1; shift; out=$(timeout 300 "$@" 2>&1); rc=$?; if [ $rc -eq 0 ]; then echo "ok      $name"; else echo "FAILED  $name (rc $rc)"; echo "$out" | tail -5; fi; }
+run engine_profile python tools/engine_profile.py
+run chain_ab python tools/chain_ab.py --rounds 2 --reps 2
+run kernel_times python tools/kernel_times.py
+run nlm_ab python tools/nlm_ab.py
+run conv_bench python tools/conv_bench.py
+run train_bench python tools/train_bench.py
+run eval_bench python tools/eval_bench.py
+run isp_step_ab python tools/isp_step_ab.py --ops=0,5 --pairs=3
