@@ -561,7 +561,7 @@ def _timed(fn, repeats=3):
     return ts[0], ts[len(ts) // 2]
 
 
-ALL_CORES_LIMIT_S = 90
+ALL_CORES_LIMIT_S = 60
 
 
 def cpu_probe(a, threads):
