@@ -100,3 +100,26 @@ def test_raw_bayer_start_pipelined_equals_sequential():
             run()
             torch.cuda.synchronize()
             assert torch.equal(engine.pred, ref)
+
+
+def test_headline_pipeline_with_the_persistent_chain_is_bit_reproducible():
+    """The headline's arrangement at the headline's size with the backbone's C = 256 stage as a persistent chain (round 5): the
+    chain's workgroups hold their CUs for ~0.8 ms while the ISP stream's kernels (NLM's 48.5 KB workgroups, the policy's small
+    launches) take whatever CUs are free — uneven residency, graph replay on two streams. Every replay must equal the eager
+    sequential step bit for bit, and no dependency wait of the chain may have given up."""
+    sys.path.insert(0, ROOT)
+    import bench
+    a = argparse.Namespace(batch=8, height=720, width=1280, schedule="mixed", retune=False)
+    step, engine, agent, x0, sched = bench.build_workload(a, torch.device("cuda:0"))
+    assert engine.chains and max(c["layers"] for c in engine.chains) >= 8
+    ref = step().clone()
+    xref = step.isp_chain().clone()
+    torch.cuda.synchronize()
+    prime, run = bench.build_pipeline(step, engine, x0)
+    prime()
+    for i in range(24):
+        run()
+        torch.cuda.synchronize()
+        assert torch.equal(run.xbuf[i & 1], xref), i
+        assert torch.equal(engine.pred, ref), i
+    assert engine.chain_status() == 0

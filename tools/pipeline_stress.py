@@ -33,5 +33,7 @@ for i in range(n):
         d = (engine.pred - ref).abs()
         nz = (d > 0).nonzero()
         print(f"replay {i}: MISMATCH max {d.max().item():.4g} in {(d > 0).sum().item()} elements; images {sorted(set(nz[:, 0].tolist()))} rows {nz[:, 1].min().item()}..{nz[:, 1].max().item()}")
-print(f"{n} pipelined replays: {bad} detector mismatches, {badx} ISP-output mismatches (excluded variants {excl})")
-sys.exit(1 if bad or badx else 0)
+st = engine.chain_status()
+print(f"{n} pipelined replays: {bad} detector mismatches, {badx} ISP-output mismatches (excluded variants {excl}); "
+      f"chains {[c['layers'] for c in engine.chains]}, status {st}")
+sys.exit(1 if bad or badx or st else 0)
