@@ -308,10 +308,10 @@ int adayolo_conv_chain_fwd(const adayolo_chain_layer* layers, int n, void* works
 
 int adayolo_conv_chain_status(const void* workspace) {
     if (!workspace) return ADAYOLO_EINVAL;
-    int w[2] = {0, 0};
+    int w[4] = {0, 0, 0, 0};                             // head, err (this launch), exit, err (sticky: the last launch that gave up)
     if (hipDeviceSynchronize() != hipSuccess) return ADAYOLO_ELAUNCH;
     if (hipMemcpy(w, workspace, sizeof(w), hipMemcpyDeviceToHost) != hipSuccess) return ADAYOLO_ELAUNCH;
-    return w[1];
+    return w[3] ? w[3] : w[1];
 }
 
 int adayolo_bottleneck256_fwd(const void* x, int x_cstride, const void* weight1, const float* bias1, const void* weight2,

@@ -146,6 +146,13 @@ __global__ __launch_bounds__(512) void k_conv_chain(const ChainArgs c) {
         if (tid == 0) {
             __hip_atomic_store(chain_head(c), 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(chain_exit(c), 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // a wait that gave up stops the waits of ITS launch only: the code moves to the sticky word adayolo_conv_chain_status
+            // reads, and the next launch starts with a clean one
+            const int e = __hip_atomic_load(chain_err(c), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (e != 0) {
+                __hip_atomic_store(chain_err(c) + 2, e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(chain_err(c), 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
         }
     }
 }

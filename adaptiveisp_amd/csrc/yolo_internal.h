@@ -98,8 +98,9 @@ __device__ __forceinline__ void bias_act_pack4(float a0, float a1, float a2, flo
 // ---- persistent chain (yolo_conv_pp.hip: k_conv_chain): several consecutive layers of the 256 x 256 kernel's tiles in ONE launch.
 // One work item = one tile of one layer; the tables are built on the host (yolo_api.hip: adayolo_conv_chain_prepare).
 // Workspace (device, caller-owned; the byte offsets are multiples of 64):
-//   [0, 64)            int head (next item to hand out), int err (!= 0: a bounded wait gave up: item + 1; sticky until the next
-//                      prepare), int exit (workgroups that have left), padding — head, exit and done[] are ZERO between launches
+//   [0, 64)            int head (next item to hand out), int err (!= 0: a bounded wait of THIS launch gave up: item + 1), int exit
+//                      (workgroups that have left), int sticky err (the last launch that gave up, until the next prepare),
+//                      padding — head, err, exit and done[] are ZERO between launches
 //   [64, ...)          int done[ndone]: arrival counters, one per (layer, m-tile)
 //   [off_layers, ...)  ConvArgs[nlayers]
 //   [off_heads, ...)   ChainHead[total]   layer-major: an item only ever waits for items BEFORE it in this order
