@@ -281,6 +281,47 @@ def test_chain_in_a_graph_is_ordered_behind_its_producers():
         _check(net, run, want, f"graph [copy, chain], rep {rep}")
 
 
+def test_a_wait_that_can_never_be_satisfied_gives_up_and_reports():
+    """Every spin in the chain is bounded: with one item's dependency made unsatisfiable (its `need` poked to 32767 in the
+    device-side table) the launch still ENDS (~1 s), `adayolo_conv_chain_status` names the item, the launch after it waits
+    normally again, and after a fresh `prepare` the chain is clean and correct."""
+    import numpy as np
+    from adaptiveisp_amd.yolo import _lib
+    L = _lib.load()
+    net = _Net(2, 40, 48, 128, 2, seed=31)
+    net.run_separately()
+    torch.cuda.synchronize()
+    want = [t.clone() for t in net.outputs()]
+    run = net.chain()
+    arr, ws = run.keep
+    n = len(net.layers)
+    img = np.zeros(ws.numel(), np.uint8)
+    info = (ctypes.c_int32 * 6)()
+    assert L.adayolo_conv_chain_tables(arr, n, img.ctypes.data_as(ctypes.c_void_p), img.size, info) == 0
+    total, ndone, off_layers, off_items, off_deps, _ = list(info)
+    deps = img[off_deps:off_deps + 16 * total].view(np.int32).reshape(total, 4)
+    victim = int(np.nonzero(deps[:, 1] >> 16)[0][3])                 # some item that waits for an input window
+    wsi = ws.view(torch.int32)
+    word = off_deps // 4 + 4 * victim + 1
+    good = int(wsi[word])
+    wsi[word] = (good & ~0xFFFF) | 0x7FFF
+    net.poison()
+    run()
+    torch.cuda.synchronize()                                         # must return: the spin is bounded
+    assert run.status() == victim + 1
+    wsi[word] = good                                                 # the table is whole again: this launch waits normally
+    net.poison()
+    run()
+    torch.cuda.synchronize()
+    for got, ref in zip(net.outputs(), want):
+        assert torch.equal(got, ref)
+    assert run.status() == victim + 1                                # (sticky until the next prepare)
+    _lib.check(L.adayolo_conv_chain_prepare(arr, n, ctypes.c_void_p(ws.data_ptr()), ws.numel()), "prepare")
+    net.poison()
+    run()
+    _check(net, run, want, "after a fresh prepare")
+
+
 def test_chain_refuses_what_it_does_not_serve():
     from adaptiveisp_amd.yolo import _lib
     L = _lib.load()
