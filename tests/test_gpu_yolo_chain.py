@@ -308,14 +308,15 @@ def test_a_wait_that_can_never_be_satisfied_gives_up_and_reports():
     net.poison()
     run()
     torch.cuda.synchronize()                                         # must return: the spin is bounded
-    assert run.status() == victim + 1
+    first = run.status()
+    assert first >= victim + 1                                       # the victim (or, in a photo finish, an item waiting for IT)
     wsi[word] = good                                                 # the table is whole again: this launch waits normally
     net.poison()
     run()
     torch.cuda.synchronize()
     for got, ref in zip(net.outputs(), want):
         assert torch.equal(got, ref)
-    assert run.status() == victim + 1                                # (sticky until the next prepare)
+    assert run.status() == first                                     # (sticky until the next prepare)
     _lib.check(L.adayolo_conv_chain_prepare(arr, n, ctypes.c_void_p(ws.data_ptr()), ws.numel()), "prepare")
     net.poison()
     run()
