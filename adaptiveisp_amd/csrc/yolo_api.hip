@@ -302,8 +302,11 @@ int adayolo_conv_chain_fwd(const adayolo_chain_layer* layers, int n, void* works
     c.off_layers = (int)P.off_layers; c.off_heads = (int)P.off_heads; c.off_deps = (int)P.off_deps; c.total = (int)P.heads.size();
     c.ndone = P.ndone;
     static const int stagger = [] { const char* e = getenv("ADAYOLO_CHAIN_STAGGER"); return e ? atoi(e) : 0; }();
+    // ADAYOLO_CHAIN_GRID (measurement): fewer persistent workgroups than CUs — what is left over is free for another stream's kernels
+    static const int grid_cap = [] { const char* e = getenv("ADAYOLO_CHAIN_GRID"); return e ? atoi(e) : 0; }();
     c.stagger = stagger;
-    return launch_conv_chain(c, device_cus(), static_cast<hipStream_t>(stream)) == hipSuccess ? ADAYOLO_OK : ADAYOLO_ELAUNCH;
+    const int grid = grid_cap > 0 && grid_cap < device_cus() ? grid_cap : device_cus();
+    return launch_conv_chain(c, grid, static_cast<hipStream_t>(stream)) == hipSuccess ? ADAYOLO_OK : ADAYOLO_ELAUNCH;
 }
 
 int adayolo_conv_chain_status(const void* workspace) {
