@@ -442,13 +442,10 @@ class YoloEngine:
 
         if os.environ.get("ADAYOLO_CHAIN_ALL", "0") == "1":      # measurement: every eligible run, whatever its tile counts
             cus = 0
+        runs = dict(chain_runs([(eligible(j), tiles(j) if eligible(j) else 0) for j in range(len(P))], cus, self.CHAIN_MIN))
         while i < len(P):
-            j = i
-            while j < len(P) and eligible(j) and tiles(j) > cus:
-                j += 1
-            if j > i and j < len(P) and eligible(j):
-                j += 1
-            if j - i >= self.CHAIN_MIN:
+            j = runs.get(i, i)
+            if j > i:
                 n = j - i
                 layers = (_lib.ChainLayer * n)()
                 flops = 0.0
@@ -627,6 +624,23 @@ class YoloEngine:
             t = v.buf[..., : self.na * self.no].float()
             outs.append(t.view(self.B, v.H, v.W, self.na, self.no).permute(0, 3, 1, 2, 4).contiguous())
         return outs
+
+
+def chain_runs(entries, cus, chain_min):
+    """Which runs of a launch plan become persistent chains (YoloEngine.fuse_chains): `entries` = (eligible, tiles) per launch;
+    a run = consecutive eligible launches with MORE tiles than `cus`, plus at most one trailing eligible launch below that (it fills
+    the run's own tail); runs shorter than `chain_min` launches stay as they are. Returns [(first, end)), ...]."""
+    out, i, n = [], 0, len(entries)
+    while i < n:
+        j = i
+        while j < n and entries[j][0] and entries[j][1] > cus:
+            j += 1
+        if i < j < n and entries[j][0]:
+            j += 1
+        if j - i >= chain_min:
+            out.append((i, j))
+        i = max(j, i + 1)
+    return out
 
 
 def _src(i, f):

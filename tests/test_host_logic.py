@@ -242,3 +242,20 @@ def test_retouch_stats_host_form():
     assert st.shape == (3, 2) and not st.requires_grad
     assert st[:, 1].tolist() == [0.0, 2.0, 0.0]
     assert torch.allclose(st[[0, 2], 0], x.detach()[[0, 2]].mean(dim=(1, 2, 3))) and not torch.isfinite(st[1, 0])
+
+
+def test_chain_run_selection():
+    """YoloEngine.fuse_chains' rule (yolo/engine.py::chain_runs): layers with more tiles than CUs chain, one trailing layer below
+    that may join, short runs and ineligible launches stay launches — the detector's plan at 8x720x1280 in miniature."""
+    from adaptiveisp_amd.yolo.engine import chain_runs
+    E = lambda t: (True, t)                       # noqa: E731  eligible launch with t tiles
+    X = (False, 0)                                # another kernel's launch
+    plan = ([X, X, X, E(1840), X, X]                 # head of the network: an eligible launch alone between other kernels' launches
+            + [E(460)] * 9 + [E(230)]                # C = 256 stage (9 launches) + the stride-2 conv into C = 512 (230 tiles: trailing)
+            + [E(230), E(230)] * 8 + [E(232)]        # C = 512 stage: fewer tiles than CUs
+            + [X, E(232)] * 4 + [E(460)] * 3 + [X])  # C = 1024 stage around pq launches; three head launches at 92x160
+    assert chain_runs(plan, 256, 4) == [(6, 16)]
+    assert chain_runs(plan, 256, 2) == [(6, 16), (41, 44)]          # the head's three layers only when short runs are allowed
+    assert chain_runs(plan, 0, 4) == [(6, 33), (40, 44)]            # ADAYOLO_CHAIN_ALL: every eligible run of four or more
+    assert chain_runs([E(460)] * 3, 256, 4) == [] and chain_runs([], 256, 4) == []
+    assert chain_runs([E(100), E(460), E(460), E(460), E(460), E(100), E(100)], 256, 4) == [(1, 6)]
