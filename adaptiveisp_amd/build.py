@@ -21,7 +21,9 @@ LIBS = {
         flags=ISP_FLAGS),
     "libadayolo.so": dict(
         sources=["yolo_conv_dma.hip", "yolo_conv_dma2.hip", "yolo_conv_small.hip", "yolo_conv_pp.hip", "yolo_conv_chain.hip", "yolo_bneck.hip", "yolo_conv_pp128.hip", "yolo_conv_pq.hip", "yolo_conv_ws.hip", "yolo_misc.hip", "yolo_stem_down.hip", "yolo_nms.hip", "yolo_train.hip", "yolo_loss.hip", "yolo_api.hip"],
-        headers=["yolo_internal.h", "../../include/adayolo.h"],
+        # (yolo_conv_chain.hip compiles the tile bodies of yolo_conv_pp.hip / yolo_conv_pp128.hip into its own translation unit:
+        # a change to either rebuilds it)
+        headers=["yolo_internal.h", "yolo_chain.h", "yolo_conv_pp.hip", "yolo_conv_pp128.hip", "../../include/adayolo.h"],
         flags=["-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"] + os.environ.get("ADAYOLO_EXTRA_FLAGS", "").split()),
 }
 
