@@ -382,3 +382,32 @@ def test_engine_with_chains_equals_engine_without(monkeypatch):
         g.replay()
         torch.cuda.synchronize()
         assert eng.chain_status() == 0 and torch.equal(eng.pred, want)
+
+
+def test_engine_with_chains_equals_engine_without_at_4k(monkeypatch):
+    """Config 5's size (4 x 2160 x 3840): every stage of the backbone has more tiles than CUs there, so the engine's chain runs
+    through the C = 256, C = 512 and C = 1024 stages with BOTH tile kinds (a mixed chain of two dozen layers) — bit-identical
+    to one launch per layer."""
+    import os
+    from _synth import synth_yolo_state_dict, test_image
+    from adaptiveisp_amd.yolo import YoloEngine, yolov3
+    tune = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "adaptiveisp_amd", "yolo", "tuning", "mi355x.json")
+    det = yolov3()
+    det.load_state_dict(synth_yolo_state_dict(det, seed=2))
+    det = det.eval()
+    x = torch.from_numpy(test_image(4, 2160, 3840, seed=5, special=False)).to(DEV)
+    monkeypatch.setenv("ADAYOLO_CHAIN", "0")
+    plain = YoloEngine(det, 4, 2160, 3840, device=DEV)
+    plain.autotune(cache=tune, write=False)
+    want = plain(x).clone()
+    del plain
+    torch.cuda.empty_cache()
+    monkeypatch.setenv("ADAYOLO_CHAIN", "1")
+    eng = YoloEngine(det, 4, 2160, 3840, device=DEV)
+    eng.autotune(cache=tune, write=False)
+    assert eng.chains and max(c["layers"] for c in eng.chains) >= 16, [c["layers"] for c in eng.chains]
+    for _ in range(2):
+        got = eng(x)
+        torch.cuda.synchronize()
+        assert eng.chain_status() == 0
+        assert torch.equal(got, want)
