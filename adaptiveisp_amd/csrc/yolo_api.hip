@@ -209,10 +209,31 @@ int chain_plan(const adayolo_chain_layer* L, int n, ChainPlan& P, bool tables) {
     P.heads.clear(); P.deps.clear();
     if (!tables) { P.heads.resize(total); return ADAYOLO_OK; }      // (only the count is needed)
     P.heads.reserve(total); P.deps.reserve(total);
+    // Hand-out order of a layer's m-tiles. ADAYOLO_CHAIN_ORDER=snake (measurement): the m-tiles are cut into 8 contiguous chunks (one
+    // per XCD, the launch-per-layer kernels' xcd_remap), handed out round-robin over the chunks — workgroup b of the launch sits
+    // on XCD b % 8 and draws item ~b first, and workgroups that finish in their starting order keep drawing "their" chunk —
+    // ascending inside even chunks, descending inside odd ones, so that the two tiles on either side of a chunk boundary are
+    // handed out at the same end of the layer (a consumer next to a boundary does not wait for a producer handed out 450 items
+    // after its own neighbours). Default: ascending.
+    static const bool snake = [] { const char* e = getenv("ADAYOLO_CHAIN_ORDER"); return e && !strcmp(e, "snake"); }();
     for (int l = 0; l < n; ++l) {
         const ConvArgs& a = P.layers[l];
-        for (int lid = 0; lid < a.mtiles * a.ntiles; ++lid) {
-            const int mt = lid / a.ntiles;
+        std::vector<int> order(a.mtiles);
+        for (int i = 0; i < a.mtiles; ++i) order[i] = i;
+        if (snake && a.mtiles >= 16) {
+            const int q = a.mtiles / 8, r = a.mtiles % 8;
+            int start[9];
+            start[0] = 0;
+            for (int c = 0; c < 8; ++c) start[c + 1] = start[c] + q + (c < r ? 1 : 0);
+            int k = 0;
+            for (int pos = 0; pos <= q; ++pos)
+                for (int c = 0; c < 8; ++c) {
+                    const int size = start[c + 1] - start[c];
+                    if (pos < size) order[k++] = (c & 1) ? start[c + 1] - 1 - pos : start[c] + pos;
+                }
+        }
+        for (int it = 0; it < a.mtiles * a.ntiles; ++it) {
+            const int mt = order[it / a.ntiles], lid = mt * a.ntiles + it % a.ntiles;
             const int m0 = mt * 256, m1 = std::min(m0 + 255, a.M - 1);
             ChainDeps dp{0, 0, 0, 0};
             if (in_src[l] >= 0) {
