@@ -91,7 +91,9 @@ __global__ __launch_bounds__(512) void k_conv_chain(const ChainArgs c) {
                     }
                     __builtin_amdgcn_s_sleep(32);
                 }
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                // (an item whose input and residual were complete before the launch reads nothing another workgroup of THIS launch
+                // wrote: the launch boundary has made it visible, no acquire — the first item of most workgroups)
+                if (((d[1] | d[3]) >> 16) != 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             }
             __syncthreads();
 #ifdef ADAYOLO_CHAIN_STAMPS
