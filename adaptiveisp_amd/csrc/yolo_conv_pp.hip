@@ -29,6 +29,9 @@
 // MFMAs cost more than the texture-address queue they were meant to spare.
 #include "yolo_internal.h"
 #include "yolo_chain.h"
+#ifndef PP_PRIO_MODE
+#define PP_PRIO_MODE 0      // 0: s_setprio 1 around every MFMA section (default); 1: no priority; 2: static priority for the second wave group (measurement builds)
+#endif
 #include <type_traits>
 #include <cstdlib>
 #ifdef ADAYOLO_PLAIN_STORES   // A/B switch (measurement): keep the output lines in the XCD L2 instead of streaming them
@@ -309,7 +312,9 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int lid, unsi
     // wait that retires the half-tile issued three phases ago (readable from the load section two phases on)
     auto mma = [&](int ni, int half, const bf16x8 (&w)[4], unsigned long long g0, unsigned char* d0, unsigned long long g1,
                    unsigned char* d1) {
+#if PP_PRIO_MODE == 0
         __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
 #pragma unroll
@@ -324,11 +329,16 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int lid, unsi
                 }
             }
         }
+#if PP_PRIO_MODE == 0
         __builtin_amdgcn_s_setprio(0);
+#endif
         wait_vm<6>();
     };
     PP_STAMP(2);
     read_w(smem, 0, wx);                                 // W0 of k-tile 0
+#if PP_PRIO_MODE == 2      // measurement: static priority for the second wave group, no flips around the MFMA sections
+    if (wm == 1) __builtin_amdgcn_s_setprio(1);
+#endif
     if (wm == 1) barrier();                              // stagger group 1 by one barrier
 
     KPos p2 = p1;

@@ -26,6 +26,9 @@
 // (profiles/round2_conv_pp_ablation.txt).
 #include "yolo_internal.h"
 #include "yolo_chain.h"
+#ifndef PP_PRIO_MODE
+#define PP_PRIO_MODE 0      // 0: s_setprio 1 around every MFMA section (default); 1: no priority; 2: static priority for the second wave group (measurement builds)
+#endif
 #include <type_traits>
 
 namespace adayolo {
@@ -248,7 +251,9 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int gid, unsi
     // source addresses are computed in the load section in front (see yolo_conv_pp.hip): between two MFMAs only
     // s_mov m0 + the DMA instruction remain
     auto mma = [&](int ni, const bf16x8 (&w)[4], const unsigned long long (&g)[4], unsigned char* const (&d)[4], int npieces) {
+#if PP_PRIO_MODE == 0
         __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
@@ -261,10 +266,15 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int gid, unsi
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
+#if PP_PRIO_MODE == 0
         __builtin_amdgcn_s_setprio(0);
+#endif
     };
 
     read_w(smem, 0, wx);                                 // W0 of k-tile 0
+#if PP_PRIO_MODE == 2
+    if (wn == 1) __builtin_amdgcn_s_setprio(1);
+#endif
     if (wn == 1) barrier();                              // stagger group 1 by one barrier
 
     KPos p2 = q2, p3 = q2;                               // p2: k-tile t+2, p3: k-tile t+3 (advanced inside the loop)
