@@ -3,6 +3,8 @@
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
+#include <unordered_map>
 #include <vector>
 
 using namespace adayolo;
@@ -207,7 +209,7 @@ int chain_plan(const adayolo_chain_layer* L, int n, ChainPlan& P, bool tables) {
     P.bytes = up64(P.off_deps + (size_t)total * sizeof(ChainDeps));
     if (P.bytes >= 0x7FFFFFFFu) return ADAYOLO_ESHAPE;
     P.heads.clear(); P.deps.clear();
-    if (!tables) { P.heads.resize(total); return ADAYOLO_OK; }      // (only the count is needed)
+    if (!tables) return ADAYOLO_OK;                                  // (only the sizes are needed)
     P.heads.reserve(total); P.deps.reserve(total);
     // Hand-out order of a layer's m-tiles. ADAYOLO_CHAIN_ORDER=snake (measurement): the m-tiles are cut into 8 contiguous chunks (one
     // per XCD, the launch-per-layer kernels' xcd_remap), handed out round-robin over the chunks — workgroup b of the launch sits
@@ -281,7 +283,7 @@ int device_cus() {
 }  // namespace
 
 size_t adayolo_conv_chain_workspace_bytes(const adayolo_chain_layer* layers, int n) {
-    ChainPlan P;
+    ChainPlan P;                                         // (with the tables: a dependency window the kernel cannot hold is "not served")
     return chain_plan(layers, n, P, true) == ADAYOLO_OK ? P.bytes : 0;
 }
 
@@ -302,26 +304,78 @@ int adayolo_conv_chain_tables(const adayolo_chain_layer* layers, int n, void* ho
     return ADAYOLO_OK;
 }
 
+// What `prepare` leaves on the host for a workspace: the launch arguments, a fingerprint of the layer list they were built from
+// and the pinned word the kernel mirrors a give-up code to. `fwd` is then a checked launch: one map lookup + one hash of the
+// caller's list, no tables, no allocation.
+namespace {
+struct ChainDesc {
+    ChainArgs args;
+    unsigned long long fingerprint;
+    size_t bytes;
+};
+std::mutex g_chain_mu;
+std::unordered_map<const void*, ChainDesc> g_chain_desc;
+int* g_chain_flags = nullptr;                 // one pinned page: 1024 give-up words, handed out round-robin per prepare
+int g_chain_flags_next = 0;
+
+unsigned long long chain_fingerprint(const adayolo_chain_layer* L, int n) {
+    unsigned long long h = 1469598103934665603ull;             // FNV-1a over the FIELDS (struct padding is not the caller's to define)
+    auto mix = [&](unsigned long long v) { for (int i = 0; i < 8; ++i) { h ^= (v >> (8 * i)) & 0xFF; h *= 1099511628211ull; } };
+    mix((unsigned long long)n);
+    for (int l = 0; l < n; ++l) {
+        const adayolo_chain_layer& d = L[l];
+        for (const void* p : {d.in, d.weight, (const void*)d.bias, d.residual, (const void*)d.out, d.weight2, (const void*)d.bias2,
+                              (const void*)d.out2})
+            mix((unsigned long long)(uintptr_t)p);
+        for (int v : {d.in_cstride, d.res_cstride, d.out_cstride, d.B, d.H, d.W, d.Cin, d.Cout, d.ksize, d.stride, d.act,
+                      d.out2_cstride, d.Cout2, d.tile})
+            mix((unsigned long long)(unsigned)v);
+    }
+    return h;
+}
+}  // namespace
+
 int adayolo_conv_chain_prepare(const adayolo_chain_layer* layers, int n, void* workspace, size_t workspace_bytes) {
     ChainPlan P;
-    const int rc = chain_plan(layers, n, P, false);
+    const int rc = chain_plan(layers, n, P, true);
     if (rc != ADAYOLO_OK) return rc;
     if (!workspace || workspace_bytes < P.bytes || ((uintptr_t)workspace & 63)) return ADAYOLO_EINVAL;
     std::vector<unsigned char> img(P.bytes, 0);
-    const int rc2 = adayolo_conv_chain_tables(layers, n, img.data(), img.size(), nullptr);
-    if (rc2 != ADAYOLO_OK) return rc2;
-    return hipMemcpy(workspace, img.data(), P.bytes, hipMemcpyHostToDevice) == hipSuccess ? ADAYOLO_OK : ADAYOLO_ELAUNCH;
+    memcpy(img.data() + P.off_layers, P.layers.data(), P.layers.size() * sizeof(ConvArgs));
+    memcpy(img.data() + P.off_heads, P.heads.data(), P.heads.size() * sizeof(ChainHead));
+    memcpy(img.data() + P.off_deps, P.deps.data(), P.deps.size() * sizeof(ChainDeps));
+    if (hipMemcpy(workspace, img.data(), P.bytes, hipMemcpyHostToDevice) != hipSuccess) return ADAYOLO_ELAUNCH;
+    std::lock_guard<std::mutex> lock(g_chain_mu);
+    if (!g_chain_flags) {
+        void* p = nullptr;
+        if (hipHostMalloc(&p, 4096, hipHostMallocMapped) != hipSuccess) return ADAYOLO_ELAUNCH;
+        memset(p, 0, 4096);
+        g_chain_flags = static_cast<int*>(p);
+    }
+    ChainDesc d;
+    d.args.ws = static_cast<unsigned char*>(workspace);
+    auto old = g_chain_desc.find(workspace);
+    d.args.host_err = old != g_chain_desc.end() ? old->second.args.host_err : g_chain_flags + (g_chain_flags_next++ & 1023);
+    *d.args.host_err = 0;
+    d.args.off_layers = (int)P.off_layers; d.args.off_heads = (int)P.off_heads; d.args.off_deps = (int)P.off_deps;
+    d.args.total = (int)P.heads.size(); d.args.ndone = P.ndone; d.args.stagger = 0;
+    d.fingerprint = chain_fingerprint(layers, n);
+    d.bytes = P.bytes;
+    g_chain_desc[workspace] = d;
+    return ADAYOLO_OK;
 }
 
 int adayolo_conv_chain_fwd(const adayolo_chain_layer* layers, int n, void* workspace, size_t workspace_bytes, void* stream) {
-    ChainPlan P;
-    const int rc = chain_plan(layers, n, P, false);
-    if (rc != ADAYOLO_OK) return rc;
-    if (!workspace || workspace_bytes < P.bytes || ((uintptr_t)workspace & 63)) return ADAYOLO_EINVAL;
+    if (!layers || n < 1 || !workspace) return ADAYOLO_EINVAL;
     ChainArgs c;
-    c.ws = static_cast<unsigned char*>(workspace);
-    c.off_layers = (int)P.off_layers; c.off_heads = (int)P.off_heads; c.off_deps = (int)P.off_deps; c.total = (int)P.heads.size();
-    c.ndone = P.ndone;
+    {
+        std::lock_guard<std::mutex> lock(g_chain_mu);
+        auto it = g_chain_desc.find(workspace);
+        // the workspace must have been prepared for THIS layer list: tables of another list would be read at wrong offsets
+        if (it == g_chain_desc.end() || it->second.fingerprint != chain_fingerprint(layers, n) || workspace_bytes < it->second.bytes)
+            return ADAYOLO_EINVAL;
+        c = it->second.args;
+    }
     static const int stagger = [] { const char* e = getenv("ADAYOLO_CHAIN_STAGGER"); return e ? atoi(e) : 0; }();
     // ADAYOLO_CHAIN_GRID (measurement): fewer persistent workgroups than CUs — what is left over is free for another stream's kernels
     static const int grid_cap = [] { const char* e = getenv("ADAYOLO_CHAIN_GRID"); return e ? atoi(e) : 0; }();
@@ -336,6 +390,13 @@ int adayolo_conv_chain_status(const void* workspace) {
     if (hipDeviceSynchronize() != hipSuccess) return ADAYOLO_ELAUNCH;
     if (hipMemcpy(w, workspace, sizeof(w), hipMemcpyDeviceToHost) != hipSuccess) return ADAYOLO_ELAUNCH;
     return w[3] ? w[3] : w[1];
+}
+
+int adayolo_conv_chain_poll(const void* workspace) {
+    std::lock_guard<std::mutex> lock(g_chain_mu);
+    auto it = g_chain_desc.find(workspace);
+    if (it == g_chain_desc.end()) return ADAYOLO_EINVAL;
+    return __atomic_load_n(it->second.args.host_err, __ATOMIC_RELAXED);       // pinned host memory: no device call
 }
 
 int adayolo_bottleneck256_fwd(const void* x, int x_cstride, const void* weight1, const float* bias1, const void* weight2,

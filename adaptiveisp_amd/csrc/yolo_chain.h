@@ -9,17 +9,23 @@
 // launch); counters through agent-scope accesses.
 #pragma once
 #include "yolo_internal.h"
+#ifndef CHAIN_INV_WAIT
+#define CHAIN_INV_WAIT 1
+#endif
 
 namespace adayolo {
 
-// LDS: both tile bodies end at 147456 + 1 KB of bias; the scheduler words follow
+// LDS: both tile bodies end at 147456 + 1 KB of bias; the scheduler words follow (yolo_conv_chain.hip asserts that neither
+// tile body's kSmem reaches them)
 constexpr int kChainSchedOff = 147456 + 1024;      // int[8]: {next item, its inputs are ready, layer, tile, arrival counter, exit ticket, -, -}
 #ifdef ADAYOLO_CHAIN_STAMPS
 constexpr int kChainSmem = kChainSchedOff + 32 + 128;
 #else
 constexpr int kChainSmem = kChainSchedOff + 32;
 #endif
-constexpr unsigned kChainSpinLimit = 1u << 19;     // ~1 s of polling before a wait gives up
+// A dependency wait gives up after kChainWaitTicks of the constant 100 MHz s_memrealtime clock (wall time, whatever the
+// shader clock and the contention: the old bound counted polling iterations)
+constexpr unsigned long long kChainWaitTicks = 100000000ull;     // 1 s
 
 struct ChainCtx {
     const ChainArgs* c;
@@ -81,7 +87,15 @@ struct ChainLook {
         } else {
             int ready = 0;
             if (item < c.total && chain_arrived(deps, val, lane)) {
+                // the acquire. Two hardware facts it leans on: (1) a CU's L1 takes the invalidate and the loads
+                // the other seven waves issue behind the tile's end barrier in program order of ARRIVAL, so an invalidate that
+                // was issued before the barrier is ahead of them; (2) an sc1 store whose vmcnt has retired is visible on
+                // every XCD. CHAIN_INV_WAIT=1 additionally waits for the invalidate's acknowledgement before
+                // `ready` is written — it also waits for this wave's own output stores: measured, see DESIGN 9
                 asm volatile("buffer_inv sc1" ::: "memory");
+#if CHAIN_INV_WAIT
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
                 ready = 1;
             }
             if (lane == 0) {

@@ -17,7 +17,9 @@ namespace chain {
 using ppc::barrier;
 using ppc::wait_vm;
 constexpr int kSmemChain = kChainSmem;
-constexpr unsigned kSpinLimit = kChainSpinLimit;
+// the scheduler words sit behind BOTH tile bodies' LDS (ring / epilogue overlay + bias): a change to a tile's pitch, BN or ring
+// must move kChainSchedOff with it
+static_assert(ppc::kSmem <= kChainSchedOff && pp128c::kSmem <= kChainSchedOff, "the chain's scheduler words overlap a tile body's LDS");
 typedef chain_cint_p cint_p;
 #ifdef ADAYOLO_CHAIN_STAMPS
 __device__ unsigned long long g_chain_acc[16];
@@ -79,13 +81,14 @@ __global__ __launch_bounds__(512) void k_conv_chain(const ChainArgs c) {
             if (wave == 0) {
                 int d[4];
                 chain_load4(c, c.off_deps, item, d);
-                // bounded: a wait that gives up records its item; once ANY wait of the launch has given up no other one spins (the
-                // launch then finishes within one limit, wrong — adayolo_conv_chain_status tells)
-                unsigned spins = 0;
+                // bounded in WALL time: a wait that gives up records its item; once ANY wait of the launch has given up no other one
+                // spins (the launch then finishes within one limit, wrong — and says so: the code reaches the sticky word and the
+                // pinned host word, YoloEngine raises at its next forward / sync point: adayolo_conv_chain_poll / _status)
+                const unsigned long long t_wait0 = __builtin_amdgcn_s_memrealtime();
                 while (!chain_arrived(d, chain_counter(c, d, lane), lane)) {
                     const int e = __hip_atomic_load(chain_err(c), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     if (e != 0) break;
-                    if (++spins > kSpinLimit) {
+                    if (__builtin_amdgcn_s_memrealtime() - t_wait0 > kChainWaitTicks) {
                         if (lane == 0) __hip_atomic_store(chain_err(c), item + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         break;
                     }
@@ -154,6 +157,8 @@ __global__ __launch_bounds__(512) void k_conv_chain(const ChainArgs c) {
             if (e != 0) {
                 __hip_atomic_store(chain_err(c) + 2, e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __hip_atomic_store(chain_err(c), 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                // ... and to the pinned host word the production path polls without a device round trip
+                if (c.host_err) __hip_atomic_store(c.host_err, e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             }
         }
     }

@@ -113,6 +113,8 @@ struct ChainDeps {                                 // done[lo .. lo + n) each >=
 };
 struct ChainArgs {
     unsigned char* ws;
+    int* host_err;               // pinned HOST word (device-visible): the launch's last workgroup mirrors a give-up code there, so
+                                 // that adayolo_conv_chain_poll reads it without touching the device (nullptr: not mirrored)
     int off_layers, off_heads, off_deps, total, ndone;
     int stagger;                 // cycles: workgroup b starts ((b >> 3) & 7) * stagger late (0: all at once). ADAYOLO_CHAIN_STAGGER
 };

@@ -149,6 +149,10 @@ def run_eval(agent, detector, batches, cfg, steps=5, conf_thres=0.001, iou_thres
     res = dict(mp=0.0, mr=0.0, map50=0.0, map75=0.0, map=0.0, seen=seen, ap_class=np.zeros(0, int), ap=np.zeros((0, niou)),
                records=records, filter_names=filter_names)
     stats = [torch.cat(x, 0).cpu().numpy() for x in zip(*stats)] if stats else []
+    # (the copy above drained the device) a persistent conv chain whose dependency wait gave up has produced wrong detections
+    # with every launch returning OK: every forward polls the host word of the one before it, this covers the last one
+    if hasattr(detector, "check_chains"):
+        detector.check_chains(sync=True)
     if len(stats) and stats[0].any():
         tp, fp, p, r, f1, ap, ap_class = ap_per_class(*stats)
         res.update(mp=float(p.mean()), mr=float(r.mean()), map50=float(ap[:, 0].mean()), map75=float(ap[:, 5].mean()),

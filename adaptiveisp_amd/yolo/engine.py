@@ -411,7 +411,10 @@ class YoloEngine:
         csrc/yolo_conv_pp.hip: k_conv_chain): tiles of all the run's layers drawn from one work counter, a tile waiting only for
         the producer tiles its input window / residual rows lie in. Bit-identical to the separate launches (same tile code).
         ADAYOLO_CHAIN=0 keeps the launches separate. Returns the number of chains."""
-        self.chains = getattr(self, "chains", [])
+        # chains of an earlier plan that are still IN the plan stay registered; the others are dropped (a re-plan must not leave
+        # workspaces behind that no launch uses)
+        live = {a[2].value for kind, _, a in self.plan if kind == "chain"}
+        self.chains = [c for c in getattr(self, "chains", []) if c["ws"].data_ptr() in live]
         if os.environ.get("ADAYOLO_CHAIN", "1") != "1":
             return 0
         P, out, i, made = self.plan, [], 0, 0
@@ -471,14 +474,36 @@ class YoloEngine:
                     made += 1
                     i = j
                     continue
+                # the library does not serve this run as a chain (a dependency window wider than 32 m-tiles, an output >= 2 GB,
+                # aliased tensors): the launches stay separate — said once, not silently
+                import warnings
+                warnings.warn(f"YoloEngine.fuse_chains: the run of {n} launches at plan index {i} stays unchained "
+                              f"(adayolo_conv_chain_workspace_bytes == 0: shape not served)", RuntimeWarning, stacklevel=2)
             out.extend(P[i:max(j, i + 1)])
             i = max(j, i + 1)
         self.plan = out
         return made
 
     def chain_status(self):
-        """0 when every dependency wait of every chain's last forward saw its counters arrive (blocks: a test hook)."""
+        """0 when every dependency wait of every chain's forwards saw its counters arrive. BLOCKS (device synchronise + copy):
+        tests and end-of-run checks; the forward path uses chain_poll."""
         return max([int(self.L.adayolo_conv_chain_status(ctypes.c_void_p(c["ws"].data_ptr()))) for c in getattr(self, "chains", [])] + [0])
+
+    def chain_poll(self):
+        """The same WITHOUT touching the device: the pinned host word a launch's last workgroup mirrors a give-up code to
+        (adayolo_conv_chain_poll). 0 = nothing recorded so far (a forward still in flight has not reported yet)."""
+        return max([int(self.L.adayolo_conv_chain_poll(ctypes.c_void_p(c["ws"].data_ptr()))) for c in getattr(self, "chains", [])] + [0])
+
+    def check_chains(self, sync=False):
+        """Raise if a dependency wait of a persistent chain gave up (the forward that contained it ran on incomplete inputs:
+        its detections are WRONG although every launch returned ADAYOLO_OK). `sync=False`: the host-word poll — called at the top
+        of every forward, so a bad forward is reported by the next one at the latest; `sync=True`: the blocking form, for the
+        places that synchronise anyway (end of an eval batch, end of bench.py's timed region)."""
+        code = self.chain_status() if sync else self.chain_poll()
+        if code:
+            raise _lib.AdayoloError(f"persistent conv chain: the dependency wait of work item {code - 1} gave up after 1 s — the "
+                                    f"forward that contained it ran on incomplete inputs (ADAYOLO_CHAIN=0 runs the layers as "
+                                    f"separate launches)")
 
     def fuse_bottlenecks(self):
         """A whole Bottleneck of the C = 256 stage — cv1 (1x1 256 -> 128 + SiLU) and cv2 (3x3 128 -> 256 + SiLU, + the block's
@@ -551,6 +576,8 @@ class YoloEngine:
             raise ValueError(f"expected fp32 {(self.B, 3, self.H, self.W)} on {self.dev}, got {img.dtype} "
                              f"{tuple(img.shape)} on {img.device}")
         img = img.contiguous()
+        if getattr(self, "chains", None):
+            self.check_chains()                              # (a host memory read per chain: no device call)
         with torch.cuda.device(self.dev):
             self._pass_begin()
             try:

@@ -1052,6 +1052,8 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     mark(f"timed region done: {dt / a.steps * 1e3:.3f} ms per step")
+    if engine is not None:
+        engine.check_chains(sync=True)           # a chain wait that gave up = a wrong forward inside the timed region: raise
     if dist is not None:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

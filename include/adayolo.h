@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define ADAYOLO_ABI_VERSION 8
+#define ADAYOLO_ABI_VERSION 9
 
 #define ADAYOLO_ACT_NONE 0
 #define ADAYOLO_ACT_SILU 1
@@ -63,9 +63,14 @@ int adayolo_conv_fwd(const void* in, int in_cstride,
  *   workspace_bytes  size of the device workspace for this chain (0: not served)
  *   prepare          builds the work-item tables in `workspace` (host work + one blocking copy: a SET-UP call, not
  *                    capturable); again whenever the layer list changes
- *   fwd              one forward of the chain on `stream` (ONE kernel: capturable; no allocation, no sync). The counters in the
- *                    workspace are zero between launches: `prepare` zeroes them, every launch's last workgroup leaves them zero
- *   status           (test hook, blocks) 0 = every wait of every forward since `prepare` saw its counters arrive
+ *   fwd              one forward of the chain on `stream` (ONE kernel: capturable; no allocation, no sync, no table work: a
+ *                    checked launch — ADAYOLO_EINVAL unless `workspace` was prepared for exactly this layer list). The counters in
+ *                    the workspace are zero between launches: `prepare` zeroes them, every launch's last workgroup leaves them zero
+ *   A dependency wait is bounded (1 s of wall time, s_memrealtime). A wait that gives up lets the launch finish — on incomplete
+ *   inputs — and records its item: in the workspace (sticky until the next prepare) and in a pinned HOST word.
+ *   poll             that host word: 0, or item + 1 of the last wait that gave up. No device call, no sync — the production
+ *                    path's check (YoloEngine: before every forward and at every host sync point; a non-zero value raises)
+ *   status           the same from the workspace; BLOCKS (hipDeviceSynchronize + copy): tests, and end-of-run checks
  */
 typedef struct adayolo_chain_layer {
     const void* in; int in_cstride;
@@ -81,6 +86,7 @@ size_t adayolo_conv_chain_workspace_bytes(const adayolo_chain_layer* layers, int
 int adayolo_conv_chain_prepare(const adayolo_chain_layer* layers, int n, void* workspace, size_t workspace_bytes);
 int adayolo_conv_chain_fwd(const adayolo_chain_layer* layers, int n, void* workspace, size_t workspace_bytes, void* stream);
 int adayolo_conv_chain_status(const void* workspace);
+int adayolo_conv_chain_poll(const void* workspace);
 /* The workspace image `prepare` uploads, written to HOST memory instead (no device needed: how the -m "not gpu" tests check the
  * work-item order and every tile's dependency window). Layout: 64 bytes of counters (head, err, exit), int done[ndone], then at the
  * 64-byte-aligned offsets returned in info = {items, ndone, off_layers, off_items, off_deps, sizeof(layer record)}: the

@@ -310,6 +310,9 @@ def test_a_wait_that_can_never_be_satisfied_gives_up_and_reports():
     torch.cuda.synchronize()                                         # must return: the spin is bounded
     first = run.status()
     assert first >= victim + 1                                       # the victim (or, in a photo finish, an item waiting for IT)
+    # the production path's check: the pinned host word, read without any device call (the give-up must not be
+    # visible through a blocking test hook only)
+    assert int(L.adayolo_conv_chain_poll(ctypes.c_void_p(ws.data_ptr()))) == first
     wsi[word] = good                                                 # the table is whole again: this launch waits normally
     net.poison()
     run()
@@ -317,10 +320,68 @@ def test_a_wait_that_can_never_be_satisfied_gives_up_and_reports():
     for got, ref in zip(net.outputs(), want):
         assert torch.equal(got, ref)
     assert run.status() == first                                     # (sticky until the next prepare)
+    assert int(L.adayolo_conv_chain_poll(ctypes.c_void_p(ws.data_ptr()))) == first
     _lib.check(L.adayolo_conv_chain_prepare(arr, n, ctypes.c_void_p(ws.data_ptr()), ws.numel()), "prepare")
+    assert int(L.adayolo_conv_chain_poll(ctypes.c_void_p(ws.data_ptr()))) == 0
     net.poison()
     run()
     _check(net, run, want, "after a fresh prepare")
+    assert int(L.adayolo_conv_chain_poll(ctypes.c_void_p(ws.data_ptr()))) == 0
+
+
+def test_engine_raises_when_a_chain_wait_gave_up(monkeypatch):
+    """YoloEngine polls the host word at the top of every forward and offers the blocking check for sync points: a forward whose
+    chain gave up must not go unnoticed (rc 0 + wrong detections)."""
+    import os
+    import numpy as np
+    from adaptiveisp_amd.yolo import YoloEngine, _lib, yolov3
+    tune = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "adaptiveisp_amd", "yolo", "tuning", "mi355x.json")
+    torch.manual_seed(0)
+    monkeypatch.setenv("ADAYOLO_CHAIN", "1")
+    monkeypatch.setenv("ADAYOLO_CHAIN_ALL", "1")                     # every eligible run, whatever its tile counts
+    eng = YoloEngine(yolov3().eval(), 2, 256, 320, device=DEV)
+    eng.autotune(cache=tune, write=False)
+    if not eng.chains:
+        pytest.skip("no run of this plan is served as a chain at this size")
+    x = torch.rand(2, 3, 256, 320, device=DEV)
+    eng(x)
+    torch.cuda.synchronize()
+    eng.check_chains(sync=True)                                      # clean so far
+    L = _lib.load()
+    ws = eng.chains[0]["ws"]
+    img = np.zeros(ws.numel(), np.uint8)
+    info = (ctypes.c_int32 * 6)()
+    kind, fn, args = next(p for p in eng.plan if p[0] == "chain" and p[2][2].value == ws.data_ptr())
+    assert L.adayolo_conv_chain_tables(args[0], args[1], img.ctypes.data_as(ctypes.c_void_p), img.size, info) == 0
+    total, _, _, _, off_deps, _ = list(info)
+    deps = img[off_deps:off_deps + 16 * total].view(np.int32).reshape(total, 4)
+    victim = int(np.nonzero(deps[:, 1] >> 16)[0][0])
+    wsi = ws.view(torch.int32)
+    word = off_deps // 4 + 4 * victim + 1
+    good = int(wsi[word])
+    wsi[word] = (good & ~0xFFFF) | 0x7FFF
+    eng(x)                                                           # this forward is wrong, and returns normally
+    torch.cuda.synchronize()
+    wsi[word] = good
+    with pytest.raises(_lib.AdayoloError, match="gave up"):
+        eng(x)                                                       # ... the next one says so before it launches anything
+    with pytest.raises(_lib.AdayoloError, match="gave up"):
+        eng.check_chains(sync=True)
+
+
+def test_chain_fwd_refuses_a_workspace_prepared_for_another_list():
+    from adaptiveisp_amd.yolo import _lib
+    L = _lib.load()
+    net = _Net(2, 40, 48, 128, 2, seed=5)
+    run = net.chain()
+    arr, ws = run.keep
+    n = len(net.layers)
+    vp = ctypes.c_void_p
+    assert L.adayolo_conv_chain_fwd(arr, n, vp(ws.data_ptr()), ws.numel(), _lib.stream_ptr()) == 0
+    assert L.adayolo_conv_chain_fwd(arr, n - 1, vp(ws.data_ptr()), ws.numel(), _lib.stream_ptr()) == -1
+    other = torch.empty_like(ws)
+    assert L.adayolo_conv_chain_fwd(arr, n, vp(other.data_ptr()), other.numel(), _lib.stream_ptr()) == -1     # never prepared
+    torch.cuda.synchronize()
 
 
 def test_chain_refuses_what_it_does_not_serve():

@@ -32,6 +32,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 import re
 
 WINDOW = 4                                  # runs per label that decide "varies" and set the tolerance
+# Labels whose reference side (or both sides) runs through MIOpen / rocBLAS / ATen reductions with atomics — the PyTorch heads,
+# the critic and every torch-autograd comparison. Their error is a draw from the libraries' reduction order: four samples that
+# happen to coincide do not make them deterministic, so they ALWAYS get the 16x-the-worst rule, whatever the window
+# shows. Everything else (a HIP kernel against a golden vector / the C oracle) is classed by its measured runs.
+LIBRARY_PATH = re.compile(r"^(critic_to_actor_|fused_eval_path_matches_torch_path|policy_selection|value#|teacher_forced_step:param:|"
+                          r"trunk_train\.(agent|b24|critic|value|agent_step)\.|yolo\.pair_engine\.)")
 
 
 def newest_round_files():
@@ -78,7 +84,7 @@ for label, rs in sorted(runs.items()):
         continue
     rs = rs[-WINDOW:]                       # the runs of the current tree
     cap_r, cap_a = max(r["cap_r"] for r in rs), max(r["cap_a"] for r in rs)
-    varies = len({(r["max_abs"], r["max_rel"]) for r in rs}) > 1
+    varies = len({(r["max_abs"], r["max_rel"]) for r in rs}) > 1 or bool(LIBRARY_PATH.match(label))
     if varies:
         nondet.append(label)
         rtol = min(cap_r, up(max(16.0 * max(r["max_rel"] for r in rs), cap_r / 50.0, 2.4e-7))) if cap_r > 0 else 0.0
