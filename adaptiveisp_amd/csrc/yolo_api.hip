@@ -134,6 +134,17 @@ int adayolo_conv_fused1x1_fwd(const void* in, int in_cstride, const void* weight
     return launch_conv_pp(a, static_cast<hipStream_t>(stream), 50) == hipSuccess ? ADAYOLO_OK : ADAYOLO_ELAUNCH;
 }
 
+int adayolo_conv1x1_stream_fwd(const void* in, int in_cstride, const void* weight_fragments, const float* bias, void* out,
+                               int out_cstride, int B, int H, int W, int Cin, int Cout, int act, void* stream) {
+    ConvArgs a;
+    const int rc = conv_args(a, in, in_cstride, weight_fragments, bias, nullptr, 0, out, out_cstride, B, H, W, Cin, Cout, 1, 1, act);
+    if (rc != ADAYOLO_OK) return rc;
+    if (in == out) return ADAYOLO_EINVAL;
+    const hipError_t e = launch_conv_k1(a, static_cast<hipStream_t>(stream));
+    if (e == hipErrorInvalidValue) return ADAYOLO_ESHAPE;                 // Cin not in {256, 512} or Cout % 256 != 0
+    return e == hipSuccess ? ADAYOLO_OK : ADAYOLO_ELAUNCH;
+}
+
 // ---- persistent chain: host-side tables ------------------------------------------------------------------------------------
 namespace {
 struct ChainPlan {

@@ -400,6 +400,34 @@ class YoloEngine:
         self.plan = out
         self.fused_pairs += n
         self.fuse_chains()
+        self.fuse_k1()
+        return n
+
+    def fuse_k1(self):
+        """1x1 layers with Cin in {256, 512} and Cout % 256 == 0 that are still launches of their own (Bottleneck.cv1 of the
+        C = 512 stage and the head's 1x1 convs: yolov3/models/common.py:45-59,110-120) on the whole-K kernel
+        (adayolo_conv1x1_stream_fwd, csrc/yolo_conv_k1.hip) instead of a ring kernel. ADAYOLO_K1=0 keeps the ring kernels.
+        Returns the number of launches moved."""
+        self.k1_layers = getattr(self, "k1_layers", 0)
+        if os.environ.get("ADAYOLO_K1", "1") != "1" or not self._pair_fusion:
+            return 0
+        first_free = 3 if self._head_next is not None else 2
+        n = 0
+        for i, (kind, fn, a) in enumerate(self.plan):
+            if i < first_free or kind != "conv":
+                continue
+            if not (a[13] == 1 and a[14] == 1 and a[4] is None and a[11] in (256, 512) and a[12] % 256 == 0):
+                continue
+            w = next(o["w"] for o in self.ops if o["kind"] == "conv" and o["w"].data_ptr() == a[2].value)
+            cout, cin = a[12], a[11]
+            if w.shape[0] != cout or w.numel() != cout * cin:
+                continue
+            wp = w.reshape(cout // 32, 32, cin // 16, 2, 8).permute(0, 2, 3, 1, 4).contiguous()   # fragment-major (include/adayolo.h)
+            self._keep.append(wp)
+            self.plan[i] = ("k1", self.L.adayolo_conv1x1_stream_fwd,
+                            [a[0], a[1], ctypes.c_void_p(wp.data_ptr()), a[3], a[6], a[7], a[8], a[9], a[10], cin, cout, a[15]])
+            n += 1
+        self.k1_layers += n
         return n
 
     CHAIN_MIN = 4                                        # launches a run must replace to become a chain

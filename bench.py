@@ -34,7 +34,7 @@ TUNE_CACHE = os.path.join(ROOT, "adaptiveisp_amd", "yolo", "tuning", "mi355x.jso
 CONV_KERNEL_NAMES = {2: "dma::k_conv_igemm_dma<128,128,2,2,2>", 5: "dma2::k_conv_igemm_dma32<128,128,2,2,2,0,64,1>",
                      22: "dma2::k_conv_igemm_dma32<128,64,4,1,4,0,32,1>", 26: "dma2::k_conv_igemm_dma32<128,256,2,4,3,0,32,4>",
                      27: "dma2::k_conv_igemm_dma32<256,128,4,2,3,0,32,4>", 40: "smallk::k_conv3x3_small<...>",
-                     50: "pp::k_conv_pp<0, false>", 57: "pp::k_conv_chain", 58: "pp::k_conv_pp<0, true>", 59: "bnk::k_bneck<0>", 60: "pp128::k_conv_pp128<0, false>", 80: "pq::k_conv_pq<0, 4>", 85: "pq::k_conv_pq<0, 2>", 90: "ws::k_conv_ws<...>"}
+                     50: "pp::k_conv_pp<0, false>", 57: "pp::k_conv_chain", 58: "pp::k_conv_pp<0, true>", 59: "bnk::k_bneck<0>", 60: "pp128::k_conv_pp128<0, false>", 70: "k1::k_conv_k1<...>", 80: "pq::k_conv_pq<0, 4>", 85: "pq::k_conv_pq<0, 2>", 90: "ws::k_conv_ws<...>"}
 
 
 _T0 = time.perf_counter()
@@ -423,6 +423,9 @@ def time_conv_kernels(engine, x, reps=20, runner=None):
             return 59, 2.0 * B * H * W * (256 * 128 + 9 * 128 * 256)
         if kind == "chain":             # a run of 256 x 256-kernel layers as one persistent launch (YoloEngine.fuse_chains)
             return 57, next(c["flops"] for c in engine.chains if c["ws"].data_ptr() == args[2].value)
+        if kind == "k1":                # a 1x1 layer on the whole-K kernel (YoloEngine.fuse_k1)
+            B, H, W, cin, cout = args[6:11]
+            return 70, 2.0 * B * H * W * cin * cout
         if kind not in ("conv", "conv2"):
             return None, 0.0
         B, H, W, cin, cout, k, s = args[8:15]
@@ -549,6 +552,24 @@ def rocprof_reference(kernel_name):
     return None, None
 
 
+def rocprof_top_conv_kernel(kernels):
+    """The entry of `kernels` (time_conv_kernels' table) whose kernel is the highest row of the newest committed rocprofv3
+    kernel-stats CSV that names one of them; None without a profile."""
+    import csv
+    names = {r["kernel"].split("::")[-1].replace(" ", ""): r for r in kernels}
+    for path in newest_profiles("rocprofv3_kernel_stats.csv"):
+        try:
+            rows = sorted(csv.DictReader(open(path)), key=lambda r: -float(r["TotalDurationNs"]))
+        except Exception:
+            continue
+        for r in rows:
+            nm = r["Name"].replace(" ", "")
+            for key, ent in names.items():
+                if key and key in nm:
+                    return ent
+    return None
+
+
 def _timed(fn, repeats=3):
     """1 warm-up + `repeats` timed runs -> (min, median) seconds (SURVEY 8(d) protocol)."""
     fn()
@@ -667,22 +688,33 @@ def cpu_baseline(a, sched):
     all_cores = None
     if ncpu > threads:
         import subprocess
-        mark(f"cpu_baseline: all-cores probe ({ncpu} threads, child process, {ALL_CORES_LIMIT_S} s limit)")
-        try:
-            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-probe", str(ncpu), "--height", str(a.height),
-                                "--width", str(a.width), "--schedule", a.schedule], capture_output=True, text=True,
-                               timeout=ALL_CORES_LIMIT_S, cwd=ROOT)
-            rec = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
-            sa, da = rec["isp_step_s"], rec["detector_s"]
-            all_cores = {"threads": ncpu, "isp_step_s": round(sa, 3), "detector_s": round(da, 3),
-                         "images_per_sec": round(1.0 / (nsteps * sa + da), 4), "repeats": 1,
-                         "vs_value": round((1.0 / (nsteps * sa + da)) / (1.0 / (isp_ref + d_med)), 3)}
-        except subprocess.TimeoutExpired:
-            all_cores = {"threads": ncpu, "timeout_s": ALL_CORES_LIMIT_S,
-                         "note": f"1 warm-up + 1 repeat of the reference step and the detector did not finish within the limit with {ncpu} "
-                                 f"threads (the {threads}-thread figure above takes ~{2 * (step_med + d_med):.0f} s for the same work)"}
-        except Exception as e:                               # noqa: BLE001
-            all_cores = {"error": f"{type(e).__name__}: {e}"}
+        # every hardware thread first; if that does not finish inside its limit (on this pool's hosts the 256-thread run of the
+        # ~2000-op reference step degenerates into OpenMP spin-waits), half of them — so that `all_cores` carries a NUMBER
+        # (VERDICT r5 item 7), plus the record of what timed out
+        tried = []
+        for nthr, limit in ((ncpu, ALL_CORES_LIMIT_S), (max(threads + 1, ncpu // 2), ALL_CORES_LIMIT_S)):
+            if nthr <= threads or any(t["threads"] == nthr for t in tried):
+                continue
+            mark(f"cpu_baseline: all-cores probe ({nthr} threads, child process, {limit} s limit)")
+            try:
+                r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-probe", str(nthr), "--height", str(a.height),
+                                    "--width", str(a.width), "--schedule", a.schedule], capture_output=True, text=True,
+                                   timeout=limit, cwd=ROOT)
+                rec = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+                sa, da = rec["isp_step_s"], rec["detector_s"]
+                all_cores = {"threads": nthr, "isp_step_s": round(sa, 3), "detector_s": round(da, 3),
+                             "value": round(1.0 / (nsteps * sa + da), 4), "unit": "images/sec",
+                             "images_per_sec": round(1.0 / (nsteps * sa + da), 4), "repeats": 1,
+                             "vs_value": round((1.0 / (nsteps * sa + da)) / (1.0 / (isp_ref + d_med)), 3), "timed_out": tried}
+                break
+            except subprocess.TimeoutExpired:
+                tried.append({"threads": nthr, "timeout_s": limit})
+            except Exception as e:                               # noqa: BLE001
+                tried.append({"threads": nthr, "error": f"{type(e).__name__}: {e}"})
+        if all_cores is None:
+            all_cores = {"timed_out": tried,
+                         "note": f"1 warm-up + 1 repeat of the reference step and the detector did not finish within the limit at any "
+                                 f"thread count above {threads} (the {threads}-thread figure takes ~{2 * (step_med + d_med):.0f} s for the same work)"}
     r3 = lambda v: round(v, 3)  # noqa: E731
     return {"all_cores": all_cores, "value": round(1.0 / (isp_ref + d_med), 4), "value_from": "medians", "value_min_times": round(1.0 / (nsteps * step_min + d_min), 4),
             "unit": "images/sec", "cores": threads, "kind": "port",
@@ -1145,13 +1177,26 @@ def main():
                     # includes the few launches that time-slice a CU with an NLM workgroup (std dev ~ the mean)
                     "rocprof_avg_launch_ms": round(ref_ms, 4) if ref_ms else None, "rocprof_source": ref_src}
 
-        line["roofline"] = roof(d["kernels"][0])        # dominant = largest total time
+        # Which kernel the top-level `roofline` names: the TOP ROW of the committed rocprofv3 summary of this command when it is
+        # one of the detector's conv kernels (so the fraction cannot move because kernels were re-partitioned and the live
+        # shares of three near-equal kernels swapped places: VERDICT r5 weak #7); the largest live share otherwise
+        dom, dom_rule = d["kernels"][0], "largest live share of conv time"
+        top = rocprof_top_conv_kernel(d["kernels"]) if at_baseline else None
+        if top is not None:
+            dom, dom_rule = top, "top row of the committed rocprofv3 kernel stats"
+        line["roofline"] = roof(dom)
+        line["roofline"]["chosen_by"] = dom_rule
+        # ... and the WHOLE detector against the same roof (all launches of one forward, detector alone on the chip): the figure
+        # that moves only when the detector gets faster
+        line["roofline"]["detector"] = {"ms": round(d["detector_ms"], 3), "tflops": round(d["detector_tflops"], 1),
+                                        "frac": round(d["detector_tflops"] / MFMA_BF16_PEAK_TFLOPS, 4),
+                                        "flops_per_forward": engine.flops, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s"}
         line["roofline"]["measured"] = (f"HIP event pair around every launch, in the network, {d['reps']} forwards; avg_launch_ms = " +
                                         ("in the headline's arrangement (next batch's ISP filters between the layers, its policy on a "
                                          "second stream)" if pipelined == "interleaved" else
                                          "beside the ISP episode of the next batch on a second stream (the headline's arrangement)"
                                          if pipelined else "single stream") + "; *_clean = detector alone")
-        line["roofline"]["other_kernels"] = [roof(r) for r in d["kernels"][1:4]]
+        line["roofline"]["other_kernels"] = [roof(r) for r in d["kernels"] if r is not dom][:3]
         # live figures vs the committed rocprofv3 summary of the same command. rocprofv3 times a dispatch from its first
         # workgroup's start to its last one's end; an event pair on the stream also contains the time a launch WAITS for CUs —
         # in the two-stream arrangement the detector's first small launches queue behind NLM's workgroups (3 x 48.5 KB of LDS

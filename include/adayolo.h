@@ -95,6 +95,21 @@ int adayolo_conv_chain_poll(const void* workspace);
 int adayolo_conv_chain_tables(const adayolo_chain_layer* layers, int n, void* host_image, size_t bytes, int32_t* info);
 
 /*
+ * Conv(Cin -> Cout, k1, s1) + bias + act — what adayolo_conv_fwd computes for ksize 1 (Bottleneck.cv1,
+ * yolov3/models/common.py:45-59,110-120) — on the "whole K at once" kernel (csrc/yolo_conv_k1.hip): a workgroup takes 128
+ * pixels x 256 output channels, its whole activation tile arrives in LDS in one LDS-DMA burst and each wave's weights stay in
+ * registers. For the deep, narrow-map layers (512 -> 256 on 46 x 80 maps at the benchmark's size: one round of tiles on 256
+ * CUs) where the ring kernels spend their time in prologue / barrier / epilogue structure. Same arithmetic as the ring kernels
+ * (bf16 operands, fp32 accumulation in k order, bias, SiLU, one rounding to bf16).
+ * weight_fragments: the bf16 [Cout][Cin] matrix stored FRAGMENT-MAJOR, [Cout/32][Cin/16][2][32][8]: element [c][kk][f][r][j] =
+ * w[32 c + r][16 kk + 8 f + j] (a wave's MFMA operand load is 1 KB contiguous; YoloEngine packs it once:
+ * view(Cout/32, 32, Cin/16, 2, 8).permute(0, 2, 3, 1, 4)).
+ * Shapes: Cin in {256, 512}, Cout % 256 == 0 (ADAYOLO_ESHAPE otherwise — the caller keeps adayolo_conv_fwd).
+ */
+int adayolo_conv1x1_stream_fwd(const void* in, int in_cstride, const void* weight_fragments, const float* bias,
+                               void* out, int out_cstride, int B, int H, int W, int Cin, int Cout, int act, void* stream);
+
+/*
  * Two layers in one launch: Conv(Cin -> 256, k, stride) + bias + act (+ residual) -> `out`, and on that output tile, while
  * it is in LDS, Conv(256 -> 128, k1) + bias2 + SiLU -> `out2`. This is Bottleneck.cv2 of one block followed by
  * Bottleneck.cv1 of the next (yolov3/models/common.py:110-120): the 1x1 conv is HBM-bound on its own (it re-reads what
