@@ -406,10 +406,13 @@ class YoloEngine:
     def fuse_k1(self):
         """1x1 layers with Cin in {256, 512} and Cout % 256 == 0 that are still launches of their own (Bottleneck.cv1 of the
         C = 512 stage and the head's 1x1 convs: yolov3/models/common.py:45-59,110-120) on the whole-K kernel
-        (adayolo_conv1x1_stream_fwd, csrc/yolo_conv_k1.hip) instead of a ring kernel. ADAYOLO_K1=0 keeps the ring kernels.
+        (adayolo_conv1x1_stream_fwd, csrc/yolo_conv_k1.hip) instead of a ring kernel. OFF by default (ADAYOLO_K1=1 turns it on):
+        measured in round 6 (profiles/round6_k1_ab.txt) the whole-K kernel is no faster than the 256 x 128 ring kernel on these
+        layers (512 -> 256 @46x80: 16.2-17.4 vs 13.5-16.0 us back to back, detector 3.356 vs 3.339 ms) — a CU's operand ingest
+        (128 KB of activations + 256 KB of weights per 128 px x 256 ch of output) bounds both, not the k-loop's structure.
         Returns the number of launches moved."""
         self.k1_layers = getattr(self, "k1_layers", 0)
-        if os.environ.get("ADAYOLO_K1", "1") != "1" or not self._pair_fusion:
+        if os.environ.get("ADAYOLO_K1", "0") != "1" or not self._pair_fusion:
             return 0
         first_free = 3 if self._head_next is not None else 2
         n = 0
