@@ -20,7 +20,7 @@ LIBS = {
         headers=["isp_internal.h", "../../include/adaisp.h"],
         flags=ISP_FLAGS),
     "libadayolo.so": dict(
-        sources=["yolo_conv_dma.hip", "yolo_conv_dma2.hip", "yolo_conv_small.hip", "yolo_conv_pp.hip", "yolo_conv_chain.hip", "yolo_bneck.hip", "yolo_conv_pp128.hip", "yolo_conv_k1.hip", "yolo_conv_pq.hip", "yolo_conv_ws.hip", "yolo_misc.hip", "yolo_stem_down.hip", "yolo_nms.hip", "yolo_train.hip", "yolo_loss.hip", "yolo_api.hip"],
+        sources=["yolo_conv_dma.hip", "yolo_conv_dma2.hip", "yolo_conv_small.hip", "yolo_conv_pp.hip", "yolo_conv_chain.hip", "yolo_bneck.hip", "yolo_bneck_ws.hip", "yolo_conv_pp128.hip", "yolo_conv_k1.hip", "yolo_conv_pq.hip", "yolo_conv_ws.hip", "yolo_misc.hip", "yolo_stem_down.hip", "yolo_nms.hip", "yolo_train.hip", "yolo_loss.hip", "yolo_api.hip"],
         # (yolo_conv_chain.hip compiles the tile bodies of yolo_conv_pp.hip / yolo_conv_pp128.hip into its own translation unit:
         # a change to either rebuilds it)
         headers=["yolo_internal.h", "yolo_chain.h", "yolo_conv_pp.hip", "yolo_conv_pp128.hip", "../../include/adayolo.h"],

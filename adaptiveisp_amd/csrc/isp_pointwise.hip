@@ -328,6 +328,15 @@ __global__ __launch_bounds__(kThreads) void k_pointwise(const float* __restrict_
 #ifndef ISP_POOL_ROWS
 #define ISP_POOL_ROWS 3
 #endif
+// Round 6: a row that belongs to TWO pool windows (three of every four window boundaries at H = 720: 12-row windows on an
+// 11.25-row pitch) is read by both windows' workgroups — with non-temporal loads twice from the fabric (+6.7 % of the reads:
+// profiles/round5_pmc_traffic.json, 94.4 MB fetched per launch against 88.6). ISP_POOL_SHARED_L2 = 1: exactly those rows are
+// read with PLAIN loads (they allocate in the XCD's L2; everything else stays non-temporal and leaves the L2 to them: 48 rows x
+// 15 KB x 8 images = 5.9 MB over eight 4 MB L2s), and consecutive pool rows run on ONE XCD (workgroup bx of an image sits on XCD
+// bx % 8: pool row oy = (bx % 8) * 8 + bx / 8), so the second reader finds the row where the first one left it.
+#ifndef ISP_POOL_SHARED_L2
+#define ISP_POOL_SHARED_L2 1
+#endif
 #ifndef ISP_POOL_PIPE
 #define ISP_POOL_PIPE 0
 #endif
@@ -364,7 +373,7 @@ template <> struct PoolWalk<OpSatPlus> { static constexpr int rows = ISP_POOL_RO
 template <class OP>
 __device__ __forceinline__ void stream_pool(const OP& op, const float* __restrict__ in, float* __restrict__ out,
                                             int H, int W, int ys, int ye, int y_own_end,
-                                            int x, bool active, const Clip clip, float4 (&acc)[3]) {
+                                            int x, bool active, const Clip clip, float4 (&acc)[3], int y_shared_top, int y_shared_bot) {
     constexpr int R = PoolWalk<OP>::rows;
     const long plane = (long)H * W;
     const int xs = active ? x : 0;                      // inactive lanes (beyond a ragged right edge) read a valid quad and drop it
@@ -374,10 +383,17 @@ __device__ __forceinline__ void stream_pool(const OP& op, const float* __restric
     auto load = [&](float4 (&r)[R], float4 (&g)[R], float4 (&b)[R], int y0) {
 #pragma unroll
         for (int u = 0; u < R; ++u) {
-            const long o = (long)min(y0 + u, ye - 1) * W + xs;
-            r[u] = ld4(reinterpret_cast<const float4*>(in + o));
-            g[u] = ld4(reinterpret_cast<const float4*>(in + plane + o));
-            b[u] = ld4(reinterpret_cast<const float4*>(in + 2 * plane + o));
+            const int yy = min(y0 + u, ye - 1);
+            const long o = (long)yy * W + xs;
+            if (ISP_POOL_SHARED_L2 && (yy == y_shared_top || yy == y_shared_bot)) {       // (wave-uniform) the rows two windows share
+                r[u] = *reinterpret_cast<const float4*>(in + o);
+                g[u] = *reinterpret_cast<const float4*>(in + plane + o);
+                b[u] = *reinterpret_cast<const float4*>(in + 2 * plane + o);
+            } else {
+                r[u] = ld4(reinterpret_cast<const float4*>(in + o));
+                g[u] = ld4(reinterpret_cast<const float4*>(in + plane + o));
+                b[u] = ld4(reinterpret_cast<const float4*>(in + 2 * plane + o));
+            }
         }
     };
     auto work = [&](float4 (&r)[R], float4 (&g)[R], float4 (&b)[R], int y0) {
@@ -432,7 +448,7 @@ constexpr int kOpRuntime = -2;
 template <class OP>
 __device__ __forceinline__ void pool_strips(const float* __restrict__ in, float* __restrict__ o, const float* __restrict__ p,
                                             float* __restrict__ colsum, int H, int W, int ys, int ye, int y_own_end,
-                                            const Clip clip) {
+                                            const Clip clip, int y_shared_top, int y_shared_bot) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nwaves = (int)blockDim.x >> 6;
     const int strips = (W + 255) >> 8, Wp = strips << 8;
     OP op;
@@ -442,7 +458,7 @@ __device__ __forceinline__ void pool_strips(const float* __restrict__ in, float*
         float4 acc[3];
 #pragma unroll
         for (int c = 0; c < 3; ++c) acc[c] = make_float4(0.f, 0.f, 0.f, 0.f);
-        stream_pool<OP>(op, in, o, H, W, ys, ye, y_own_end, x, x < W, clip, acc);
+        stream_pool<OP>(op, in, o, H, W, ys, ye, y_own_end, x, x < W, clip, acc, y_shared_top, y_shared_bot);
 #pragma unroll
         for (int c = 0; c < 3; ++c) *reinterpret_cast<float4*>(colsum + c * Wp + x) = acc[c];
     }
@@ -454,7 +470,11 @@ void k_pointwise_pool(const float* __restrict__ img, float* __restrict__ out, fl
                       const int32_t* __restrict__ ids, int uniform_op, const float* __restrict__ params, int pstride,
                       int H, int W, unsigned flags) {
     extern __shared__ __attribute__((aligned(16))) float colsum[];      // [3][Wp], Wp = 256 x strips
+#if ISP_POOL_SHARED_L2
+    const int oy = ((int)blockIdx.x & 7) * 8 + ((int)blockIdx.x >> 3), b = blockIdx.y;      // consecutive pool rows on one XCD
+#else
     const int oy = blockIdx.x, b = blockIdx.y;
+#endif
     int op = OPSEL != kOpRuntime ? OPSEL : (ids ? ids[b] : uniform_op);
     if (op_is_conv(op) || op == ADAISP_OP_NLM) return;                   // block-uniform: the whole workgroup leaves
     if (!op_is_pointwise(op)) op = ADAISP_OP_ZERO;                       // unknown id (device data): the zero image, like -1
@@ -466,7 +486,11 @@ void k_pointwise_pool(const float* __restrict__ img, float* __restrict__ out, fl
     const Clip clip((flags & ADAISP_CLIP01) != 0);
     const int ys = win_lo(oy, H), ye = win_hi(oy, H);
     const int y_own_end = oy == 63 ? H : win_lo(oy + 1, H);
-#define POOL_CASE(ID, OP) case ID: if (OPSEL == kOpRuntime || OPSEL == ID) pool_strips<OP>(in, o, p, colsum, H, W, ys, ye, y_own_end, clip); break;
+    // the rows this window shares with its neighbours (-1: none): its first row if the window above ends behind it, its last row
+    // if the window below starts on it
+    const int y_shared_top = (oy > 0 && win_hi(oy - 1, H) > ys) ? ys : -1;
+    const int y_shared_bot = (oy < 63 && win_lo(oy + 1, H) < ye) ? ye - 1 : -1;
+#define POOL_CASE(ID, OP) case ID: if (OPSEL == kOpRuntime || OPSEL == ID) pool_strips<OP>(in, o, p, colsum, H, W, ys, ye, y_own_end, clip, y_shared_top, y_shared_bot); break;
     switch (op) {
         POOL_CASE(ADAISP_OP_ZERO, OpZero) POOL_CASE(ADAISP_OP_EXPOSURE, OpExposure) POOL_CASE(ADAISP_OP_GAMMA, OpGamma)
         POOL_CASE(ADAISP_OP_WB, OpWB) POOL_CASE(ADAISP_OP_CCM, OpCCM) POOL_CASE(ADAISP_OP_TONE, OpTone)

@@ -422,6 +422,17 @@ int adayolo_bottleneck256_fwd(const void* x, int x_cstride, const void* weight1,
                                 static_cast<hipStream_t>(stream)) == hipSuccess ? ADAYOLO_OK : ADAYOLO_ELAUNCH;
 }
 
+int adayolo_bottleneck_ws_fwd(const void* x, int x_cstride, const void* weight1, const float* bias1, const void* weight2,
+                              const float* bias2, void* out, int out_cstride, int B, int H, int W, int C, void* stream) {
+    if (!x || !weight1 || !bias1 || !weight2 || !bias2 || !out || x == out) return ADAYOLO_EINVAL;
+    if (B <= 0 || H <= 0 || W <= 0) return ADAYOLO_EINVAL;
+    if ((C != 64 && C != 128) || x_cstride % 8 || out_cstride % 8 || x_cstride < C || out_cstride < C) return ADAYOLO_ESHAPE;
+    const hipError_t e = launch_bottleneck_ws(x, x_cstride, weight1, bias1, weight2, bias2, out, out_cstride, B, H, W, C,
+                                              static_cast<hipStream_t>(stream));
+    if (e == hipErrorInvalidValue) return ADAYOLO_ESHAPE;                  // a tensor beyond 32-bit byte offsets
+    return e == hipSuccess ? ADAYOLO_OK : ADAYOLO_ELAUNCH;
+}
+
 int adayolo_conv_keep_fwd(const void* in, int in_cstride, const void* weight, const float* bias, const void* residual,
                           int res_cstride, void* out, int out_cstride, void* pre, int pre_cstride, int B, int H, int W, int Cin,
                           int Cout, int ksize, int stride, int act, int variant, void* stream) {

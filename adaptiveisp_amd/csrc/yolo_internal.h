@@ -129,6 +129,9 @@ hipError_t launch_conv_pp128_splitk(ConvArgs a, hipStream_t s, int S, void* work
 // one Bottleneck (1x1 256 -> 128 + SiLU, 3x3 128 -> 256 + SiLU, + x) per launch, hidden tensor in LDS (yolo_bneck.hip)
 hipError_t launch_bottleneck256(const void* x, int x_cs, const void* w1, const float* b1, const void* w2, const float* b2,
                                 void* out, int out_cs, int B, int H, int W, hipStream_t s);
+// one Bottleneck of the shallow stages (C = 64 / 128) per launch: weights in registers, x patch by LDS-DMA, h in LDS (yolo_bneck_ws.hip)
+hipError_t launch_bottleneck_ws(const void* x, int x_cs, const void* w1, const float* b1, const void* w2, const float* b2,
+                                void* out, int out_cs, int B, int H, int W, int C, hipStream_t s);
 hipError_t launch_conv_k1(ConvArgs a, hipStream_t s);                 // 1x1, whole K at once: weights in registers (fragment-major copy), activation tile in LDS (yolo_conv_k1.hip)
 hipError_t launch_conv_pq(ConvArgs a, hipStream_t s, int variant);    // 256x128, 4 waves, two workgroups per CU (yolo_conv_pq.hip)
 hipError_t launch_conv_ws(ConvArgs a, hipStream_t s, int variant);    // 3x3 s1, Cin 32 / 64: weights in registers, patch in LDS, persistent (yolo_conv_ws.hip)

@@ -9,7 +9,7 @@ _HERE = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB_PATH = os.environ.get("ADAYOLO_LIB") or os.path.join(_HERE, "csrc", "libadayolo.so")
 ABI_VERSION = 9
 ACT_NONE, ACT_SILU = 0, 1
-EXPORTS = ("adayolo_conv_fwd", "adayolo_conv_fwd_variant", "adayolo_conv_fused1x1_fwd", "adayolo_conv1x1_stream_fwd", "adayolo_bottleneck256_fwd", "adayolo_conv_keep_fwd", "adayolo_conv_splitk_fwd", "adayolo_conv_dsilu_fwd", "adayolo_conv_s2grad_fwd", "adayolo_conv_splitk_workspace_bytes", "adayolo_conv_chain_workspace_bytes", "adayolo_conv_chain_prepare", "adayolo_conv_chain_fwd", "adayolo_conv_chain_status", "adayolo_conv_chain_poll", "adayolo_conv_chain_tables", "adayolo_stem_fwd", "adayolo_upsample2x", "adayolo_detect_decode", "adayolo_nms", "adayolo_nms_workspace_bytes", "adayolo_stem_fwd_act", "adayolo_stem_keep_fwd", "adayolo_stem_down_fwd", "adayolo_letterbox_pack", "adayolo_silu_fwd", "adayolo_silu_bwd",
+EXPORTS = ("adayolo_conv_fwd", "adayolo_conv_fwd_variant", "adayolo_conv_fused1x1_fwd", "adayolo_conv1x1_stream_fwd", "adayolo_bottleneck256_fwd", "adayolo_bottleneck_ws_fwd", "adayolo_conv_keep_fwd", "adayolo_conv_splitk_fwd", "adayolo_conv_dsilu_fwd", "adayolo_conv_s2grad_fwd", "adayolo_conv_splitk_workspace_bytes", "adayolo_conv_chain_workspace_bytes", "adayolo_conv_chain_prepare", "adayolo_conv_chain_fwd", "adayolo_conv_chain_status", "adayolo_conv_chain_poll", "adayolo_conv_chain_tables", "adayolo_stem_fwd", "adayolo_upsample2x", "adayolo_detect_decode", "adayolo_nms", "adayolo_nms_workspace_bytes", "adayolo_stem_fwd_act", "adayolo_stem_keep_fwd", "adayolo_stem_down_fwd", "adayolo_letterbox_pack", "adayolo_silu_fwd", "adayolo_silu_bwd",
            "adayolo_zero_insert2x", "adayolo_upsample2x_bwd", "adayolo_image_grad", "adayolo_detloss_fwd", "adayolo_detloss_bwd",
            "adayolo_strerror",
            "adayolo_abi_version")
@@ -60,6 +60,8 @@ def load():
     L.adayolo_conv_fused1x1_fwd.restype = ci
     L.adayolo_bottleneck256_fwd.argtypes = [vp, ci, vp, vp, vp, vp, vp, ci, ci, ci, ci, vp]
     L.adayolo_bottleneck256_fwd.restype = ci
+    L.adayolo_bottleneck_ws_fwd.argtypes = [vp, ci, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, vp]
+    L.adayolo_bottleneck_ws_fwd.restype = ci
     L.adayolo_conv_keep_fwd.argtypes = [vp, ci, vp, vp, vp, ci, vp, ci, vp, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, vp]
     L.adayolo_conv_keep_fwd.restype = ci
     L.adayolo_stem_fwd.argtypes = [vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, cf, ci, vp]

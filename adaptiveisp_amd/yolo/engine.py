@@ -51,6 +51,9 @@ def _pack_conv(w, b, pad_cout_to=None):
     return w.to(torch.bfloat16).contiguous(), b
 
 
+BNECK_WS_DEFAULT = "1"       # whole-Bottleneck launches for the C = 64 / 128 stages (YoloEngine.fuse_bottlenecks_ws)
+
+
 class YoloEngine:
     def __init__(self, model: DetectionModel, batch, height, width, device="cuda:0", head_chunks=None):
         """`head_chunks`: run the stem and the first down-sampling conv depth-first over this many batch chunks, so the
@@ -87,7 +90,10 @@ class YoloEngine:
                 n = self.ops[2] if len(self.ops) > 2 else None       # Bottleneck.cv1 of layer 2: 1x1, 64 -> 32
                 if n is not None and n["kind"] == "conv" and n["src"] is o["dst"] and n["res"] is None and \
                         (n["k"], n["s"], n["act"], n["cout"], n["src"].C) == (1, 1, _lib.ACT_SILU, 32, 64) and \
-                        self.plan[2][0] == "conv" and os.environ.get("ADAYOLO_FUSE_HEAD_NEXT", "1") == "1":
+                        self.plan[2][0] == "conv" and os.environ.get("ADAYOLO_FUSE_HEAD_NEXT", "1") == "1" and \
+                        os.environ.get("ADAYOLO_BNECK_WS", BNECK_WS_DEFAULT) != "1":
+                    # (with the whole-Bottleneck kernel for the shallow stages the block's own launch computes cv1: k_stem_down
+                    # neither computes nor writes the hidden tensor)
                     self._head_next = n
         if self.B % head_chunks:
             raise ValueError(f"head_chunks={head_chunks} does not divide the batch {self.B}")
@@ -374,6 +380,7 @@ class YoloEngine:
         number of fused pairs."""
         self.fused_pairs = getattr(self, "fused_pairs", 0)
         if self._pair_fusion:
+            self.fuse_bottlenecks_ws()
             self.fuse_bottlenecks()
         if not self._pair_fusion or os.environ.get("ADAYOLO_FUSE_1X1", "1") != "1":
             return 0
@@ -535,6 +542,36 @@ class YoloEngine:
             raise _lib.AdayoloError(f"persistent conv chain: the dependency wait of work item {code - 1} gave up after 1 s — the "
                                     f"forward that contained it ran on incomplete inputs (ADAYOLO_CHAIN=0 runs the layers as "
                                     f"separate launches)")
+
+    def fuse_bottlenecks_ws(self):
+        """A whole Bottleneck of the shallow stages — cv1 (1x1 C -> C/2 + SiLU) and cv2 (3x3 C/2 -> C + SiLU, + the block's
+        input), C = 64 on 368 x 640 maps and C = 128 on 184 x 320 at the benchmark's size (yolov3/models/common.py:110-120,
+        yolov3.yaml:13-27) — as ONE launch with the hidden tensor in LDS (adayolo_bottleneck_ws_fwd, csrc/yolo_bneck_ws.hip)
+        wherever the plan holds exactly that pair. ADAYOLO_BNECK_WS=0 keeps the two launches. Returns the number of fused blocks."""
+        self.fused_ws_blocks = getattr(self, "fused_ws_blocks", 0)
+        if os.environ.get("ADAYOLO_BNECK_WS", BNECK_WS_DEFAULT) != "1":
+            return 0
+        out, i, n, P = [], 0, 0, self.plan
+        first_free = 3 if self._head_next is not None else 2
+        while i < len(P):
+            kind, fn, a = P[i]
+            if i >= first_free and kind == "conv" and i + 1 < len(P) and P[i + 1][0] == "conv":
+                b = P[i + 1][2]
+                C = a[11]
+                if (C in (64, 128) and (a[12], a[13], a[14], a[15]) == (C // 2, 1, 1, _lib.ACT_SILU) and a[4] is None and
+                        (b[11], b[12], b[13], b[14], b[15]) == (C // 2, C, 3, 1, _lib.ACT_SILU) and b[4] is not None and
+                        b[4].value == a[0].value and b[5] == a[1] and b[0].value == a[6].value and b[1] == a[7] and
+                        (b[8], b[9], b[10]) == (a[8], a[9], a[10]) and b[6].value != a[0].value and
+                        2 * a[8] * a[9] * a[10] * max(a[1], b[7]) + 256 <= 0xFFFFFF00):
+                    out.append(("bneckws", self.L.adayolo_bottleneck_ws_fwd,
+                                [a[0], a[1], a[2], a[3], b[2], b[3], b[6], b[7], a[8], a[9], a[10], C]))
+                    i, n = i + 2, n + 1
+                    continue
+            out.append(P[i])
+            i += 1
+        self.plan = out
+        self.fused_ws_blocks += n
+        return n
 
     def fuse_bottlenecks(self):
         """A whole Bottleneck of the C = 256 stage — cv1 (1x1 256 -> 128 + SiLU) and cv2 (3x3 128 -> 256 + SiLU, + the block's

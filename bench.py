@@ -34,7 +34,7 @@ TUNE_CACHE = os.path.join(ROOT, "adaptiveisp_amd", "yolo", "tuning", "mi355x.jso
 CONV_KERNEL_NAMES = {2: "dma::k_conv_igemm_dma<128,128,2,2,2>", 5: "dma2::k_conv_igemm_dma32<128,128,2,2,2,0,64,1>",
                      22: "dma2::k_conv_igemm_dma32<128,64,4,1,4,0,32,1>", 26: "dma2::k_conv_igemm_dma32<128,256,2,4,3,0,32,4>",
                      27: "dma2::k_conv_igemm_dma32<256,128,4,2,3,0,32,4>", 40: "smallk::k_conv3x3_small<...>",
-                     50: "pp::k_conv_pp<0, false>", 57: "pp::k_conv_chain", 58: "pp::k_conv_pp<0, true>", 59: "bnk::k_bneck<0>", 60: "pp128::k_conv_pp128<0, false>", 70: "k1::k_conv_k1<...>", 80: "pq::k_conv_pq<0, 4>", 85: "pq::k_conv_pq<0, 2>", 90: "ws::k_conv_ws<...>"}
+                     50: "pp::k_conv_pp<0, false>", 57: "pp::k_conv_chain", 58: "pp::k_conv_pp<0, true>", 59: "bnk::k_bneck<0>", 61: "bws::k_bneck_ws<...>", 60: "pp128::k_conv_pp128<0, false>", 70: "k1::k_conv_k1<...>", 80: "pq::k_conv_pq<0, 4>", 85: "pq::k_conv_pq<0, 2>", 90: "ws::k_conv_ws<...>"}
 
 
 _T0 = time.perf_counter()
@@ -423,6 +423,9 @@ def time_conv_kernels(engine, x, reps=20, runner=None):
             return 59, 2.0 * B * H * W * (256 * 128 + 9 * 128 * 256)
         if kind == "chain":             # a run of 256 x 256-kernel layers as one persistent launch (YoloEngine.fuse_chains)
             return 57, next(c["flops"] for c in engine.chains if c["ws"].data_ptr() == args[2].value)
+        if kind == "bneckws":           # a whole Bottleneck of the C = 64 / 128 stages (YoloEngine.fuse_bottlenecks_ws)
+            B, H, W, C = args[8:12]
+            return 61, 2.0 * B * H * W * (C * (C // 2) + 9 * (C // 2) * C)
         if kind == "k1":                # a 1x1 layer on the whole-K kernel (YoloEngine.fuse_k1)
             B, H, W, cin, cout = args[6:11]
             return 70, 2.0 * B * H * W * cin * cout

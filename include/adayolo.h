@@ -146,6 +146,21 @@ int adayolo_bottleneck256_fwd(const void* x, int x_cstride,
                               int B, int H, int W, void* stream);
 
 /*
+ * The same for the SHALLOW stages — C = 128 (hidden 64: the two blocks on 184 x 320 maps at the benchmark's size) and C = 64
+ * (hidden 32: the block on 368 x 640 maps), yolov3/models/common.py:110-120, yolov3/models/yolov3.yaml:13-27 —
+ *     out = x + SiLU(bias2 + W2 (3x3, pad 1) * SiLU(bias1 + W1 (1x1) * x))
+ * on the weights-in-registers kernel (csrc/yolo_bneck_ws.hip): persistent workgroups, the 3x3's weights in registers, the x patch
+ * of a tile by LDS-DMA, the hidden tensor only ever in LDS (rounded to bf16 exactly as the stand-alone 1x1 stores it), ALL
+ * output channels of a pixel from one workgroup. weight1: bf16 [C/2][C]; weight2: bf16 [C][3][3][C/2]; biases fp32; x and out
+ * NHWC bf16 with channel strides (multiples of 8, >= C), x != out, each < 4 GB.
+ * ADAYOLO_ESHAPE: C not in {64, 128}, or a tensor beyond 32-bit byte offsets — the caller runs the two layers separately.
+ */
+int adayolo_bottleneck_ws_fwd(const void* x, int x_cstride, const void* weight1, const float* bias1,
+                              const void* weight2, const float* bias2, void* out, int out_cstride,
+                              int B, int H, int W, int C, void* stream);
+
+
+/*
  * Same as adayolo_conv_fwd with an explicit kernel (what YoloEngine.autotune picks per layer; results agree to the
  * bf16 rounding of the output, tests/test_gpu_yolo_variants.py): 0 = library default (= 2); 2 = LDS-DMA ring, 16x16x32
  * MFMA; 5 / 22 / 26 / 27 = lean-address LDS-DMA ring on 32x32x16 MFMA with tiles 128x128 (by shape) / 128x64 /

@@ -94,7 +94,9 @@ def main():
                     e1.record()
                     e1.synchronize()
                     ts.append(e0.elapsed_time(e1) * 1e3)
-                if kind == "k1":
+                if kind == "bneckws":
+                    key = f"bneckws {args[9]}x{args[10]} C{args[11]}"
+                elif kind == "k1":
                     key = f"k1 {args[7]}x{args[8]} {args[9]}->{args[10]}"
                 elif kind in ("conv", "conv2"):
                     key = f"{kind} {args[9]}x{args[10]} {args[11]}->{args[12]} k{args[13]}s{args[14]} v{args[16] if kind == 'conv' else 'fused'}"

@@ -29,6 +29,10 @@ for kind, fn, args in eng.plan:
     elif kind == "chain":                                 # a run of layers as one persistent launch (YoloEngine.fuse_chains)
         c = next(c for c in eng.chains if c["ws"].data_ptr() == args[2].value)
         rows.append((t, f"chain of {c['layers']} layers ({c['flops'] / 1e9:.0f} GFLOP): {t:7.1f} us {c['flops'] / t / 1e6:7.1f} TF"))
+    elif kind == "bneckws":                               # a whole Bottleneck of the C = 64 / 128 stages in one launch
+        B, H, W, C = args[8:12]
+        fl = 2.0 * B * H * W * (C * (C // 2) + 9 * (C // 2) * C)
+        rows.append((t, f"bottleneck {H}x{W} C{C} whole-block: {t:7.1f} us {fl / t / 1e6:7.1f} TF  {B * H * W * C * 4 / t / 1e3:6.0f} GB/s"))
     elif kind == "k1":                                    # a 1x1 layer on the whole-K kernel (YoloEngine.fuse_k1)
         B, H, W, cin, cout = args[6:11]
         fl = 2.0 * B * H * W * cin * cout
