@@ -97,6 +97,7 @@ template <int CM>
 __global__ __launch_bounds__(512) void k_bneck_ws(const BwsArgs a) {
     using G = Geo<CM>;
     constexpr int CX = G::CX, PW = G::PW, PH = G::PH, TW = G::TW, TH = G::TH;
+    static_assert(PW == 18, "stage_piece divides by 18 with a multiply");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* const xbuf = smem + G::oX;
     unsigned char* const hbuf = smem + G::oH;
@@ -116,32 +117,31 @@ __global__ __launch_bounds__(512) void k_bneck_ws(const BwsArgs a) {
     const __amdgpu_buffer_rsrc_t rsO = __builtin_amdgcn_make_buffer_rsrc((void*)a.out, 0, kRecords, kDescFlags);
 
     // ---- x patch DMA: instruction g = wave + 8 i covers patch rows [g RPD, g RPD + RPD); lane -> (row, 16-byte slot)
-    const int dslot = lane % G::CPRX, drow = lane / G::CPRX;
-    unsigned pinfo[G::NP];                               // patch y << 16 | patch x << 8 | source chunk (after the swizzle); y >= PH: past the patch
-#pragma unroll
-    for (int i = 0; i < G::NP; ++i) {
-        const int rr = (wave + 8 * i) * G::RPD + drow;
-        const int py = rr / PW;
-        pinfo[i] = ((unsigned)py << 16) | ((unsigned)(rr - py * PW) << 8) | (unsigned)(dslot ^ row_key<G::CPRX>(rr));
-    }
+    const int dslot0 = lane % G::CPRX, drow0 = lane / G::CPRX;
+    // (a piece's (patch y, patch x, source chunk) is recomputed where it is issued — ~8 integer instructions — rather than kept in
+    // NP registers across stage C: beside the 144 weight registers they spill, and a scratch reload in front of a DMA instruction
+    // waits for every DMA instruction before it)
     auto tile_coords = [&](int t, int& b, int& oy0, int& ox0) {
         const int tx = t % a.tiles_x, r = t / a.tiles_x;
         ox0 = tx * TW; oy0 = (r % a.tiles_y) * TH; b = r / a.tiles_y;
     };
+    // one DMA instruction of a patch: `i`-th piece of this wave, for the tile at (b, oy0, ox0); dead = past the last tile
+    auto stage_piece = [&](int i, int b, int oy0, int ox0, bool live, int drow, int dslot) __attribute__((always_inline)) {
+        if ((wave + 8 * i) < G::PINS) {                  // (uniform)
+            const int rr = (wave + 8 * i) * G::RPD + drow;
+            const int py = (int)(((unsigned)rr * 3641u) >> 16);            // rr / 18 for rr < 4096 (PW = 18)
+            const int px = rr - py * PW;
+            const int iy = oy0 - 1 + py, ix = ox0 - 1 + px;
+            const bool ok = (int)live & (py < PH) & (iy >= 0) & (iy < a.H) & (ix >= 0) & (ix < a.W);
+            const unsigned voff = ok ? 2u * (unsigned)(((b * a.H + iy) * a.W + ix) * a.x_cs) + 16u * (unsigned)(dslot ^ row_key<G::CPRX>(rr)) : kOOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (lds_ptr_t)(xbuf + (wave + 8 * i) * 1024), 16, voff, 0, 0, 0);
+        }
+    };
     auto stage_patch = [&](int t) {
         int b, oy0, ox0;
         tile_coords(t < ntiles ? t : ntiles - 1, b, oy0, ox0);
-        const bool live = t < ntiles;
 #pragma unroll
-        for (int i = 0; i < G::NP; ++i) {
-            if ((wave + 8 * i) < G::PINS) {              // (uniform)
-                const int py = (int)(pinfo[i] >> 16), px = (int)((pinfo[i] >> 8) & 0xFFu);
-                const int iy = oy0 - 1 + py, ix = ox0 - 1 + px;
-                const bool ok = (int)live & (py < PH) & (iy >= 0) & (iy < a.H) & (ix >= 0) & (ix < a.W);
-                const unsigned voff = ok ? 2u * (unsigned)(((b * a.H + iy) * a.W + ix) * a.x_cs) + 16u * (pinfo[i] & 0xFFu) : kOOB;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (lds_ptr_t)(xbuf + (wave + 8 * i) * 1024), 16, voff, 0, 0, 0);
-            }
-        }
+        for (int i = 0; i < G::NP; ++i) stage_piece(i, b, oy0, ox0, t < ntiles, drow0, dslot0);
     };
     int t = blockIdx.x;
     stage_patch(t);                                      // the first patch is in flight while the weights are fetched
@@ -229,8 +229,15 @@ __global__ __launch_bounds__(512) void k_bneck_ws(const BwsArgs a) {
         BWS_T(2);
         barrier();                                       // B: h is complete; nobody reads the x patch any more
         BWS_T(3);
-        // the next tile's patch lands under stage C
-        stage_patch(t + (int)gridDim.x);
+        // the next tile's patch is requested INSIDE stage C, one DMA instruction behind every NSTEP / NP-th MFMA step: issued
+        // in one burst here the six instructions hold the wave for ~1.9k cycles (the CU's DMA path takes ~24 B/clk: stamps,
+        // profiles/round6_bneck_ws_stamps.txt) with the matrix pipe idle; between MFMA steps the partner wave of the SIMD computes
+        const int tn = t + (int)gridDim.x;
+        int nb_, noy0, nox0;
+        tile_coords(tn < ntiles ? tn : ntiles - 1, nb_, noy0, nox0);
+        const bool nlive = tn < ntiles;
+        int drowC = drow0, dslotC = dslot0;               // (opaque per tile: the pieces' lane terms are recomputed, not hoisted + spilled)
+        asm volatile("" : "+v"(drowC), "+v"(dslotC));
         BWS_T(4);
 
         // ---- C: the 3x3 from the h patch (yolo_conv_ws.hip's loop). Accumulators start at the bias.
@@ -270,6 +277,9 @@ __global__ __launch_bounds__(512) void k_bneck_ws(const BwsArgs a) {
                     for (int pf = 0; pf < 2; ++pf)
                         acc[pf] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wreg[tap][kp * 2 + k2], fr_[st & 1][k2][pf], acc[pf], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < G::NP; ++i)
+                    if (i * NSTEP / G::NP == st) { stage_piece(i, nb_, noy0, nox0, nlive, drowC, dslotC); __builtin_amdgcn_sched_barrier(0); }
                 self(self, std::integral_constant<int, st + 1>{});
             }
         };

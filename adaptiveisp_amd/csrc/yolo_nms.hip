@@ -9,8 +9,12 @@
 //   k_nms_mask  one wave per (row block, column block) pair of 64 boxes: lane r holds row box r, the 64 column boxes
 //               sit in LDS, and the lane produces the 64-bit word "which column boxes does my box suppress" — a
 //               wave64 ballot-shaped word per lane, written as mask[row][column block];
-//   k_nms_scan  one wave walks the boxes in order with the running `removed` bit set in LDS; only KEPT boxes (at most
-//               max_det of them) touch their mask row, so the scan stops after max_det keeps.
+//   k_nms_scan  one workgroup walks the boxes in order, 64 at a time, with the running `removed` bit set in LDS. A block of 64
+//               whose boxes are all removed already costs one LDS read. Otherwise its 64 diagonal mask words are fetched (one
+//               memory round trip), the block is resolved sequentially in registers — the greedy order exactly — and the mask
+//               rows of the boxes it KEEPS are OR-ed into the later blocks' words by all threads at once (one more round trip,
+//               every load independent). Round 6: the form before walked box by box, one dependent round trip per kept box —
+//               0.63 ms for 300 keeps among 30 000 candidates (config 3's loop at conf 0.001); the scan stops after max_det keeps.
 #include "yolo_internal.h"
 
 namespace adayolo {
@@ -39,37 +43,74 @@ __global__ __launch_bounds__(64) void k_nms_mask(const float4* __restrict__ boxe
     const float4 me = boxes[row];
     unsigned long long bits = 0ull;
     const int ncol = min(64, n - cb * 64);
+    // (most pairs do not intersect at all — boxes of different classes are 7680 px apart by construction: their IoU is 0 / union,
+    // never above a threshold >= 0, and the division is skipped: the same bits as evaluating box_iou_tv for every pair)
+    const float area_me = (me.z - me.x) * (me.w - me.y);
     for (int j = 0; j < ncol; ++j) {
         const int cj = cb * 64 + j;
-        if (cj > row && box_iou_tv(me, col[j]) > thr) bits |= 1ull << j;
+        const float4 o = col[j];
+        const float w = fmaxf(fminf(me.z, o.z) - fmaxf(me.x, o.x), 0.0f);
+        const float h = fmaxf(fminf(me.w, o.w) - fmaxf(me.y, o.y), 0.0f);
+        const float inter = w * h;
+        if (cj > row && inter > 0.0f) {
+            const float area_o = (o.z - o.x) * (o.w - o.y);
+            if (inter / (area_me + area_o - inter) > thr) bits |= 1ull << j;
+        }
     }
     mask[(long)row * nb + cb] = bits;
 }
 
-__global__ __launch_bounds__(64) void k_nms_scan(const unsigned long long* __restrict__ mask, int n, int nb,
-                                                 int max_det, int* __restrict__ keep, int* __restrict__ num_keep) {
-    extern __shared__ unsigned long long removed[];  // [nb]
-    const int lane = threadIdx.x;
-    for (int w = lane; w < nb; w += 64) removed[w] = 0ull;
+constexpr int kScanThreads = 512;
+__global__ __launch_bounds__(kScanThreads) void k_nms_scan(const unsigned long long* __restrict__ mask, int n, int nb,
+                                                            int max_det, int* __restrict__ keep, int* __restrict__ num_keep) {
+    extern __shared__ unsigned long long removed[];  // [nb] running "suppressed" bits, then [64] diagonal words
+    unsigned long long* const diag = removed + nb;
+    const int tid = threadIdx.x;
+    for (int w = tid; w < nb; w += kScanThreads) removed[w] = 0ull;
     __syncthreads();
     int count = 0;
-    for (int i = 0; i < n && count < max_det; ++i) {
-        const unsigned long long word = removed[i >> 6];          // broadcast read
-        if ((word >> (i & 63)) & 1ull) continue;                   // wave-uniform
-        if (lane == 0) keep[count] = i;
-        ++count;
-        for (int w = (i >> 6) + lane; w < nb; w += 64) removed[w] |= mask[(long)i * nb + w];
+    for (int b = 0; b < nb && count < max_det; ++b) {
+        const int nvalid = min(64, n - b * 64);
+        const unsigned long long valid = nvalid == 64 ? ~0ull : ((1ull << nvalid) - 1ull);
+        const unsigned long long word = removed[b];                // broadcast read (uniform)
+        if ((~word & valid) == 0ull) continue;                     // every box of the block is suppressed already: no memory access
+        if (tid < 64) diag[tid] = tid < nvalid ? mask[(long)(b * 64 + tid) * nb + b] : 0ull;
+        __syncthreads();
+        // the greedy walk inside the block, identically in every thread (64 steps on LDS broadcasts)
+        unsigned long long cur = word, kept = 0ull;
+        int c = count;
+        for (int r = 0; r < nvalid && c < max_det; ++r) {
+            if (!((cur >> r) & 1ull)) {
+                kept |= 1ull << r;
+                cur |= diag[r];
+                if (tid == 0) keep[c] = b * 64 + r;
+                ++c;
+            }
+        }
+        count = c;
+        // OR the kept boxes' mask rows into the words of the later blocks: thread -> word, loop over the kept rows (independent loads)
+        if (count < max_det) {
+            for (int w = b + 1 + tid; w < nb; w += kScanThreads) {
+                unsigned long long acc = 0ull, k = kept;
+                while (k) {
+                    const int r = __builtin_ctzll(k);
+                    k &= k - 1ull;
+                    acc |= mask[(long)(b * 64 + r) * nb + w];
+                }
+                removed[w] |= acc;
+            }
+        }
         __syncthreads();
     }
-    if (lane == 0) *num_keep = count;
-    for (int k = count + lane; k < max_det; k += 64) keep[k] = -1;
+    if (tid == 0) *num_keep = count;
+    for (int k = count + tid; k < max_det; k += kScanThreads) keep[k] = -1;
 }
 
 hipError_t launch_nms(const float* boxes, int n, float thr, int max_det, unsigned long long* mask_ws, int* keep,
                       int* num_keep, hipStream_t s) {
     const int nb = (n + 63) / 64;
     if (n > 0) hipLaunchKernelGGL(k_nms_mask, dim3(nb, nb), dim3(64), 0, s, reinterpret_cast<const float4*>(boxes), n, thr, nb, mask_ws);
-    hipLaunchKernelGGL(k_nms_scan, dim3(1), dim3(64), (size_t)(nb > 0 ? nb : 1) * 8, s, mask_ws, n, nb, max_det, keep, num_keep);
+    hipLaunchKernelGGL(k_nms_scan, dim3(1), dim3(kScanThreads), (size_t)((nb > 0 ? nb : 1) + 64) * 8, s, mask_ws, n, nb, max_det, keep, num_keep);
     return hipGetLastError();
 }
 

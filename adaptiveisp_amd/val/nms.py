@@ -15,16 +15,17 @@ MAX_WH = 7680      # class offset (pixels), general.py:888
 MAX_NMS = 30000    # boxes entering NMS, general.py:889
 
 
-def hip_nms(boxes, scores, iou_thres, max_det=300):
-    """Kept indices (int64, device) of greedy IoU NMS. `boxes` [n,4] xyxy fp32 on a HIP device, any score order."""
+def hip_nms(boxes, scores, iou_thres, max_det=300, presorted=False):
+    """Kept indices (int64, device) of greedy IoU NMS. `boxes` [n,4] xyxy fp32 on a HIP device, any score order
+    (`presorted`: the caller hands them over in descending score order already — no second sort, no gather)."""
     from ..yolo import _lib
     if boxes.device.type != "cuda":
         raise _lib.AdayoloError("hip_nms needs device tensors: there is no CPU path")
     n = boxes.shape[0]
     if n == 0:
         return torch.zeros(0, dtype=torch.int64, device=boxes.device)
-    order = scores.argsort(descending=True, stable=True)
-    b = boxes.float()[order].contiguous()
+    order = None if presorted else scores.argsort(descending=True, stable=True)
+    b = boxes.float().contiguous() if presorted else boxes.float()[order].contiguous()
     L = _lib.load()
     ws = torch.empty(L.adayolo_nms_workspace_bytes(n), dtype=torch.uint8, device=boxes.device)
     keep = torch.empty(max_det, dtype=torch.int32, device=boxes.device)
@@ -35,7 +36,8 @@ def hip_nms(boxes, scores, iou_thres, max_det=300):
                            ctypes.c_void_p(cnt.data_ptr()), _lib.stream_ptr())
     _lib.check(rc, "adayolo_nms")
     k = int(cnt.item())
-    return order[keep[:k].long()]
+    kept = keep[:k].long()
+    return kept if presorted else order[kept]
 
 
 def _with_label_rows(pred, labels, nc, nm):
@@ -74,7 +76,7 @@ def non_max_suppression(prediction, conf_thres=0.25, iou_thres=0.45, classes=Non
     if isinstance(prediction, (list, tuple)):
         prediction = prediction[0]
     if nms_fn is None:
-        nms_fn = lambda b, s, t: hip_nms(b, s, t, max_det)       # noqa: E731
+        nms_fn = lambda b, s, t: hip_nms(b, s, t, max_det, presorted=True)       # noqa: E731  (every segment below is sorted)
     B = prediction.shape[0]
     nc = prediction.shape[2] - nm - 5
     first_mask = 5 + nc
@@ -99,7 +101,8 @@ def non_max_suppression(prediction, conf_thres=0.25, iou_thres=0.45, classes=Non
     if classes is not None:
         wanted = (det[:, 5:6] == torch.tensor(classes, device=det.device)).any(1)
         det, image = det[wanted], image[wanted]
-    counts = torch.bincount(image, minlength=B).tolist()
+    # (one image: its segment is the whole list — no count kernel, no host read)
+    counts = [int(det.shape[0])] if B == 1 else torch.bincount(image, minlength=B).tolist()
     output, start = [], 0
     for n in counts:
         seg = det[start:start + n]
