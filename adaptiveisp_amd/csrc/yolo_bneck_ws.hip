@@ -26,6 +26,7 @@ namespace bws {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
@@ -66,7 +67,7 @@ struct Geo {
     static constexpr int RPD = 1024 / RBX;            // x rows per DMA instruction: 4 / 8
     static constexpr int PINS = (PROWS + RPD - 1) / RPD;                  // 45 / 41
     static constexpr int NP = (PINS + 7) / 8;         // DMA instructions per wave: 6
-    static constexpr int kXBytes = (NF * 32 > PINS * RPD ? NF * 32 : PINS * RPD) * RBX;   // 49 152 / 45 056 (stage B reads whole fragments)
+    static constexpr int kXBytes = (NF * 32 > PINS * RPD ? NF * 32 : PINS * RPD) * RBX;   // 49 152 / 45 056 (stage B reads whole 16-pixel groups: <= NF * 32 rows)
     static constexpr int RBH = 2 * CM;                // bytes per h-patch row: 128 / 64
     static constexpr int kHBytes = PROWS * RBH;       // 23 040 / 20 736
     static constexpr int kOutPitch = 2 * CX + 16;     // 272 / 144
@@ -181,48 +182,49 @@ __global__ __launch_bounds__(512) void k_bneck_ws(const BwsArgs a) {
         barrier();                                       // A: patch(t) is in LDS (and, first tile: W1 / biases are)
         BWS_T(1);                                        //  5 = stage C, 6 = residual + SiLU + barrier C, 7 = rows + stores)
 
-        // ---- B: h = SiLU(b1 + W1 x) on the patch. Unit u = (pixel fragment f, channel fragment cf); waves take u = wave, wave + 8
+        // ---- B: h = SiLU(b1 + W1 x) on the patch, on v_mfma_f32_16x16x32_bf16: unit u = (16 patch pixels g, 16 hidden channels
+        //      cq) — NG x NCQ = 48 / 42 units, u = wave + 8 uu: SIX per wave (with 32 x 32 MFMAs the 12 / 11 units were two for
+        //      half of the waves and one for the others: the stage took two units' time, 3.9k cycles of a 14.6k-cycle tile —
+        //      profiles/round6_bneck_ws_stamps.txt). NCQ divides 8, so a wave's units share their channel group: its W1
+        //      fragments are read once per tile. Four (two) dependent MFMAs per unit; the units' chains are independent.
         // (lane-derived addressing of this stage: opaque per tile, so that it is recomputed — a dozen integer instructions — rather
         // than hoisted out of the tile loop and spilled beside the 144 weight registers)
-        int frB = fr, fqB = fq;
-        asm volatile("" : "+v"(frB), "+v"(fqB));
+        {
+            constexpr int NCQ = CM / 16, NG = (G::PROWS + 15) / 16, NUQ = NG * NCQ, KQ = CX / 32;
+            static_assert(8 % NCQ == 0, "a wave's units must share their channel group");
+            int l15 = lane & 15, kq = lane >> 4;
+            asm volatile("" : "+v"(l15), "+v"(kq));
+            const int cq = wave % NCQ;
+            const int wrow = 16 * cq + l15;               // this lane's row of W1 (a hidden channel)
+            const unsigned char* wr = w1s + wrow * G::RBX;
+            const int kw = row_key<G::CPRX>(wrow);
+            bf16x8 wf[KQ];
 #pragma unroll
-        for (int uu = 0; uu < (G::NU + 7) / 8; ++uu) {
-            const int u = wave + 8 * uu;
-            if (u < G::NU) {                             // (uniform)
-                const int f = u / (CM / 32), cf = u % (CM / 32);
-                f32x16 hacc;
+            for (int k4 = 0; k4 < KQ; ++k4) wf[k4] = *reinterpret_cast<const bf16x8*>(wr + (((4 * k4 + kq) ^ kw) << 4));
+            const float4 b4 = *reinterpret_cast<const float4*>(b1s + 16 * cq + 4 * kq);     // D rows 4 kq + (0..3) of the unit's 16 channels
 #pragma unroll
-                for (int e = 0; e < 16; ++e) hacc[e] = 0.0f;
-                const int p = 32 * f + frB;               // patch pixel of this lane's MFMA column
-                const unsigned char* xr = xbuf + p * G::RBX;
-                const unsigned char* wr = w1s + (cf * 32 + frB) * G::RBX;
-                const int kx = row_key<G::CPRX>(p), kw = row_key<G::CPRX>(cf * 32 + frB);
-                // (two k-steps of fragments in registers at a time: stage B runs beside the 144 weight registers of stage C)
-                bf16x8 xf[2], wf[2];
-                xf[0] = *reinterpret_cast<const bf16x8*>(xr + ((fqB ^ kx) << 4));
-                wf[0] = *reinterpret_cast<const bf16x8*>(wr + ((fqB ^ kw) << 4));
+            for (int uu = 0; uu < (NUQ + 7) / 8; ++uu) {
+                const int u = wave + 8 * uu;
+                if (u < NUQ) {                           // (uniform)
+                    const int g = u / NCQ;
+                    const int p = 16 * g + l15;          // patch pixel of this lane's MFMA column
+                    const unsigned char* xr = xbuf + p * G::RBX;
+                    const int kx = row_key<G::CPRX>(p);
+                    bf16x8 xf[KQ];
 #pragma unroll
-                for (int kk = 0; kk < G::KK1; ++kk) {
-                    if (kk + 1 < G::KK1) {
-                        xf[(kk + 1) & 1] = *reinterpret_cast<const bf16x8*>(xr + (((2 * (kk + 1) + fqB) ^ kx) << 4));
-                        wf[(kk + 1) & 1] = *reinterpret_cast<const bf16x8*>(wr + (((2 * (kk + 1) + fqB) ^ kw) << 4));
-                    }
-                    hacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[kk & 1], xf[kk & 1], hacc, 0, 0, 0);
-                }
-                // lane holds pixel p and hidden channels cf * 32 + 8 qd + 4 fqB + (0..3): 8 bytes of chunk cf * 4 + qd of row p
-                const int py = p / PW, px = p - py * PW;
-                const int iy = oy0 - 1 + py, ix = ox0 - 1 + px;
-                const bool inside = (p < G::PROWS) & (iy >= 0) & (iy < a.H) & (ix >= 0) & (ix < a.W);
-                const int hk = px_key<CM>(px);
-                unsigned char* const dst = hbuf + p * G::RBH + 8 * fqB;
+                    for (int k4 = 0; k4 < KQ; ++k4) xf[k4] = *reinterpret_cast<const bf16x8*>(xr + (((4 * k4 + kq) ^ kx) << 4));
+                    f32x4 hacc = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-                for (int qd = 0; qd < 4; ++qd) {
-                    const float4 b4 = *reinterpret_cast<const float4*>(b1s + cf * 32 + 8 * qd + 4 * fqB);
+                    for (int k4 = 0; k4 < KQ; ++k4) hacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[k4], xf[k4], hacc, 0, 0, 0);
+                    // lane holds pixel p and hidden channels 16 cq + 4 kq + (0..3): 8 bytes — half (kq & 1) of chunk 2 cq + (kq >> 1) of row p
+                    const int py = (int)(((unsigned)p * 3641u) >> 16), px = p - py * PW;      // p / 18
+                    const int iy = oy0 - 1 + py, ix = ox0 - 1 + px;
+                    const bool inside = (p < G::PROWS) & (iy >= 0) & (iy < a.H) & (ix >= 0) & (ix < a.W);
                     unsigned lo, hi;
-                    bias_act_pack4<true>(hacc[4 * qd], hacc[4 * qd + 1], hacc[4 * qd + 2], hacc[4 * qd + 3], b4, lo, hi);
+                    bias_act_pack4<true>(hacc[0], hacc[1], hacc[2], hacc[3], b4, lo, hi);
                     if (!inside) { lo = 0u; hi = 0u; }
-                    if (p < G::PROWS) *reinterpret_cast<u32x2*>(dst + (((cf * 4 + qd) ^ hk) << 4)) = u32x2{lo, hi};
+                    if (p < G::PROWS)
+                        *reinterpret_cast<u32x2*>(hbuf + p * G::RBH + (((2 * cq + (kq >> 1)) ^ px_key<CM>(px)) << 4) + 8 * (kq & 1)) = u32x2{lo, hi};
                 }
             }
         }
