@@ -187,10 +187,17 @@ int chain_plan(const adayolo_chain_layer* L, int n, ChainPlan& P, bool tables) {
         a.ntiles = a.Cout / bn;
         // the written-through stores address their tensor with 32-bit byte offsets
         if ((long)a.M * a.out_cs * 2 >= 0x7FFFFFFFL || (a.out2 && (long)a.M * a.out2_cs * 2 >= 0x7FFFFFFFL)) return ADAYOLO_ESHAPE;
-        s_in[l] = Span{(const char*)a.in, (const char*)a.in + (long)a.B * a.H * a.W * a.in_cs * 2};
-        s_res[l] = Span{(const char*)a.res, a.res ? (const char*)a.res + (long)a.M * a.res_cs * 2 : nullptr};
-        s_out[l] = Span{(const char*)a.out, (const char*)a.out + (long)a.M * a.out_cs * 2};
-        s_out2[l] = Span{(const char*)a.out2, a.out2 ? (const char*)a.out2 + (long)a.M * a.out2_cs * 2 : nullptr};
+        // the bytes a tensor view really touches: `rows` rows of `c` channels at a stride of `cs` — the LAST row ends after its c
+        // channels, not after a whole stride (a channel slice that ends its parent buffer would otherwise reach (cs - c) elements
+        // into whatever the allocator placed behind it: in a long-lived process with a split cached block that is another tensor
+        // of the same chain, and the chain was refused for an overlap that does not exist — round 6)
+        auto span = [](const void* p, long rows, int cs, int c) {
+            return p ? Span{(const char*)p, (const char*)p + ((rows - 1) * cs + c) * 2} : Span{nullptr, nullptr};
+        };
+        s_in[l] = span(a.in, (long)a.B * a.H * a.W, a.in_cs, a.Cin);
+        s_res[l] = span(a.res, a.M, a.res_cs, a.Cout);
+        s_out[l] = span(a.out, a.M, a.out_cs, a.Cout);
+        s_out2[l] = span(a.out2, a.M, a.out2_cs, d.weight2 ? d.Cout2 : 0);
         if (overlap(s_out[l], s_in[l]) || overlap(s_out[l], s_res[l]) || overlap(s_out2[l], s_in[l]) || overlap(s_out2[l], s_res[l]) ||
             overlap(s_out[l], s_out2[l]))
             return ADAYOLO_ESHAPE;

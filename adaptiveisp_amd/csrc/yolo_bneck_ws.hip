@@ -69,7 +69,7 @@ struct Geo {
     static constexpr int NP = (PINS + 7) / 8;         // DMA instructions per wave: 6
     static constexpr int kXBytes = (NF * 32 > PINS * RPD ? NF * 32 : PINS * RPD) * RBX;   // 49 152 / 45 056 (stage B reads whole 16-pixel groups: <= NF * 32 rows)
     static constexpr int RBH = 2 * CM;                // bytes per h-patch row: 128 / 64
-    static constexpr int kHBytes = PROWS * RBH;       // 23 040 / 20 736
+    static constexpr int kHBytes = (PROWS + 15) / 16 * 16 * RBH;          // 24 576 / 21 504 (whole 16-pixel groups: stage B writes its padding rows)
     static constexpr int kOutPitch = 2 * CX + 16;     // 272 / 144
     static constexpr int kOutBytes = TH * TW * kOutPitch;                 // 34 816 / 36 864
     static constexpr int kW1Bytes = CM * RBX;         // 16 384 / 4 096
@@ -202,29 +202,44 @@ __global__ __launch_bounds__(512) void k_bneck_ws(const BwsArgs a) {
 #pragma unroll
             for (int k4 = 0; k4 < KQ; ++k4) wf[k4] = *reinterpret_cast<const bf16x8*>(wr + (((4 * k4 + kq) ^ kw) << 4));
             const float4 b4 = *reinterpret_cast<const float4*>(b1s + 16 * cq + 4 * kq);     // D rows 4 kq + (0..3) of the unit's 16 channels
+            // Units go THREE at a time, without a branch between them: one unit alone is a latency chain — LDS reads, four dependent
+            // MFMAs, exp -> rcp — of ~600 cycles with nothing beside it but the SIMD's other wave (six in a row: the 3.9k cycles
+            // this stage took with either MFMA shape, profiles/round6_bneck_ws_stamps.txt); three interleave their reads, their
+            // MFMA chains and their SiLUs. A slot past the last unit (C = 64: 42 units in 48 slots) redoes the wave's previous
+            // unit — the same values to the same addresses; rows past the patch (the last group's padding) are written too:
+            // the h buffer holds whole 16-pixel groups, stage C never reads them.
+            constexpr int NB = 3, NSLOT = ((NUQ + 7) / 8 + NB - 1) / NB * NB;
 #pragma unroll
-            for (int uu = 0; uu < (NUQ + 7) / 8; ++uu) {
-                const int u = wave + 8 * uu;
-                if (u < NUQ) {                           // (uniform)
-                    const int g = u / NCQ;
-                    const int p = 16 * g + l15;          // patch pixel of this lane's MFMA column
-                    const unsigned char* xr = xbuf + p * G::RBX;
-                    const int kx = row_key<G::CPRX>(p);
-                    bf16x8 xf[KQ];
+            for (int u0 = 0; u0 < NSLOT; u0 += NB) {
+                bf16x8 xf[NB][KQ];
+                f32x4 hacc[NB];
+                int pp[NB];
 #pragma unroll
-                    for (int k4 = 0; k4 < KQ; ++k4) xf[k4] = *reinterpret_cast<const bf16x8*>(xr + (((4 * k4 + kq) ^ kx) << 4));
-                    f32x4 hacc = {0.0f, 0.0f, 0.0f, 0.0f};
+                for (int j = 0; j < NB; ++j) {
+                    int u = wave + 8 * (u0 + j);
+                    if (u >= NUQ) u -= 8;                 // (uniform)
+                    pp[j] = 16 * (u / NCQ) + l15;        // patch pixel of this lane's MFMA column
+                    const unsigned char* xr = xbuf + pp[j] * G::RBX;
+                    const int kx = row_key<G::CPRX>(pp[j]);
 #pragma unroll
-                    for (int k4 = 0; k4 < KQ; ++k4) hacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[k4], xf[k4], hacc, 0, 0, 0);
+                    for (int k4 = 0; k4 < KQ; ++k4) xf[j][k4] = *reinterpret_cast<const bf16x8*>(xr + (((4 * k4 + kq) ^ kx) << 4));
+                    hacc[j] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+                }
+#pragma unroll
+                for (int k4 = 0; k4 < KQ; ++k4)
+#pragma unroll
+                    for (int j = 0; j < NB; ++j) hacc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[k4], xf[j][k4], hacc[j], 0, 0, 0);
+#pragma unroll
+                for (int j = 0; j < NB; ++j) {
                     // lane holds pixel p and hidden channels 16 cq + 4 kq + (0..3): 8 bytes — half (kq & 1) of chunk 2 cq + (kq >> 1) of row p
+                    const int p = pp[j];
                     const int py = (int)(((unsigned)p * 3641u) >> 16), px = p - py * PW;      // p / 18
                     const int iy = oy0 - 1 + py, ix = ox0 - 1 + px;
                     const bool inside = (p < G::PROWS) & (iy >= 0) & (iy < a.H) & (ix >= 0) & (ix < a.W);
                     unsigned lo, hi;
-                    bias_act_pack4<true>(hacc[0], hacc[1], hacc[2], hacc[3], b4, lo, hi);
+                    bias_act_pack4<true>(hacc[j][0], hacc[j][1], hacc[j][2], hacc[j][3], b4, lo, hi);
                     if (!inside) { lo = 0u; hi = 0u; }
-                    if (p < G::PROWS)
-                        *reinterpret_cast<u32x2*>(hbuf + p * G::RBH + (((2 * cq + (kq >> 1)) ^ px_key<CM>(px)) << 4) + 8 * (kq & 1)) = u32x2{lo, hi};
+                    *reinterpret_cast<u32x2*>(hbuf + p * G::RBH + (((2 * cq + (kq >> 1)) ^ px_key<CM>(px)) << 4) + 8 * (kq & 1)) = u32x2{lo, hi};
                 }
             }
         }

@@ -14,6 +14,16 @@ from .metrics import ap_per_class, process_batch
 from .nms import non_max_suppression
 
 
+_SIDE = {}
+
+
+def _side_stream(dev):
+    key = str(dev)
+    if key not in _SIDE:
+        _SIDE[key] = torch.cuda.Stream(device=dev)
+    return _SIDE[key]
+
+
 class _EpisodeGraph:
     """One batch's ISP episode + detector forward as ONE hipGraph replay (run_eval(graph=True)). At batch 1 the loop is bound by
     the host — ~60 launches and one device-to-host read per RL step for 2 ms of kernels — so the fixed-shape part is captured
@@ -23,8 +33,11 @@ class _EpisodeGraph:
     batch with the eager loop (with the default states, `stopped` is raised on the last step only)."""
 
     def __init__(self, agent, detector, im, noises, states, steps, pipeline):
-        self.im, self.z, self.s0 = im.clone(), noises.clone(), states.clone()
         dev = im.device
+        # the agent and the detector engine work on buffers of their own: nothing of theirs may be in flight — another shape's
+        # replay on the side stream — while this warm-up and capture run them
+        torch.cuda.synchronize(dev)
+        self.im, self.z, self.s0 = im.clone(), noises.clone(), states.clone()
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side), torch.no_grad():       # warm-up outside the capture (lazy initialisation, workspaces)
@@ -58,7 +71,9 @@ class _EpisodeGraph:
     def launch(self, im, noises, states, keep_retouch=False):
         dev = self.im.device
         if not hasattr(self, "_side"):
-            self._side = torch.cuda.Stream(device=dev)
+            # ONE side stream per device for every graph (a second batch shape has its own graph, but the same agent and detector
+            # buffers underneath: their replays must not overlap each other either)
+            self._side = _side_stream(dev)
             self._slots, self._n = [None, None], 0
         k = self._n % 2
         self._n += 1
@@ -152,6 +167,10 @@ def run_eval(agent, detector, batches, cfg, steps=5, conf_thres=0.001, iou_thres
             if not any(v > 0 for v in stop[:-1]):                      # no early exit before the last step: the replay IS the loop
                 ids = [[int(v) for v in sel[i * nb:(i + 1) * nb]] for i in range(steps)]
                 retouch, preds, replayed = slot["retouch"], slot["preds"], True
+        if not replayed and graph and im.is_cuda:
+            # the eager loop below runs the agent and the detector on THIS stream while the next batch's replay may be in flight on
+            # the side stream — on the same internal buffers: behind it (the next launch in turn waits for this stream)
+            torch.cuda.current_stream(dev).wait_stream(_side_stream(dev))
         with torch.no_grad():
             for i in range(0 if not replayed else steps, steps):
                 pipe = None if pipeline is None else pipeline[i]
