@@ -328,14 +328,15 @@ __global__ __launch_bounds__(kThreads) void k_pointwise(const float* __restrict_
 #ifndef ISP_POOL_ROWS
 #define ISP_POOL_ROWS 3
 #endif
-// Round 6: a row that belongs to TWO pool windows (three of every four window boundaries at H = 720: 12-row windows on an
-// 11.25-row pitch) is read by both windows' workgroups — with non-temporal loads twice from the fabric (+6.7 % of the reads:
-// profiles/round5_pmc_traffic.json, 94.4 MB fetched per launch against 88.6). ISP_POOL_SHARED_L2 = 1: exactly those rows are
-// read with PLAIN loads (they allocate in the XCD's L2; everything else stays non-temporal and leaves the L2 to them: 48 rows x
-// 15 KB x 8 images = 5.9 MB over eight 4 MB L2s), and consecutive pool rows run on ONE XCD (workgroup bx of an image sits on XCD
-// bx % 8: pool row oy = (bx % 8) * 8 + bx / 8), so the second reader finds the row where the first one left it.
+// Round 6 (measured, OFF): a row that belongs to TWO pool windows (three of every four window boundaries at H = 720: 12-row windows
+// on an 11.25-row pitch) is read by both windows' workgroups — 94.4 MB fetched per launch against 88.6 (profiles/round5_pmc_traffic.json).
+// ISP_POOL_SHARED_L2 = 1 reads exactly those rows with PLAIN loads (everything else stays non-temporal) and runs consecutive pool
+// rows on ONE XCD (workgroup bx of an image sits on XCD bx % 8: pool row oy = (bx % 8) * 8 + bx / 8), hoping the second reader
+// finds the row in that XCD's L2. It does not: the fabric counter stays at 183.4 MB per launch and the time at 38.2 vs 38.0 us
+// (profiles/round6_isp_pool_shared_l2_ab.txt, round6_pmc_traffic.json) — the two readers are a whole window walk (~30 us of
+// streaming through a 4 MB L2) apart. Bit-identical either way.
 #ifndef ISP_POOL_SHARED_L2
-#define ISP_POOL_SHARED_L2 1
+#define ISP_POOL_SHARED_L2 0
 #endif
 #ifndef ISP_POOL_PIPE
 #define ISP_POOL_PIPE 0

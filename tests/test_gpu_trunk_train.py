@@ -243,6 +243,9 @@ def test_critic_statistics_kernel_alone():
 
 @pytest.mark.parametrize("use_td,use_truncated,use_penalty", [(True, True, True), (False, True, True), (True, False, False)])
 def test_td_kernel_matches_the_elementwise_arithmetic(use_td, use_truncated, use_penalty, monkeypatch):
+    """NOT the parity test of a16 (that is test_td_kernels_match_the_reference_fixture below: `td.npz`, generated by executing the
+    reference's own statements of train.py:264-305). This one is product against product — adaisp_td_fwd / _bwd against
+    rl.td_losses' element-wise ATen branch on random inputs — a consistency screen that keeps the two branches of OUR code equal."""
     from adaptiveisp_amd import rl
     from adaptiveisp_amd.config import cfg as base_cfg
     from adaptiveisp_amd.util import Dict

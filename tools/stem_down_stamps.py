@@ -23,10 +23,12 @@ assert eng.L.adayolo_debug_stem_down(buf, N * 12) == 0
 a = np.ctypeslib.as_array(buf).reshape(N, 12).astype(np.int64)
 names = ["setup + weight / image loads issued + image patch stored", "barrier", "B: stem conv + SiLU -> patch", "barrier",
          "C: second conv (36 MFMAs per wave)", "barrier", "D: bias + SiLU -> LDS tile", "barrier", "stores", "E: 1x1 + SiLU + stores"]
-d = np.diff(a[:, :11], axis=1)
-ok = (a[:, 10] > a[:, 0])
-print(f"{ok.sum()} workgroups sampled; whole workgroup median {np.median(a[ok, 10] - a[ok, 0]):.0f} cycles")
+last = 10 if eng._head_next is not None else 9            # (round 6: with the whole-Bottleneck launch the 1x1 stage E is not run)
+names = names[:last]
+d = np.diff(a[:, :last + 1], axis=1)
+ok = (a[:, last] > a[:, 0])
+print(f"{ok.sum()} workgroups sampled; whole workgroup median {np.median(a[ok, last] - a[ok, 0]):.0f} cycles")
 for i, n in enumerate(names):
     print(f"  {np.median(d[ok, i]):8.0f}  p90 {np.percentile(d[ok, i], 90):8.0f}   {n}")
-span = a[ok, 10].max() - a[ok, 0].min()
+span = a[ok, last].max() - a[ok, 0].min()
 print(f"first stamp to last stamp: {span} cycles")
