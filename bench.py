@@ -173,7 +173,7 @@ def build_pipeline(step, engine, x0, cut=None, gate=None, detector_eager=False):
 
     detector_eager: the measuring form of the SAME arrangement — the graphs hold only the ISP stream's part and `run()`
     launches the detector eagerly on the second stream beside the graph replay, so that its launches can be bracketed by
-    HIP events (event-record nodes inside a captured graph are not available on this ROCm: tools/graph_event_probe.py)."""
+    HIP events (event-record nodes inside a captured graph are not available on this ROCm: round 3)."""
     sched = step.sched
     nh = 2 * len(sched)
     if cut is None:

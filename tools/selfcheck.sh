@@ -11,3 +11,6 @@ run conv_bench python tools/conv_bench.py
 run train_bench python tools/train_bench.py
 run eval_bench python tools/eval_bench.py
 run isp_step_ab python tools/isp_step_ab.py --ops=0,5 --pairs=3
+run engine_env_ab python tools/engine_env_ab.py "ADAYOLO_BNECK_WS=0" "ADAYOLO_BNECK_WS=1" --rounds 2 --reps 2
+run eval_graph_prof python tools/eval_graph_prof.py 12
+run k1_bench python tools/k1_bench.py --reps 8
