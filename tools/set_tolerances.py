@@ -55,7 +55,7 @@ def newest_round_files():
 files = sys.argv[1:] or newest_round_files()
 # labels that keep their call-site cap: a comparison of two launch PLANS that happens to be bit-identical with the committed
 # tuning table (the Bottleneck kernel and the fused pair round h the same way) but need not be with another choice of kernels
-KEEP_CAP = {"yolo.engine_bneck_vs_default_plan"}
+KEEP_CAP = {"yolo.engine_bneck_vs_default_plan", "yolo.engine_bneck_ws_vs_two_launch_plan", "yolo.bottleneck_ws_vs_two_layers"}
 
 
 def up(v, digits=2):
