@@ -8,6 +8,7 @@ Weights are snapshotted (BatchNorm folded with its running statistics) and re-sn
 parameter or buffer changes (tensor version counters), so optimizer steps / load_state_dict are picked up.
 """
 import ctypes
+import os
 import math
 
 import torch
@@ -163,4 +164,10 @@ class FastPolicy:
             rc = L.adaisp_policy_finish(ctypes.byref(fa), B, st)
             _lib._check(rc, "adaisp_policy_finish")
         out["_keep"] = (pooled, z, states)        # inputs stay alive until the stream has consumed them
+        n_extra = int(os.environ.get("ADAISP_EXPERIMENT_EXTRA_LAUNCHES", "0"))      # measurement aid: N trivial
+        if n_extra:                                                                   # one-workgroup launches behind every policy step
+            if not hasattr(self, "_extra"):
+                self._extra = torch.zeros(64, device=dev)
+            for _ in range(n_extra):
+                self._extra.add_(1.0)
         return out
