@@ -34,7 +34,7 @@ TUNE_CACHE = os.path.join(ROOT, "adaptiveisp_amd", "yolo", "tuning", "mi355x.jso
 CONV_KERNEL_NAMES = {2: "dma::k_conv_igemm_dma<128,128,2,2,2>", 5: "dma2::k_conv_igemm_dma32<128,128,2,2,2,0,64,1>",
                      22: "dma2::k_conv_igemm_dma32<128,64,4,1,4,0,32,1>", 26: "dma2::k_conv_igemm_dma32<128,256,2,4,3,0,32,4>",
                      27: "dma2::k_conv_igemm_dma32<256,128,4,2,3,0,32,4>", 40: "smallk::k_conv3x3_small<...>",
-                     50: "pp::k_conv_pp<0, false>", 57: "pp::k_conv_chain", 58: "pp::k_conv_pp<0, true>", 59: "bnk::k_bneck<0>", 61: "bws::k_bneck_ws<...>", 60: "pp128::k_conv_pp128<0, false>", 70: "k1::k_conv_k1<...>", 80: "pq::k_conv_pq<0, 4>", 85: "pq::k_conv_pq<0, 2>", 90: "ws::k_conv_ws<...>"}
+                     50: "pp::k_conv_pp<0, false>", 57: "pp::k_conv_chain", 58: "pp::k_conv_pp<0, true>", 59: "bnk::k_bneck<0>", 61: "bws::k_bneck_ws", 60: "pp128::k_conv_pp128<0, false>", 70: "k1::k_conv_k1", 80: "pq::k_conv_pq<0, 4>", 85: "pq::k_conv_pq<0, 2>", 90: "ws::k_conv_ws"}
 
 
 _T0 = time.perf_counter()
