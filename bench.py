@@ -703,7 +703,9 @@ def cpu_baseline(a, sched):
         # ~2000-op reference step degenerates into OpenMP spin-waits), half of them — so that `all_cores` carries a NUMBER
         # (VERDICT r5 item 7), plus the record of what timed out
         tried = []
-        for nthr, limit in ((ncpu, ALL_CORES_LIMIT_S), (max(threads + 1, ncpu // 2), ALL_CORES_LIMIT_S)):
+        # (every hardware thread gets half the limit: on this pool it has never finished — rounds 5 and 6 — and the line should not
+        # spend a minute finding that out again; half of them get the full limit)
+        for nthr, limit in ((ncpu, ALL_CORES_LIMIT_S // 2), (max(threads + 1, ncpu // 2), ALL_CORES_LIMIT_S)):
             if nthr <= threads or any(t["threads"] == nthr for t in tried):
                 continue
             mark(f"cpu_baseline: all-cores probe ({nthr} threads, child process, {limit} s limit)")
