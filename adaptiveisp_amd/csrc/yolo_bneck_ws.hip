@@ -20,6 +20,9 @@
 // Both GEMMs accumulate in fp32 over k in the order the stand-alone kernels use.
 #include "yolo_internal.h"
 #include <type_traits>
+#ifndef BWS_PRIO
+#define BWS_PRIO 1          // waves 0-3 at priority 2 (yolo_conv_ws.hip's arrangement); 0: all waves equal (measurement)
+#endif
 
 namespace adayolo {
 namespace bws {
@@ -110,7 +113,9 @@ __global__ __launch_bounds__(512) void k_bneck_ws(const BwsArgs a) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int pg = wave / G::NCG, cg = wave % G::NCG;
+#if BWS_PRIO
     if (wave < 4) __builtin_amdgcn_s_setprio(2);          // waves w and w + 4 share a SIMD (same channels, other pixels): see stage C
+#endif
     const int ntiles = a.B * a.tiles_y * a.tiles_x;
     const int fq = lane >> 5, fr = lane & 31;
 
