@@ -226,6 +226,8 @@ class Agent(nn.Module):
             raise ValueError("current just support shared_feature_extractor")
         x_down = self.down_sample(x)
         coef = (1.0 - progress) * self.cfg.exploration_penalty
+        if train and self.entropy_coef_dev is not None:
+            coef = self.entropy_coef_dev                     # a captured iteration: the coefficient is a device scalar the host refreshes
         res = self.policy_heads(
             x_down, z[:, 0:1], states, coef, train=bool(train), forced_id=selected_filter_id, with_masks=not train)
         packed, op_ids, selected, surrogate, penalty, new_states, pdf, table = res[:8]
@@ -275,6 +277,9 @@ class Agent(nn.Module):
     # summation order differs from ten separate nn.Linear calls, so results agree to fp32 rounding, not bit for bit
     # (tests/test_host_logic.py::test_batched_heads_match_the_per_filter_heads). `agent.batched_heads = False` restores the loop.
     batched_heads = True
+    # Training under a captured hipGraph (train.Trainer, graph mode): a 1-element fp32 DEVICE tensor that holds
+    # (1 - progress) * cfg.exploration_penalty of the current iteration; forward() then ignores `progress` for that coefficient
+    entropy_coef_dev = None
 
     def _head_consts(self, device):
         c = self._head_cache
@@ -353,7 +358,8 @@ class Agent(nn.Module):
         B = x_down.shape[0]
         masks = []
         batched = train and not with_masks and self.batched_heads and self._head_consts(x_down.device) is not None
-        if batched and x_down.is_cuda and isinstance(entropy_coef, (int, float)):
+        if batched and x_down.is_cuda and (isinstance(entropy_coef, (int, float)) or
+                                           (isinstance(entropy_coef, torch.Tensor) and entropy_coef.numel() == 1)):
             # regressors, pdf, sampling, surrogate, gather, state update, penalties: one launch each way (policy_train.py)
             from . import policy_train
             x = self._heads_pre(filter_features)

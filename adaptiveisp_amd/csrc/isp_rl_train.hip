@@ -279,7 +279,7 @@ __global__ __launch_bounds__(256) void k_policy_tail_fwd(adaisp_policy_tail_args
             usage_pen += st[3 + k] * oh;
             ns[3 + k] = fmaxf(st[3 + k], oh);
         }
-        const float entropy_pen = a.entropy_coef * (-ent + a.log_num_filters);
+        const float entropy_pen = (a.entropy_coef_dev ? *a.entropy_coef_dev : a.entropy_coef) * (-ent + a.log_num_filters);
         const float early = (1.0f - last) * last * a.early_stop_penalty;
         float runtime_pen = 0.0f;
         if (a.runtime && sel >= 0 && sel < F) runtime_pen = a.runtime_lambda * a.runtime[sel];
@@ -349,7 +349,7 @@ __global__ __launch_bounds__(256) void k_policy_tail_bwd(adaisp_policy_tail_args
         }
         tot += 1e-30f;
         const float dsur = a.d_surrogate ? a.d_surrogate[b] : 0.0f;
-        const float dpen = (a.d_penalty ? a.d_penalty[b] : 0.0f) * a.entropy_coef;
+        const float dpen = (a.d_penalty ? a.d_penalty[b] : 0.0f) * (a.entropy_coef_dev ? *a.entropy_coef_dev : a.entropy_coef);
         float dotp = 0.0f;
         for (int k = 0; k < F; ++k) {
             dpdf[k] = dpen * (logf(pdf[k]) + 1.0f);
@@ -453,7 +453,8 @@ __global__ __launch_bounds__(256) void k_gradnorm_finish(float* __restrict__ ws,
 }
 
 __global__ __launch_bounds__(256) void k_adam(const adaisp_adam_tensor* __restrict__ table, int ntensors, const float* __restrict__ coefp,
-                                              double lr, double beta1, double beta2, double eps) {
+                                              double lr, const double* __restrict__ lr_dev, double beta1, double beta2, double eps) {
+    if (lr_dev) lr = *lr_dev;                                             // (a captured launch: this iteration's learning rate)
     const long chunk = blockIdx.x;
     const adaisp_adam_tensor t = table[find_tensor(table, ntensors, chunk)];
     const long lo = (chunk - t.chunk0) * kChunk, hi = lo + kChunk < t.n ? lo + kChunk : t.n;
@@ -556,8 +557,8 @@ int adaisp_image_stats(const float* img, float* stats, float* workspace, int B, 
     return hipGetLastError() == hipSuccess ? ADAISP_OK : ADAISP_ELAUNCH;
 }
 
-int adaisp_clip_adam_step(const adaisp_adam_tensor* table, int ntensors, long nchunks, float* workspace, float max_norm, double lr,
-                          double beta1, double beta2, double eps, void* stream) {
+static int clip_adam(const adaisp_adam_tensor* table, int ntensors, long nchunks, float* workspace, float max_norm, double lr,
+                     const double* lr_dev, double beta1, double beta2, double eps, void* stream) {
     if (!table || !workspace || ntensors < 1 || nchunks < 1 || nchunks > 0x7fffffffL) return ADAISP_EINVAL;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const bool clip = max_norm > 0.0f;
@@ -566,8 +567,19 @@ int adaisp_clip_adam_step(const adaisp_adam_tensor* table, int ntensors, long nc
         hipLaunchKernelGGL(k_gradnorm_finish, dim3(1), dim3(256), 0, s, workspace, nchunks, max_norm);
     }
     hipLaunchKernelGGL(k_adam, dim3((unsigned)nchunks), dim3(256), 0, s, table, ntensors,
-                       clip ? workspace + nchunks : static_cast<const float*>(nullptr), lr, beta1, beta2, eps);
+                       clip ? workspace + nchunks : static_cast<const float*>(nullptr), lr, lr_dev, beta1, beta2, eps);
     return hipGetLastError() == hipSuccess ? ADAISP_OK : ADAISP_ELAUNCH;
+}
+
+int adaisp_clip_adam_step(const adaisp_adam_tensor* table, int ntensors, long nchunks, float* workspace, float max_norm, double lr,
+                          double beta1, double beta2, double eps, void* stream) {
+    return clip_adam(table, ntensors, nchunks, workspace, max_norm, lr, nullptr, beta1, beta2, eps, stream);
+}
+
+int adaisp_clip_adam_step_dev(const adaisp_adam_tensor* table, int ntensors, long nchunks, float* workspace, float max_norm,
+                              const double* lr_dev, double beta1, double beta2, double eps, void* stream) {
+    if (!lr_dev) return ADAISP_EINVAL;
+    return clip_adam(table, ntensors, nchunks, workspace, max_norm, 0.0, lr_dev, beta1, beta2, eps, stream);
 }
 
 static int tail_check(const adaisp_policy_tail_args* a) {

@@ -184,28 +184,44 @@ def _same_params(model, opt, cached):
     return hit
 
 
-def synced_step(models, optimizers, buckets, max_grad_norm=1e-5):
-    """After loss.backward(): all-reduce(mean) the gradients (one bucket = one collective), clip, step.
-    Mirrors train.py:341-351 with the collective inserted before the clip."""
-    optimizers = list(optimizers)
+def reduce_gradients(buckets):
+    """The iteration's collective: every bucket all-reduced (mean) and scattered back into .grad."""
     works = [b.all_reduce_mean(async_op=GradBucket._active()) for b in buckets]
     for b, w in zip(buckets, works):
         b.finish(w)
+
+
+def synced_step(models, optimizers, buckets, max_grad_norm=1e-5, lr_dev=None, collective=True, release=True):
+    """After loss.backward(): all-reduce(mean) the gradients (one bucket = one collective), clip, step.
+    Mirrors train.py:341-351 with the collective inserted before the clip. `lr_dev`: per optimizer a 1-element float64 device
+    tensor holding its learning rate (captured iterations: optim.clip_adam_step); such an optimizer MUST be served by the
+    kernels — torch's step would bake the host-side rate into the capture. `collective=False`: the caller has already reduced
+    the gradients (`reduce_gradients`); `release=False`: the gradients stay where they are after the step (a captured backward
+    writes them to the same addresses at every replay) instead of zero_grad(set_to_none=True)."""
+    optimizers = list(optimizers)
+    if collective:
+        reduce_gradients(buckets)
     cached = {id(m): ps for b in buckets for m, ps in zip(getattr(b, "modules", ()), getattr(b, "per_module", ()))}
     from . import optim as aoptim
     paired = len(models) == len(optimizers)
     for i, m in enumerate(models):
         # clip + Adam of one model as three launches where the kernels serve the optimizer (optim.clip_adam_step), else torch's
-        if paired and _same_params(m, optimizers[i], cached) and aoptim.clip_adam_step(optimizers[i], max_grad_norm):
-            optimizers[i].zero_grad(set_to_none=True)
+        if paired and _same_params(m, optimizers[i], cached) and aoptim.clip_adam_step(
+                optimizers[i], max_grad_norm, lr_dev=None if lr_dev is None else lr_dev[i]):
+            if release:
+                optimizers[i].zero_grad(set_to_none=True)
             optimizers[i] = None
             continue
+        if lr_dev is not None:
+            raise RuntimeError("synced_step: lr_dev given but the clip + Adam kernels do not serve this optimizer "
+                               "(optim.clip_adam_step): a captured step needs them")
         torch.nn.utils.clip_grad_norm_(cached.get(id(m)) or list(m.parameters()), max_grad_norm)
     for o in optimizers:
         if o is None:
             continue
         o.step()
-        o.zero_grad(set_to_none=True)       # (the reference's default too: the next backward writes the gradients instead of adding to zeros)
+        if release:
+            o.zero_grad(set_to_none=True)   # (the reference's default too: the next backward writes the gradients instead of adding to zeros)
 
 
 def launch_ranks(n, target, argv, module=False):

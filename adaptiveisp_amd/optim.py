@@ -33,9 +33,11 @@ def _served(opt):
             and not isinstance(g["betas"][0], torch.Tensor))
 
 
-def clip_adam_step(opt, max_norm):
+def clip_adam_step(opt, max_norm, lr_dev=None):
     """clip_grad_norm_(the optimizer's parameters, max_norm) + opt.step() on the kernels. Returns False — nothing done — when
-    the kernels do not serve this optimizer in this state (the caller then runs torch's clip and step)."""
+    the kernels do not serve this optimizer in this state (the caller then runs torch's clip and step). `lr_dev`: a 1-element
+    float64 DEVICE tensor the kernels read the learning rate from instead of `param_groups[0]["lr"]` (an iteration captured in
+    a hipGraph: the host refreshes the scalar, the launch stays the same)."""
     if not (enabled() and _served(opt)):
         return False
     group = opt.param_groups[0]
@@ -62,7 +64,10 @@ def clip_adam_step(opt, max_norm):
             steps.append(st["step"])
             chunk0 += (n + CHUNK - 1) // CHUNK
         cache = opt.__dict__["_adaisp_table"] = dict(sig=sig, rows=np.array(rows, dtype=np.int64), steps=steps, nchunks=chunk0,
-                                                     ws=torch.empty((chunk0 + 2,), dtype=torch.float32, device=dev))
+                                                     ws=torch.empty((chunk0 + 2,), dtype=torch.float32, device=dev),
+                                                     # the table's staging block for a CAPTURED step (a pinned allocation
+                                                     # inside a stream capture invalidates it)
+                                                     pinned=torch.empty((len(rows), 7), dtype=torch.int64, pin_memory=True))
     table = cache["rows"].copy()
     for i, p in enumerate(params):
         g, st = p.grad, opt.state[p]
@@ -71,16 +76,28 @@ def clip_adam_step(opt, max_norm):
         # load_state_dict (a resumed checkpoint) replaces the state tensors: the cached addresses must still be theirs
         if st["exp_avg"].data_ptr() != table[i, 2] or st["exp_avg_sq"].data_ptr() != table[i, 3] or st["step"].data_ptr() != table[i, 4]:
             opt.__dict__.pop("_adaisp_table", None)
-            return clip_adam_step(opt, max_norm)
+            return clip_adam_step(opt, max_norm, lr_dev=lr_dev)
         table[i, 1] = g.data_ptr()
     L = _lib.load()
     torch._foreach_add_(cache["steps"], 1)
-    dtable = to_device_async(table, dev)
+    if torch.cuda.is_current_stream_capturing():
+        # the copy becomes a node of the graph that reads this block at every replay: it stays as it is (the gradients of a
+        # replay live where the capture's did) and alive with the optimizer
+        cache["pinned"].copy_(torch.from_numpy(table))
+        dtable = cache["pinned"].to(dev, non_blocking=True)
+    else:
+        dtable = to_device_async(table, dev)
     b1, b2 = group["betas"]
+    mn = float(max_norm) if max_norm is not None else 0.0
     with torch.cuda.device(dev):
-        rc = L.adaisp_clip_adam_step(dtable.data_ptr(), len(params), cache["nchunks"], cache["ws"].data_ptr(),
-                                     float(max_norm) if max_norm is not None else 0.0, float(group["lr"]), float(b1), float(b2),
-                                     float(group["eps"]), _lib._stream())
+        if lr_dev is not None:
+            if lr_dev.dtype != torch.float64 or lr_dev.numel() != 1 or lr_dev.device != dev:
+                raise ValueError("lr_dev: a 1-element float64 tensor on the parameters' device")
+            rc = L.adaisp_clip_adam_step_dev(dtable.data_ptr(), len(params), cache["nchunks"], cache["ws"].data_ptr(), mn,
+                                             lr_dev.data_ptr(), float(b1), float(b2), float(group["eps"]), _lib._stream())
+        else:
+            rc = L.adaisp_clip_adam_step(dtable.data_ptr(), len(params), cache["nchunks"], cache["ws"].data_ptr(), mn,
+                                         float(group["lr"]), float(b1), float(b2), float(group["eps"]), _lib._stream())
     _lib._check(rc, "adaisp_clip_adam_step")
     for p in params:                                           # written through raw pointers
         _lib._wrote(p)

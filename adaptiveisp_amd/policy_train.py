@@ -23,7 +23,7 @@ class _TailArgs(ctypes.Structure):
                 [("reg", _Regressor * MAX_FILTERS)] +
                 [(k, ctypes.c_void_p) for k in ("x", "logits", "noise", "states", "runtime", "table", "packed", "op_ids",
                                                 "selected", "pdf", "surrogate", "new_states", "penalty", "d_packed",
-                                                "d_surrogate", "d_penalty", "d_x", "d_logits")])
+                                                "d_surrogate", "d_penalty", "d_x", "d_logits", "entropy_coef_dev")])
 
 
 def enabled():
@@ -45,7 +45,11 @@ class _TailFn(torch.autograd.Function):
         a.noise_stride = int(noise.stride(0)) if noise.dim() > 1 else 1
         a.sample, a.forced_id = 1 if sample else 0, -1 if forced_id is None else int(forced_id)
         a.one_minus_exploration, a.exploration_over_f = 1 - cfg.exploration, cfg.exploration * 1.0 / F
-        a.entropy_coef, a.log_num_filters, a.test_steps = float(entropy_coef), math.log(F), cfg.test_steps
+        if isinstance(entropy_coef, torch.Tensor):       # a device scalar read by the kernels at run time (captured iterations)
+            a.entropy_coef, a.entropy_coef_dev = 0.0, entropy_coef.data_ptr()
+        else:
+            a.entropy_coef, a.entropy_coef_dev = float(entropy_coef), None
+        a.log_num_filters, a.test_steps = math.log(F), cfg.test_steps
         a.filter_usage_penalty, a.early_stop_penalty = cfg.filter_usage_penalty, cfg.early_stop_penalty
         a.runtime_lambda = cfg.filter_runtime_penalty_lambda if cfg.filter_runtime_penalty else 0.0
         for j, f in enumerate(agent.filters):
@@ -60,7 +64,7 @@ class _TailFn(torch.autograd.Function):
         a.pdf, a.surrogate, a.new_states, a.penalty = pdf.data_ptr(), surrogate.data_ptr(), new_states.data_ptr(), penalty.data_ptr()
         with torch.cuda.device(dev):
             _lib._check(L.adaisp_policy_tail_fwd(ctypes.byref(a), _lib._stream()), "adaisp_policy_tail_fwd")
-        ctx.a, ctx.keep = a, (x, logits, noise, states, runtime, pdf, selected)
+        ctx.a, ctx.keep = a, (x, logits, noise, states, runtime, pdf, selected, entropy_coef)
         ctx.mark_non_differentiable(op_ids, selected, new_states, pdf, table)
         return packed, op_ids, selected, surrogate, penalty, new_states, pdf, table
 
@@ -78,9 +82,13 @@ class _TailFn(torch.autograd.Function):
         return None, None, None, None, d_x, d_logits, None, None
 
 
+def _is_dev_scalar(t, like):
+    return isinstance(t, torch.Tensor) and t.numel() == 1 and t.dtype == torch.float32 and t.device == like.device and not t.requires_grad
+
+
 def serves(agent, x, logits, entropy_coef):
     return (enabled() and x.is_cuda and x.dtype == torch.float32 and logits.dtype == torch.float32
-            and isinstance(entropy_coef, (int, float)) and len(agent.filters) <= MAX_FILTERS
+            and (isinstance(entropy_coef, (int, float)) or _is_dev_scalar(entropy_coef, x)) and len(agent.filters) <= MAX_FILTERS
             and x.shape[2] <= 24 and all(f._regressor is not None for f in agent.filters))
 
 

@@ -139,22 +139,31 @@ def retouch_stats(retouch):
 
 
 def train_iteration(cfg, agent, value, detector, loss_fn, imgs, z, states, labels, progress, optimizers, buckets=None,
-                    use_truncated=True, max_bri=0.9, on_retouch=None):
+                    use_truncated=True, max_bri=0.9, on_retouch=None, assigned=None, lr_dev=None, step=True):
     """One optimisation step (train.py:255-351). `detector(x)` must return the three raw head maps with autograd
     through to x (the frozen reward model); `buckets` (adaptiveisp_amd.dist.GradBucket per model) enables the
     data-parallel gradient all-reduce before the 1e-5 clip. `on_retouch(retouch)` is called as soon as the retouched batch
     is enqueued, with `retouch_stats(retouch)` and the new state vectors as further arguments (the trainer starts its NaN /
     brightness guard and the read-back of the states there, long before the iteration's backward is launched).
+    `assigned` = (packed, packed_pair): the labels' target assignment already on the device (yolo.loss.StaticLabelTables — an
+    iteration captured in a hipGraph reads tables of fixed address; `labels` is then unused); `lr_dev`: dist.synced_step;
+    `step=False`: stop after backward() — the caller runs the collective and the optimizers (a capture split around an
+    all-reduce that stays outside it).
     Returns the scalars of td_losses plus the retouched batch."""
     from . import dist as adist
     from .yolo.loss import batched_per_sample_loss as per_sample_loss
     from .yolo.loss import assign_labels, assign_labels_packed
     values = None
+    if assigned is not None and getattr(detector, "per_sample_loss_pair", None) is None:
+        raise ValueError("train_iteration: `assigned` tables are for the pair engine (yolo.YoloTrainPairEngine)")
     if getattr(detector, "per_sample_loss_pair", None) is not None:
         # HIP training engine, pair form (yolo.YoloTrainPairEngine): ONE detector forward over [input batch; retouched batch],
         # one loss launch for both, the backward over the retouched half only
-        with torch.no_grad():
-            packed, packed_pair = assign_labels_packed(loss_fn, detector.head_shapes(), labels, imgs.device, pair=True)
+        if assigned is not None:
+            packed, packed_pair = assigned
+        else:
+            with torch.no_grad():
+                packed, packed_pair = assign_labels_packed(loss_fn, detector.head_shapes(), labels, imgs.device, pair=True)
         (retouch, new_states, surrogate, penalty), _, _ = agent((imgs, z, states), progress)
         stats = retouch_stats(retouch)
         if on_retouch is not None:
@@ -225,9 +234,10 @@ def train_iteration(cfg, agent, value, detector, loss_fn, imgs, z, states, label
     # deposits the same sums (and the critic's two calls may share autograd nodes)
     torch.autograd.backward([out["value_loss"], out["agent_loss"]])
     models = [agent, value]
-    if buckets is None:
-        buckets = [adist.GradBucket(*models)]
-    adist.synced_step(models, optimizers, buckets, max_grad_norm=1e-5)
+    if step:
+        if buckets is None:
+            buckets = [adist.GradBucket(*models)]
+        adist.synced_step(models, optimizers, buckets, max_grad_norm=1e-5, lr_dev=lr_dev)
     out["retouch"] = retouch.detach()
     out["new_states"] = new_states.detach()
     out["detect_loss_input"], out["detect_loss_retouch"] = l_in.detach(), l_re.detach()

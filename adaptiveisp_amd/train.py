@@ -21,12 +21,17 @@ from .yolo.checkpoint import save_isp_checkpoint
 
 class Trainer:
     def __init__(self, cfg, agent, value, detector, loss_fn, replay, batch_size, lr=3e-5, epochs=800, save_dir=None,
-                 use_truncated=True, max_bri=0.9, rank=0, world=1, sync_bn=False):
+                 use_truncated=True, max_bri=0.9, rank=0, world=1, sync_bn=False, graph=None):
         """`detector(x)` returns the three raw head maps with autograd to x (frozen reward model in train mode with
         BN in eval, train.py:236-243). `epochs` -> max_iter_step = epochs*1000//batch_size as train.py:156 (the global
         batch: per-rank batch x world). `sync_bn`: under data parallelism, compute the BatchNorm statistics of the
         agent / value CNNs (agent.py:40,51; value.py:22,34 run in train mode) over the GLOBAL batch with
-        torch.nn.SyncBatchNorm — the single-GPU batch-64 semantics of the reference — instead of per rank."""
+        torch.nn.SyncBatchNorm — the single-GPU batch-64 semantics of the reference — instead of per rank.
+        `graph` (default: ADAISP_TRAIN_GRAPH, "1"): after `graph_warmup` ordinary iterations the whole iteration — agent,
+        detector pair, critic, TD losses, backward, clip + Adam of both models — is captured ONCE as a hipGraph and replayed
+        (see _GraphIteration); the host's work per iteration is then the replay pool's bookkeeping, the label assignment and
+        one upload. Under data parallelism (world > 1) the capture is split around the gradient all-reduce, which is issued as
+        before. Needs a HIP device and the pair engine; anything else runs the ordinary loop."""
         if sync_bn and world > 1:
             agent = torch.nn.SyncBatchNorm.convert_sync_batchnorm(agent)
             value = torch.nn.SyncBatchNorm.convert_sync_batchnorm(value)
@@ -46,18 +51,31 @@ class Trainer:
         self.value_scheduler = torch.optim.lr_scheduler.LambdaLR(self.value_optimizer, lr_lambda=lf)
         self.buckets = [adist.GradBucket(agent, value)]          # ONE flattened bucket = one collective per iteration
         self.iter = 0
+        want = os.environ.get("ADAISP_TRAIN_GRAPH", "1") == "1" if graph is None else bool(graph)
+        self.graph_mode = bool(want and next(agent.parameters()).is_cuda and not (sync_bn and world > 1)   # (SyncBatchNorm: collectives inside the forward)
+                               and getattr(detector, "per_sample_loss_pair", None) is not None)
+        # world > 1: the gradient all-reduce stays OUTSIDE the capture (two graphs per iteration: forward + backward | clip + Adam);
+        # graph="split" forces that form on one rank (tests)
+        self.graph_split = bool(self.graph_mode and (world > 1 or graph == "split"))
+        self.graph_warmup = 3            # ordinary iterations first: Adam's state and every lazily built table exist, every kernel has run
+        self._git = None
         self._flag_host = self._states_host = None
         adist.broadcast_parameters([agent, value], src=0)
         self.history = []
 
     def step(self):
+        feed = self.replay.get_feed_dict_and_states(self.batch_size)
+        if self.graph_mode and self.iter >= self.graph_warmup:
+            return self._step_graph(feed)
+        return self._step_ordinary(feed)
+
+    def _step_ordinary(self, feed):
         it = self.iter
         if not self.agent.training:                          # (Module.train() walks ~130 modules: only when the mode changes)
             self.agent.train()
         if not self.value.training:
             self.value.train()
         progress = float(it) / self.max_iter_step
-        feed = self.replay.get_feed_dict_and_states(self.batch_size)
         labels = [torch.as_tensor(lb) for lb in feed["label"]]
         guard = {}
 
@@ -119,6 +137,59 @@ class Trainer:
             self.save(it)
         return rec
 
+    # ---- the iteration as ONE hipGraph ----------------------------------------------------------------------------------
+    def _step_graph(self, feed):
+        """step() with the device side of the iteration replayed from a hipGraph (_GraphIteration). What stays on the host:
+        drawing the batch (replay.py), the labels' target assignment (yolo.loss.assign_labels_host), ONE upload of the tables
+        and the iteration's three scalars, the replay, the guard's verdict and the pool update. Same arithmetic, same order of
+        launches as the ordinary step."""
+        it = self.iter
+        progress = float(it) / self.max_iter_step
+        G = self._git
+        if G is None:
+            G = self._git = _GraphIteration(self, feed, split=self.graph_split)
+        while not G.tables.fill(feed["label"]):              # more matches than the tables hold: larger tables, new capture
+            G = self._git = _GraphIteration(self, feed, cap=2 * G.tables.cap, split=self.graph_split)
+        G.set_scalars((1.0 - progress) * self.cfg.exploration_penalty, self.agent_optimizer.param_groups[0]["lr"],
+                      self.value_optimizer.param_groups[0]["lr"])
+        G.im.copy_(feed["im"])
+        G.z.copy_(feed["z"])
+        G.state.copy_(feed["state"])
+        G.tables.upload()
+        if G.graph is None:
+            try:
+                G.capture()
+            except Exception as e:                           # noqa: BLE001 — nothing has run yet: this iteration and the rest take the ordinary loop
+                import warnings
+                warnings.warn(f"adaptiveisp_amd.train: the iteration could not be captured as a hipGraph ({type(e).__name__}: "
+                              f"{str(e)[:300]}); continuing with the ordinary loop", RuntimeWarning)
+                self.graph_mode, self._git = False, None
+                for opt in (self.agent_optimizer, self.value_optimizer):
+                    opt.zero_grad(set_to_none=True)
+                torch.cuda.synchronize(G.dev)
+                return self._step_ordinary(feed)
+        G.replay()
+        for opt in (self.agent_optimizer, self.value_optimizer):     # what Optimizer.step's wrapper records (LambdaLR looks at it)
+            opt._opt_called = True
+            if hasattr(opt, "_step_count"):
+                opt._step_count += 1
+        self.agent_scheduler.step()
+        self.value_scheduler.step()
+        bad, states_host = G.wait_guard()                    # ~1 ms into the iteration: its backward is still running
+        if bad:
+            self.replay.drop_batch(feed["records"])
+        else:
+            self.replay.replace_memory(feed["records"], G.out["retouch"], states_host, slots=feed.get("slots"))
+        slot = G.keep_scalars(it)
+        rec = dict(iter=it, agent_loss=slot[0], value_loss=slot[1], reward=slot[2], dropped=bad)
+        self.history.append(rec)
+        self.iter += 1
+        if it % 256 == 255:
+            self.materialize()                               # (and frees the 256 slots of G.keep_scalars)
+        if self.save_dir and self.rank == 0 and it % self.cfg.save_model_freq == 0 and it > 0:
+            self.save(it)
+        return rec
+
     def materialize(self):
         """History entries as plain floats (one synchronisation for all that are still device tensors)."""
         for rec in self.history:
@@ -138,6 +209,119 @@ class Trainer:
         path = os.path.join(self.save_dir, "ckpt-%d.pth" % it)           # train.py:473 naming
         save_isp_checkpoint(path, it, self.agent, self.value, self.agent_optimizer, self.value_optimizer)
         return path
+
+
+class _GraphIteration:
+    """One RL iteration (rl.train_iteration over the pair engine) captured as a hipGraph. Everything that changes between
+    iterations enters through memory of fixed address:
+      im / z / state                 the batch the replay pool drew (copied in before the replay)
+      tables                         the labels' target assignment, fixed row count, padded with rows of no image
+                                     (yolo.loss.StaticLabelTables), and behind it in the SAME upload the iteration's scalars:
+      coef (fp32)                    (1 - progress) * exploration_penalty   -> adaisp_policy_tail_args.entropy_coef_dev
+      lr[0], lr[1] (fp64)            the two optimizers' learning rates      -> adaisp_clip_adam_step_dev
+    and leaves through pinned host memory the device writes ~1 ms into the iteration, on the side stream, in this order: the
+    guard's flag (train.py:374-381), the new state vectors, a sequence number. The host polls the sequence number
+    (wait_guard) — an event recorded inside a capture cannot be waited on from the host — reads flag and states, and does the
+    pool's bookkeeping and the next batch's label assignment while the iteration's backward runs. The detector engines launch
+    their kernels one by one inside the capture (train_engine._graph: no nested graph replay); the critic's two calls and the
+    guard fork onto the side stream inside the capture and join before its end.
+    Nothing is executed at capture time: the captured iteration runs for the first time at its first replay, so a trainer
+    in graph mode makes the same sequence of updates as one in the ordinary loop (tests/test_gpu_train_graph.py)."""
+
+    def __init__(self, tr, feed, cap=512, split=False):
+        from .yolo.loss import StaticLabelTables
+        self.tr, self.split = tr, bool(split)
+        dev = feed["im"].device
+        self.dev = dev
+        B = tr.batch_size
+        self.tables = StaticLabelTables(tr.loss_fn, tr.detector.head_shapes(), B, dev, cap=cap, extra_words=6)
+        ed, eh = self.tables.extra_dev, self.tables.extra_host.numpy()
+        self.coef = ed[0:1].view(torch.float32)
+        self.lr = [ed[2:4].view(torch.float64), ed[4:6].view(torch.float64)]
+        import numpy as np
+        self._coef_h, self._lr_h = eh[0:1].view(np.float32), [eh[2:4].view(np.float64), eh[4:6].view(np.float64)]
+        self.im, self.z, self.state = (torch.empty_like(feed[k]) for k in ("im", "z", "state"))
+        self.flag_host = torch.zeros((1,), dtype=torch.bool, pin_memory=True)
+        self.states_host = torch.zeros(tuple(feed["state"].shape), dtype=feed["state"].dtype, pin_memory=True)
+        self.seq_host = torch.zeros((1,), dtype=torch.int32, pin_memory=True)
+        self.seq_dev = torch.zeros((1,), dtype=torch.int32, device=dev)
+        self._seq_np, self._replays = self.seq_host.numpy(), 0
+        self.scalars = torch.zeros((256, 3), dtype=torch.float32, device=dev)
+        self.graph = self.graph_step = self.out = self.vec3 = None
+
+    def set_scalars(self, coef, lr_agent, lr_value):
+        self._coef_h[0] = coef                               # (rounded to fp32 as the by-value kernel argument is)
+        self._lr_h[0][0], self._lr_h[1][0] = lr_agent, lr_value
+
+    def _guard(self, retouch, stats, new_states):
+        from .rl import _side_stream
+        tr = self.tr
+        cur, side = torch.cuda.current_stream(), _side_stream(self.dev)
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            mean = stats[:, 0].mean()
+            flag = ((stats[:, 1].sum() > 0) | ~torch.isfinite(mean) | (mean < 0.01) | (mean > tr.max_bri)).reshape(1)
+            self.flag_host.copy_(flag, non_blocking=True)
+            self.states_host.copy_(new_states, non_blocking=True)
+            self.seq_dev.add_(1)
+            self.seq_host.copy_(self.seq_dev, non_blocking=True)
+        stats.record_stream(side)
+        new_states.record_stream(side)
+
+    def capture(self):
+        from .rl import _side_stream
+        tr = self.tr
+        for m in (tr.agent, tr.value):
+            if not m.training:
+                m.train()
+        tr.agent.entropy_coef_dev = self.coef
+        torch.cuda.synchronize(self.dev)
+        from . import dist as adist
+        g, g2 = torch.cuda.CUDAGraph(), None
+        opts = [tr.agent_optimizer, tr.value_optimizer]
+        try:
+            with torch.cuda.graph(g):
+                out = train_iteration(tr.cfg, tr.agent, tr.value, tr.detector, tr.loss_fn, self.im, self.z, self.state, None, 0.0,
+                                      opts, buckets=tr.buckets, use_truncated=tr.use_truncated, max_bri=tr.max_bri,
+                                      on_retouch=self._guard, assigned=(self.tables.packed, self.tables.packed_pair),
+                                      lr_dev=self.lr, step=not self.split)
+                self.vec3 = torch.stack([out["agent_loss"].detach().reshape(()), out["value_loss"].detach().reshape(()),
+                                         out["reward"].detach().mean()])
+                torch.cuda.current_stream().wait_stream(_side_stream(self.dev))      # (joined whatever the stream switches say)
+            if self.split:
+                # the gradients now sit at fixed addresses (every replay of the first graph writes them there); the collective
+                # runs on them between the two replays; the second graph clips and steps from the same addresses
+                g2 = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g2, pool=g.pool()):
+                    adist.synced_step([tr.agent, tr.value], opts, tr.buckets or [], max_grad_norm=1e-5, lr_dev=self.lr,
+                                      collective=False, release=False)
+        finally:
+            tr.agent.entropy_coef_dev = None
+        self.graph, self.graph_step, self.out = g, g2, out
+
+    def replay(self):
+        self.graph.replay()
+        if self.split:
+            from . import dist as adist
+            adist.reduce_gradients(self.tr.buckets or [])
+            self.graph_step.replay()
+
+    def wait_guard(self, timeout=120.0):
+        """The guard's verdict and the new states of the replay launched last, as soon as the device has written them."""
+        import time
+        self._replays += 1
+        want, t0, spins = self._replays, time.perf_counter(), 0
+        while int(self._seq_np[0]) != want:
+            spins += 1
+            if spins & 1023 == 0 and time.perf_counter() - t0 > timeout:
+                raise RuntimeError(f"graph iteration: the guard's sequence number did not reach {want} within {timeout} s "
+                                   f"(it reads {int(self._seq_np[0])})")
+        return bool(self.flag_host[0]), self.states_host.numpy().copy()
+
+    def keep_scalars(self, it):
+        slot = self.scalars[it % 256]
+        slot.copy_(self.vec3)
+        return slot
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -303,6 +487,8 @@ def main(argv=None):
                           # what the N > 1 semantics are: BatchNorm statistics of the agent / value CNNs per rank (False) or
                           # over the global batch (True = the reference's single-GPU batch-64 behaviour); gradients of both
                           # models travel in ONE flattened all-reduce per iteration
+                          "graph": (("split" if tr.graph_split else "one") if getattr(tr, "_git", None) is not None
+                                    and tr._git.graph is not None else None),
                           "sync_bn": bool(a.sync_bn), "grad_buckets": 1, "grad_bucket_bytes": bucket_bytes,
                           "all_reduce_ms": round(ar_ms, 3) if ar_ms is not None else None,
                           "mask_fetches": getattr(bucket, "mask_fetches", 0),

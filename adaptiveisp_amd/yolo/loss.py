@@ -147,11 +147,10 @@ def pack_assigned(assigned):
     return packed
 
 
-def assign_labels_packed(loss_fn, shapes, labels, device, pair=False):
-    """`pack_assigned(assign_labels(...))` computed on the HOST in numpy (the labels are a handful of host rows; as
-    device-side PyTorch the assignment is ~200 launches and several synchronising boolean gathers, 2 ms per training
-    iteration) and moved to `device` in one copy per array. Same float32 arithmetic, same row order as
-    DetectionLoss.assign (build_targets, yolov3/utils/loss.py:320-380); tests/test_yolo_cpu.py checks equality."""
+def assign_labels_host(loss_fn, shapes, labels):
+    """The target assignment of `pack_assigned(assign_labels(...))` computed on the HOST in numpy: per layer (idx int32 [n,5],
+    box fp32 [n,6]). Same float32 arithmetic, same row order as DetectionLoss.assign (build_targets,
+    yolov3/utils/loss.py:320-380); tests/test_yolo_cpu.py checks equality."""
     import numpy as np
     f32 = np.float32
     rows = []
@@ -168,7 +167,7 @@ def assign_labels_packed(loss_fn, shapes, labels, device, pair=False):
     tgt = np.concatenate((np.repeat(targets[None], na, 0), ai[..., None]), 2)                 # [na, nt, 7]
     off = np.array([[0, 0], [1, 0], [0, 1], [-1, 0], [0, -1]], f32) * f32(0.5)
     thr = f32(loss_fn.hyp["anchor_t"])
-    packed, packed2, host = [], [], []      # (`pair`: also the assignment of the batch [labels; labels], see below)
+    host = []
     for i in range(loss_fn.nl):
         ny, nx = int(shapes[i].shape[2]), int(shapes[i].shape[3])
         gain = np.array([1, 1, nx, ny, nx, ny, 1], f32)
@@ -195,6 +194,16 @@ def assign_labels_packed(loss_fn, shapes, labels, device, pair=False):
         idx = np.stack((t[:, 0].astype(np.int64), a, gij[:, 1], gij[:, 0], t[:, 1].astype(np.int64)), 1).astype(np.int32)
         box = np.concatenate((gxy - gij.astype(f32), gwh, anc[i][a]), 1).astype(f32)
         host.append((np.ascontiguousarray(idx), np.ascontiguousarray(box)))
+    return host
+
+
+def assign_labels_packed(loss_fn, shapes, labels, device, pair=False):
+    """`pack_assigned(assign_labels(...))` computed on the HOST in numpy (assign_labels_host: the labels are a handful of host
+    rows; as device-side PyTorch the assignment is ~200 launches and several synchronising boolean gathers, 2 ms per training
+    iteration) and moved to `device` in one copy."""
+    import numpy as np
+    host = assign_labels_host(loss_fn, shapes, labels)
+    packed, packed2 = [], []                # (`pair`: also the assignment of the batch [labels; labels], see below)
     # ONE upload for all layers (int32 words; the fp32 boxes travel as their bit patterns) from pinned memory: a copy per array
     # from pageable memory makes torch synchronise the stream each time — the training loop would drain the GPU every iteration
     B = len(labels)
@@ -219,6 +228,54 @@ def assign_labels_packed(loss_fn, shapes, labels, device, pair=False):
         packed.append((d_idx[:n], d_box[:n]))
         packed2.append((d_idx, d_box))
     return (packed, packed2) if pair else packed
+
+
+class StaticLabelTables:
+    """The packed target assignment of an iteration in buffers of FIXED address and row count — what a training iteration
+    captured in a hipGraph reads (train.Trainer, graph mode): per layer `cap` rows of the [labels; labels] pair form, the rows
+    beyond the iteration's own filled with image index -1. The loss kernels walk a layer's list by image (csrc/yolo_loss.hip:
+    `if (id[0] != b) continue`, the same-cell scans compare the image index first), so a row of image -1 is a row of no image:
+    the results are those of the exact-size tables, bit for bit (tests/test_gpu_train_graph.py). `extra_words` int32 words
+    behind the tables travel in the same upload (the iteration's device scalars)."""
+
+    def __init__(self, loss_fn, shapes, batch, device, cap=512, extra_words=0):
+        self.loss_fn, self.shapes, self.B, self.cap, self.nl = loss_fn, shapes, int(batch), int(cap), loss_fn.nl
+        words = self.nl * self.cap * 11 + int(extra_words)
+        self.host = torch.empty((words,), dtype=torch.int32, pin_memory=torch.device(device).type == "cuda")
+        self.dev = torch.zeros((words,), dtype=torch.int32, device=device)
+        self.extra_host = self.host[self.nl * self.cap * 11:]
+        self.extra_dev = self.dev[self.nl * self.cap * 11:]
+        self.packed_pair, self._hviews = [], []
+        for i in range(self.nl):
+            o = i * self.cap * 11
+            self.packed_pair.append((self.dev[o:o + 5 * self.cap].view(self.cap, 5),
+                                     self.dev[o + 5 * self.cap:o + 11 * self.cap].view(torch.float32).view(self.cap, 6)))
+            self._hviews.append((self.host[o:o + 5 * self.cap].view(self.cap, 5).numpy(),
+                                 self.host[o + 5 * self.cap:o + 11 * self.cap].view(torch.float32).view(self.cap, 6).numpy()))
+        # the B-image engine of the pair (the backward over the retouched half) reads the SAME tables: the rows of images
+        # [B, 2B) are rows of no image of its own
+        self.packed = self.packed_pair
+
+    def fill(self, labels):
+        """Assign `labels` (B host label sets) on the host and write the pair tables into the staging block. False — nothing
+        written — when a layer has more rows than `cap` (the caller runs that iteration uncaptured or rebuilds with a larger cap)."""
+        host = assign_labels_host(self.loss_fn, self.shapes, labels)
+        if any(2 * idx.shape[0] > self.cap for idx, _ in host):
+            return False
+        import numpy as np
+        for (idx, box), (hi, hb) in zip(host, self._hviews):
+            n = idx.shape[0]
+            hi[:n] = idx
+            hi[n:2 * n] = idx + np.array([self.B, 0, 0, 0, 0], np.int32)
+            hi[2 * n:] = -1
+            hb[:n] = box
+            hb[n:2 * n] = box
+            hb[2 * n:] = 0.0
+        return True
+
+    def upload(self):
+        """One copy of the staging block (tables + extra words) to the device, on the current stream."""
+        self.dev.copy_(self.host, non_blocking=True)
 
 
 def batched_per_sample_loss(loss_fn, preds, labels, assigned=None):

@@ -754,11 +754,12 @@ def extra_train_iteration(dev, iters=8):
     of two iterations under torch.profiler (None if the profiler is unavailable)."""
     from adaptiveisp_amd.config import cfg
     from adaptiveisp_amd.train import build_trainer
+    from adaptiveisp_amd import train as atrain
     tr = build_trainer(cfg, 0, 1, dev, 8, 512, tune_cache=TUNE_CACHE)
-    tr.train(3)
+    tr.train(tr.graph_warmup + 3 if tr.graph_mode else 3)    # (graph mode: the ordinary iterations, the capture, two replays)
     torch.cuda.synchronize()
     waited = [0.0]
-    ev_sync, to_cpu = torch.cuda.Event.synchronize, torch.Tensor.cpu
+    ev_sync, to_cpu, wait_guard = torch.cuda.Event.synchronize, torch.Tensor.cpu, atrain._GraphIteration.wait_guard
 
     def timed(fn):
         def call(*x, **k):
@@ -768,6 +769,7 @@ def extra_train_iteration(dev, iters=8):
             return r
         return call
     torch.cuda.Event.synchronize, torch.Tensor.cpu = timed(ev_sync), timed(to_cpu)     # the host's waits for the GPU
+    atrain._GraphIteration.wait_guard = timed(wait_guard)    # (graph mode: the poll for the guard's flag, ~1 ms into the iteration)
     try:
         t0 = time.perf_counter()
         for _ in range(iters):
@@ -777,6 +779,7 @@ def extra_train_iteration(dev, iters=8):
         dt = (time.perf_counter() - t0) / iters
     finally:
         torch.cuda.Event.synchronize, torch.Tensor.cpu = ev_sync, to_cpu
+        atrain._GraphIteration.wait_guard = wait_guard
     kernel_ms = n_kernels = None
     try:
         from torch.profiler import ProfilerActivity, profile
@@ -792,6 +795,7 @@ def extra_train_iteration(dev, iters=8):
     tr.materialize()
     return {"workload": "config 4, per rank: RL iteration (agent + value + replay + frozen YOLOv3 on the input and the retouched batch + data gradient) batch 8 x 512x512",
             "detector": "one 16-image forward + 8-image backward" if hasattr(tr.detector, "half") else "two 8-image forwards + backward",
+            "one_hipgraph_per_iteration": bool(tr.graph_mode and tr._git is not None and tr._git.graph is not None),
             "ms_per_iteration": round(dt * 1e3, 2), "images_per_sec": round(8 / dt, 1), "iters": iters,
             "host_enqueue_ms": round((t_host - waited[0]) / iters * 1e3, 2), "host_wait_ms": round(waited[0] / iters * 1e3, 2),
             "kernel_ms": round(kernel_ms, 2) if kernel_ms is not None else None, "kernels_per_iteration": n_kernels}

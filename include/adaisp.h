@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define ADAISP_ABI_VERSION 6
+#define ADAISP_ABI_VERSION 7
 
 /* Kernel op codes. 0..9 follow the reference's default filter order (config.py:19-22). */
 enum adaisp_op {
@@ -344,6 +344,9 @@ typedef struct adaisp_policy_tail_args {
     /* backward only */
     const float *d_packed, *d_surrogate, *d_penalty;
     float *d_x, *d_logits;
+    /* non-NULL: the entropy coefficient is read from this DEVICE float at run time instead of `entropy_coef` (a launch captured
+     * in a hipGraph is replayed with the coefficient of its iteration: train.py:258 feeds `progress` anew every iteration) */
+    const float* entropy_coef_dev;
 } adaisp_policy_tail_args;
 int adaisp_policy_tail_fwd(const adaisp_policy_tail_args* args, void* stream);
 int adaisp_policy_tail_bwd(const adaisp_policy_tail_args* args, void* stream);
@@ -373,6 +376,10 @@ typedef struct adaisp_adam_tensor {
 } adaisp_adam_tensor;
 int adaisp_clip_adam_step(const adaisp_adam_tensor* table, int ntensors, long nchunks, float* workspace, float max_norm, double lr,
                           double beta1, double beta2, double eps, void* stream);
+/* The same with the learning rate read from a DEVICE double at run time (`lr_dev`): the launches of a captured iteration follow
+ * the LambdaLR schedule (train.py:206-218, 350-351) without a new kernel argument. Same arithmetic, same three launches. */
+int adaisp_clip_adam_step_dev(const adaisp_adam_tensor* table, int ntensors, long nchunks, float* workspace, float max_norm,
+                              const double* lr_dev, double beta1, double beta2, double eps, void* stream);
 
 /* Number of regressed parameters an op reads per image (0 for ADAISP_OP_ZERO, -1 if unknown). */
 int adaisp_num_params(int op);

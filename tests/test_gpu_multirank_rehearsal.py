@@ -37,9 +37,11 @@ def test_bench_two_ranks_on_one_device():
 
 
 def test_train_two_ranks_on_one_device():
-    line = _one_line(["-m", "adaptiveisp_amd.train", "--gpus", "2", "--iters", "4", "--warmup", "2", "--batch", "8", "--size", "512"],
+    # (6 iterations: three ordinary ones, then the iteration as two hipGraphs around the gradient all-reduce — train.Trainer)
+    line = _one_line(["-m", "adaptiveisp_amd.train", "--gpus", "2", "--iters", "6", "--warmup", "2", "--batch", "8", "--size", "512"],
                      {"ADAISP_DP_REHEARSAL": "1"})
-    assert line["n_gpus"] == 2 and line["global_batch"] == 16 and line["per_gpu_batch"] == 8 and line["iters"] == 2      # timed = iters - warmup
+    assert line["n_gpus"] == 2 and line["global_batch"] == 16 and line["per_gpu_batch"] == 8 and line["iters"] == 4      # timed = iters - warmup
+    assert line["graph"] == "split"
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "config"):
         assert k in line, k
     assert line["config"]["parallelism"] == "dp2" and line["scaling"] == "weak" and "REHEARSAL" in line["data"]

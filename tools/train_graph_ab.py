@@ -1,0 +1,78 @@
+#!/usr/bin/env python3
+"""BASELINE config 4, one rank's share (batch 8 x 512 x 512): the ordinary loop against the iteration as one hipGraph
+(train.Trainer graph mode), one process, alternating blocks. Per mode: ms per iteration, the host's time inside step() that is
+not waiting for the device (enqueue + bookkeeping), its waits. usage (GPU box): python tools/train_graph_ab.py [--iters 40] [--rounds 3]"""
+import argparse
+import os
+import statistics
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from adaptiveisp_amd import train as atrain  # noqa: E402
+from adaptiveisp_amd.config import cfg  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--iters", type=int, default=40)
+ap.add_argument("--rounds", type=int, default=3)
+ap.add_argument("--batch", type=int, default=8)
+ap.add_argument("--size", type=int, default=512)
+a = ap.parse_args()
+dev = torch.device("cuda:0")
+cache = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "adaptiveisp_amd", "yolo", "tuning", "mi355x.json")
+waited = [0.0]
+
+
+def timed(fn):
+    def call(*x, **k):
+        t = time.perf_counter()
+        r = fn(*x, **k)
+        waited[0] += time.perf_counter() - t
+        return r
+    return call
+
+
+torch.cuda.Event.synchronize = timed(torch.cuda.Event.synchronize)
+atrain._GraphIteration.wait_guard = timed(atrain._GraphIteration.wait_guard)
+trainers = {}
+for mode in (False, True):
+    os.environ["ADAISP_TRAIN_GRAPH"] = "1" if mode else "0"
+    trainers[mode] = atrain.build_trainer(cfg, 0, 1, dev, a.batch, a.size, tune_cache=cache, seed=0)
+    assert trainers[mode].graph_mode is mode
+    trainers[mode].train(6)
+    torch.cuda.synchronize()
+res = {m: [] for m in trainers}
+for rnd in range(a.rounds):
+    for mode, tr in trainers.items():
+        torch.cuda.synchronize()
+        waited[0] = 0.0
+        t0 = time.perf_counter()
+        for _ in range(a.iters):
+            tr.step()
+        t_host = time.perf_counter() - t0
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        res[mode].append((dt / a.iters * 1e3, (t_host - waited[0]) / a.iters * 1e3, waited[0] / a.iters * 1e3))
+        print(f"round {rnd} {'graph   ' if mode else 'ordinary'}: {res[mode][-1][0]:.3f} ms / iteration, host busy {res[mode][-1][1]:.3f} ms, "
+              f"host waiting {res[mode][-1][2]:.3f} ms", flush=True)
+for mode, v in res.items():
+    tr = trainers[mode]
+    tr.materialize()
+    last = tr.history[-1]
+    print(f"{'graph   ' if mode else 'ordinary'}: median {statistics.median(x[0] for x in v):.3f} ms / iteration ({a.batch * 1e3 / statistics.median(x[0] for x in v):.0f} images/s), "
+          f"host busy {statistics.median(x[1] for x in v):.3f} ms, waiting {statistics.median(x[2] for x in v):.3f} ms; "
+          f"last losses agent {last['agent_loss']:.5f} value {last['value_loss']:.5f} reward {last['reward']:.5f}; iterations {tr.iter}")
+if os.environ.get("TRAIN_GRAPH_AB_PROFILE") == "1":          # where the host's time inside a graph-mode step() goes
+    import cProfile
+    import pstats
+    tr = trainers[True]
+    pr = cProfile.Profile()
+    pr.enable()
+    for _ in range(a.iters):
+        tr.step()
+    pr.disable()
+    torch.cuda.synchronize()
+    st = pstats.Stats(pr)
+    st.sort_stats("cumulative").print_stats(45)
