@@ -251,7 +251,7 @@ def test_graph_trainer_runs_the_schedule_and_keeps_the_pool():
     graph per iteration and in the form data parallelism uses (graph="split": forward + backward | the collective, outside |
     clip + Adam). Against a trainer of the same seed in the ordinary loop the history agrees as far as two ordinary runs agree
     with each other: one fp32 ulp in a filter parameter flips bf16 roundings in the detector, and the per-image losses move in
-    the fourth digit (tools/round6/dbg_graph_hist.py: ordinary vs ordinary 1e-4 .. 3e-4 from the fourth iteration on, graph vs
+    the fourth digit (tools/train_graph_hist.py: ordinary vs ordinary 1e-4 .. 3e-4 from the fourth iteration on, graph vs
     ordinary the same); the tolerance is measured (tests/_margins.py). That a replay IS the ordinary iteration, bit for bit, is
     the test above."""
     from _margins import close_scaled

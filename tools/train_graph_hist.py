@@ -1,7 +1,13 @@
+#!/usr/bin/env python3
+"""How far do two trainers of one seed drift apart? Four runs of 12 iterations at the test size (ordinary, ordinary, graph, graph):
+the reward history of each and the differences ordinary vs ordinary, graph vs graph, ordinary vs graph. One fp32 ulp in a filter
+parameter flips bf16 roundings in the detector, so two ORDINARY runs differ by 1e-4 .. 3e-4 from the fourth iteration on; the
+graph runs differ from them by the same amount (what tests/test_gpu_train_graph.py's history tolerance rests on).
+usage (GPU box): python tools/train_graph_hist.py"""
 import os, random, sys
 import numpy as np, torch
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", "tests"))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import test_gpu_train_graph as T
 from adaptiveisp_amd.replay import DeviceReplayMemory, SyntheticSource
 from adaptiveisp_amd.train import Trainer
