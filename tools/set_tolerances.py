@@ -56,6 +56,10 @@ files = sys.argv[1:] or newest_round_files()
 # labels that keep their call-site cap: a comparison of two launch PLANS that happens to be bit-identical with the committed
 # tuning table (the Bottleneck kernel and the fused pair round h the same way) but need not be with another choice of kernels
 KEEP_CAP = {"yolo.engine_bneck_vs_default_plan", "yolo.engine_bneck_ws_vs_two_launch_plan", "yolo.bottleneck_ws_vs_two_layers"}
+# ... and families that compare two RUNS of the training loop (tests/test_gpu_train_graph.py): the runs agree bit for bit on most
+# boxes, but one fp32 ulp of run-to-run noise in a parameter flips bf16 roundings in the detector and moves a loss in the fourth
+# digit (tools/train_graph_hist.py) — a tolerance derived from runs that happened to agree would fail on the one that does not
+KEEP_CAP_PREFIX = ("train.graph.",)
 
 
 def up(v, digits=2):
@@ -80,7 +84,7 @@ except (OSError, ValueError):
     previous = {}
 table, nondet = {}, []
 for label, rs in sorted(runs.items()):
-    if label in KEEP_CAP:
+    if label in KEEP_CAP or label.startswith(KEEP_CAP_PREFIX):
         continue
     rs = rs[-WINDOW:]                       # the runs of the current tree
     cap_r, cap_a = max(r["cap_r"] for r in rs), max(r["cap_a"] for r in rs)
@@ -93,7 +97,7 @@ for label, rs in sorted(runs.items()):
         rtol = min(cap_r, up(max(max(r["r4"] for r in rs), 2.4e-7))) if cap_r > 0 else 0.0
         atol = min(cap_a, up(max(4.0 * max(r["need"] for r in rs), 1e-9))) if cap_a > 0 else 0.0
     table[label] = {"rtol": rtol, "atol": atol}
-kept = sorted(k for k in previous if k not in table and k not in KEEP_CAP)
+kept = sorted(k for k in previous if k not in table and k not in KEEP_CAP and not k.startswith(KEEP_CAP_PREFIX))
 for k in kept:
     table[k] = previous[k]
 json.dump(table, open(table_path, "w"), indent=0, sort_keys=True)
