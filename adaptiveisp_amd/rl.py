@@ -164,6 +164,14 @@ def train_iteration(cfg, agent, value, detector, loss_fn, imgs, z, states, label
         else:
             with torch.no_grad():
                 packed, packed_pair = assign_labels_packed(loss_fn, detector.head_shapes(), labels, imgs.device, pair=True)
+        if imgs.is_cuda and getattr(detector, "begin_input_half", None) is not None:
+            # the detector's shallow layers on the INPUT batch need nothing the agent computes: beside the agent's forward
+            # (yolo.YoloTrainPairEngine.begin_input_half), on the stream the critic uses later
+            cur0, side0 = torch.cuda.current_stream(), _side_stream(imgs.device)
+            side0.wait_stream(cur0)
+            with torch.cuda.stream(side0):
+                detector.begin_input_half(imgs)
+            imgs.record_stream(side0)
         (retouch, new_states, surrogate, penalty), _, _ = agent((imgs, z, states), progress)
         stats = retouch_stats(retouch)
         if on_retouch is not None:

@@ -601,6 +601,7 @@ class YoloTrainPairEngine:
     tuning table holds for the 2B shapes, i.e. bf16 rounding of the forward."""
 
     def __init__(self, model, batch, height, width, device="cuda:0"):
+        import os
         self.B = int(batch)
         self.full = YoloTrainEngine(model, 2 * self.B, height, width, device, capture=("fwd",))
         self.half = YoloTrainEngine(model, self.B, height, width, device, share_with=self.full, first_image=self.B,
@@ -610,10 +611,66 @@ class YoloTrainPairEngine:
         self.half._loss_ws = dict(tobj=[t[B:] for t in ws["tobj"]], cnt=[t[B:] for t in ws["cnt"]],
                                   part=[t[B:] for t in ws["part"]], ticket=ws["ticket"][B:])
         self.dev, self.H, self.W = self.full.dev, self.full.H, self.full.W
+        # The SHALLOW layers per half (see begin_input_half): an engine over images [0, B) of the 2B engine's buffers for the
+        # input batch; `half` (images [B, 2B)) runs the retouched batch's. ADAYOLO_TRAIN_EARLY = the number of stride-2 convs
+        # inside the shallow part (default 2: everything in front of 128 -> 256 s2 — measured best of 0..4, tools/train_graph_ab.py --early), 0 = one 2B-image forward as before.
+        self.early_cut = int(os.environ.get("ADAYOLO_TRAIN_EARLY", "2"))
+        self.first = None
+        if self.early_cut > 0:
+            self.first = YoloTrainEngine(model, self.B, height, width, device, share_with=self.full, first_image=0, capture=())
+        self._early, self._split = None, None
 
     def autotune(self, cache=None, write=True, **kw):
         self.full.autotune(cache=cache, write=write, **kw)
+        if self.first is not None:
+            self.first.autotune(cache=cache, write=write, **kw)
+        self._split = None
         return self.half.autotune(cache=cache, write=write, **kw)
+
+    # ---- the input batch's shallow layers beside the agent ------------------------------------------------------------
+    # One 2B-image forward is cheaper than two B-image ones because the DEEP layers (32 x 32 and 16 x 16 maps at 512 x 512) cannot
+    # fill 256 CUs with B images. The shallow layers can (8 x 256 x 256 ... 8 x 64 x 64 pixels), and the input batch's need
+    # nothing the agent computes: they run on a second stream beside the agent's forward — a latency chain of small launches
+    # that leaves the chip idle for ~0.9 ms — so that after the filters only the RETOUCHED half's shallow layers (B images)
+    # and the deep layers (2B images) are left on the critical path: at 8 x 512 x 512 the 3.04 ms of the 16-image forward become
+    # 0.83 (hidden) + 0.83 + 1.61 (tools/train_det_breakdown.py, PLAN_ORDER=1). Same kernels per image; the B-image shapes
+    # take their own rows of the tuning table (bf16 rounding of a layer may differ from the 2B-image kernel's, as between
+    # any two tuned shapes).
+    @staticmethod
+    def _cut_index(eng, ndown):
+        """Index into eng._forward_plan() of the launch that runs the (ndown + 1)-th stride-2 conv."""
+        plan, seen = eng._forward_plan(), 0
+        for j, (kind, _, a) in enumerate(plan):
+            if kind in ("conv", "convkeep"):
+                stride = a[14] if kind == "conv" else a[16]
+                if stride == 2:
+                    if seen == ndown:
+                        return j
+                    seen += 1
+        raise _lib.AdayoloError(f"YoloTrainPairEngine: the detector has fewer than {ndown + 1} stride-2 convs")
+
+    def _plans_split(self):
+        sig = tuple(id(e._forward_plan()) for e in (self.first, self.half, self.full))      # (a re-tuned engine rebuilds its plan)
+        if self._split is None or self._split[0] != sig:
+            cut = {id(e): self._cut_index(e, self.early_cut) for e in (self.first, self.half, self.full)}
+            self._split = (sig, self.first._forward_plan()[:cut[id(self.first)]], self.half._forward_plan()[:cut[id(self.half)]],
+                           self.full._forward_plan()[cut[id(self.full)]:])
+        return self._split[1:]
+
+    def begin_input_half(self, imgs):
+        """Enqueue the shallow layers of the INPUT batch on the current stream (the caller's side stream) and record the event
+        the deep layers wait for. Optional: per_sample_loss_pair runs them itself when this was not called for `imgs`."""
+        if self.first is None:
+            return
+        if imgs.shape != (self.B, 3, self.H, self.W) or imgs.dtype != torch.float32 or imgs.device != self.dev:
+            raise ValueError(f"expected fp32 {(self.B, 3, self.H, self.W)} on {self.dev}")
+        imgs = imgs.detach().contiguous()
+        pre = self._plans_split()[0]
+        with torch.cuda.device(self.dev):
+            self.first._run(pre, img=imgs)
+            ev = torch.cuda.Event()
+            ev.record()
+        self._early = (imgs.data_ptr(), imgs._version, ev, imgs)
 
     def head_shapes(self):
         return self.half.head_shapes()
@@ -634,7 +691,24 @@ class YoloTrainPairEngine:
         if loss_fn.nc + 5 != full.no or len(packed_pair) != len(full.raw) or loss_fn.hyp.get("fl_gamma", 0.0) != 0.0:
             raise ValueError("loss / detector mismatch (classes, layers) or focal loss requested: use the PyTorch loss")
         loss = torch.empty((2 * self.B,), dtype=torch.float32, device=self.dev)
-        full._forward_raw_halves(imgs.detach().contiguous(), retouch.detach().contiguous())
+        if self.first is None:
+            full._forward_raw_halves(imgs.detach().contiguous(), retouch.detach().contiguous())
+        else:
+            imgs_c, ret_c = imgs.detach().contiguous(), retouch.detach().contiguous()
+            pre_first, pre_half, deep = self._plans_split()
+            early, self._early = self._early, None
+            with torch.cuda.device(self.dev):
+                full._pass_begin()
+                try:
+                    if early is not None and early[0] == imgs_c.data_ptr() and early[1] == imgs_c._version:
+                        torch.cuda.current_stream().wait_event(early[2])     # the input half's shallow layers, enqueued earlier
+                    else:
+                        self.first._run(pre_first, img=imgs_c)
+                    self.half._run(pre_half, img=ret_c)
+                    full._run(deep)
+                finally:
+                    full._pass_end()
+            full._gen += 1
         self.half._gen += 1
         with torch.cuda.device(self.dev):
             a, keep = full._loss_args(loss_fn, packed_pair)

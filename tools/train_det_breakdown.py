@@ -105,6 +105,12 @@ for name, plan, kw in (("training forward", tr._forward_plan(), dict(img=x)),
         kinds[e[0]][1] += t
     print("   by kind: " + ", ".join(f"{k} {n} x = {t:.3f} ms" for k, (n, t) in sorted(kinds.items(), key=lambda kv: -kv[1][1])))
     order = sorted(range(len(plan)), key=lambda i: -ms[i])[:TOP]
+    if os.environ.get("PLAN_ORDER") == "1":                # every launch in plan order with the running sum
+        order, run = range(len(plan)), 0.0
     for i in order:
         d, fl, by = describe(plan[i])
-        print(f"   #{i:3d} {ms[i] * 1e3:8.1f} us  {d:48s} {fl / ms[i] / 1e9 if fl else 0:7.1f} TFLOP/s {by / ms[i] / 1e6 if by else 0:7.0f} GB/s")
+        tail = ""
+        if os.environ.get("PLAN_ORDER") == "1":
+            run += ms[i]
+            tail = f"   sum {run:.3f} ms"
+        print(f"   #{i:3d} {ms[i] * 1e3:8.1f} us  {d:48s} {fl / ms[i] / 1e9 if fl else 0:7.1f} TFLOP/s {by / ms[i] / 1e6 if by else 0:7.0f} GB/s{tail}")

@@ -19,6 +19,8 @@ ap.add_argument("--iters", type=int, default=40)
 ap.add_argument("--rounds", type=int, default=3)
 ap.add_argument("--batch", type=int, default=8)
 ap.add_argument("--size", type=int, default=512)
+ap.add_argument("--early", default="", help="comma list of ADAYOLO_TRAIN_EARLY values: graph-mode trainers only, one per value")
+ap.add_argument("--ordinary", action="store_true", help="with --early: the ordinary loop instead of graph mode")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 cache = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "adaptiveisp_amd", "yolo", "tuning", "mi355x.json")
@@ -37,10 +39,14 @@ def timed(fn):
 torch.cuda.Event.synchronize = timed(torch.cuda.Event.synchronize)
 atrain._GraphIteration.wait_guard = timed(atrain._GraphIteration.wait_guard)
 trainers = {}
-for mode in (False, True):
-    os.environ["ADAISP_TRAIN_GRAPH"] = "1" if mode else "0"
+modes = [("early=" + v) for v in a.early.split(",")] if a.early else [False, True]
+for mode in modes:
+    if isinstance(mode, str):
+        os.environ["ADAISP_TRAIN_GRAPH"], os.environ["ADAYOLO_TRAIN_EARLY"] = "0" if a.ordinary else "1", mode.split("=")[1]
+    else:
+        os.environ["ADAISP_TRAIN_GRAPH"] = "1" if mode else "0"
     trainers[mode] = atrain.build_trainer(cfg, 0, 1, dev, a.batch, a.size, tune_cache=cache, seed=0)
-    assert trainers[mode].graph_mode is mode
+    assert trainers[mode].graph_mode is (bool(mode) and not a.ordinary)
     trainers[mode].train(6)
     torch.cuda.synchronize()
 res = {m: [] for m in trainers}
@@ -55,19 +61,19 @@ for rnd in range(a.rounds):
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         res[mode].append((dt / a.iters * 1e3, (t_host - waited[0]) / a.iters * 1e3, waited[0] / a.iters * 1e3))
-        print(f"round {rnd} {'graph   ' if mode else 'ordinary'}: {res[mode][-1][0]:.3f} ms / iteration, host busy {res[mode][-1][1]:.3f} ms, "
+        print(f"round {rnd} {mode if isinstance(mode, str) else ('graph   ' if mode else 'ordinary')}: {res[mode][-1][0]:.3f} ms / iteration, host busy {res[mode][-1][1]:.3f} ms, "
               f"host waiting {res[mode][-1][2]:.3f} ms", flush=True)
 for mode, v in res.items():
     tr = trainers[mode]
     tr.materialize()
     last = tr.history[-1]
-    print(f"{'graph   ' if mode else 'ordinary'}: median {statistics.median(x[0] for x in v):.3f} ms / iteration ({a.batch * 1e3 / statistics.median(x[0] for x in v):.0f} images/s), "
+    print(f"{mode if isinstance(mode, str) else ('graph   ' if mode else 'ordinary')}: median {statistics.median(x[0] for x in v):.3f} ms / iteration ({a.batch * 1e3 / statistics.median(x[0] for x in v):.0f} images/s), "
           f"host busy {statistics.median(x[1] for x in v):.3f} ms, waiting {statistics.median(x[2] for x in v):.3f} ms; "
           f"last losses agent {last['agent_loss']:.5f} value {last['value_loss']:.5f} reward {last['reward']:.5f}; iterations {tr.iter}")
 if os.environ.get("TRAIN_GRAPH_AB_PROFILE") == "1":          # where the host's time inside a graph-mode step() goes
     import cProfile
     import pstats
-    tr = trainers[True]
+    tr = trainers[True] if True in trainers else list(trainers.values())[-1]
     pr = cProfile.Profile()
     pr.enable()
     for _ in range(a.iters):
