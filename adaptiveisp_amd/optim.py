@@ -33,6 +33,13 @@ def _served(opt):
             and not isinstance(g["betas"][0], torch.Tensor))
 
 
+def reserve_capture_table(opt):
+    """One pinned block for the pointer table of a clip_adam_step that is about to be CAPTURED into a hipGraph (each capture
+    keeps its own: the graph's copy node reads it at every replay)."""
+    n = sum(1 for p in opt.param_groups[0]["params"] if p in opt.state and "exp_avg" in opt.state[p])
+    opt.__dict__.setdefault("_adaisp_capture_blocks", []).append([torch.empty((n, 7), dtype=torch.int64, pin_memory=True), False])
+
+
 def clip_adam_step(opt, max_norm, lr_dev=None):
     """clip_grad_norm_(the optimizer's parameters, max_norm) + opt.step() on the kernels. Returns False — nothing done — when
     the kernels do not serve this optimizer in this state (the caller then runs torch's clip and step). `lr_dev`: a 1-element
@@ -64,10 +71,7 @@ def clip_adam_step(opt, max_norm, lr_dev=None):
             steps.append(st["step"])
             chunk0 += (n + CHUNK - 1) // CHUNK
         cache = opt.__dict__["_adaisp_table"] = dict(sig=sig, rows=np.array(rows, dtype=np.int64), steps=steps, nchunks=chunk0,
-                                                     ws=torch.empty((chunk0 + 2,), dtype=torch.float32, device=dev),
-                                                     # the table's staging block for a CAPTURED step (a pinned allocation
-                                                     # inside a stream capture invalidates it)
-                                                     pinned=torch.empty((len(rows), 7), dtype=torch.int64, pin_memory=True))
+                                                     ws=torch.empty((chunk0 + 2,), dtype=torch.float32, device=dev))
     table = cache["rows"].copy()
     for i, p in enumerate(params):
         g, st = p.grad, opt.state[p]
@@ -82,9 +86,15 @@ def clip_adam_step(opt, max_norm, lr_dev=None):
     torch._foreach_add_(cache["steps"], 1)
     if torch.cuda.is_current_stream_capturing():
         # the copy becomes a node of the graph that reads this block at every replay: it stays as it is (the gradients of a
-        # replay live where the capture's did) and alive with the optimizer
-        cache["pinned"].copy_(torch.from_numpy(table))
-        dtable = cache["pinned"].to(dev, non_blocking=True)
+        # replay live where the capture's did), belongs to THIS capture and lives as long as the optimizer. A pinned allocation
+        # inside a capture invalidates it: the caller reserved the block beforehand (reserve_capture_table)
+        blocks = opt.__dict__.get("_adaisp_capture_blocks") or []
+        free = [b for b in blocks if not b[1] and tuple(b[0].shape) == table.shape]
+        if not free:
+            raise RuntimeError("optim.clip_adam_step inside a stream capture: call optim.reserve_capture_table(opt) before the capture")
+        free[0][1] = True
+        free[0][0].copy_(torch.from_numpy(table))
+        dtable = free[0][0].to(dev, non_blocking=True)
     else:
         dtable = to_device_async(table, dev)
     b1, b2 = group["betas"]

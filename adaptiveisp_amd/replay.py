@@ -85,10 +85,15 @@ class DeviceReplayMemory:
                 self._release(record)                      # finished images leave the pool here
         return batch
 
-    def get_feed_dict_and_states(self, batch_size):
+    def get_feed_dict_and_states(self, batch_size, host_only=False):
         """-> dict(im [B,3,H,W] device tensor (a gather, no host copy), label, path, shape, state [B,S] device,
-        z [B,z_dim] device, records)."""
+        z [B,z_dim] device, records). `host_only`: no device work — `slots` a list, `state` / `z` numpy arrays, no `im` (a
+        caller that stages the batch itself: train.Trainer's graph mode gathers `images[slots]` inside its hipGraph)."""
         batch = self.get_next_fake_batch(batch_size)
+        if host_only:
+            return dict(label=[r.label for r in batch], path=[r.path for r in batch], shape=[r.shape for r in batch],
+                        state=np.stack([r.state for r in batch], 0), z=self.get_noise(batch_size), records=batch,
+                        slots=[r.slot for r in batch])
         # pinned staging + asynchronous copies: a pageable source would make each of these wait for the whole stream
         idx = to_device_async([r.slot for r in batch], self.device, dtype=torch.long)
         states = to_device_async(np.stack([r.state for r in batch], 0), self.device)
@@ -96,15 +101,17 @@ class DeviceReplayMemory:
         return dict(im=self.images.index_select(0, idx), label=[r.label for r in batch], path=[r.path for r in batch],
                     shape=[r.shape for r in batch], state=states, z=z, records=batch, slots=idx)
 
-    def replace_memory(self, batch, retouch, new_states, slots=None):
+    def replace_memory(self, batch, retouch, new_states, slots=None, device_copy=True):
         """Re-insert the retouched batch: `retouch` [B,3,H,W] device tensor is scattered into the records' own slots,
         `new_states` [B,S] becomes their state — pass it as a HOST array where the loop must not stall (a device tensor is
         read back with a blocking copy, i.e. after everything enqueued so far). `slots`: the records' slot indices on the
         device if the caller still has them (get_feed_dict_and_states()["slots"]). Over-long trajectories are kept with
-        probability cfg.over_length_keep_prob; then the pool is topped up with fresh records."""
+        probability cfg.over_length_keep_prob; then the pool is topped up with fresh records. `device_copy=False`: the caller
+        has written (or will write, before anything reads the pool) the retouched images into the records' slots itself."""
         states = new_states.detach().cpu().numpy() if isinstance(new_states, torch.Tensor) else np.asarray(new_states)
-        idx = slots if slots is not None else to_device_async([r.slot for r in batch], self.device, dtype=torch.long)
-        self.images.index_copy_(0, idx, retouch.detach().to(self.images.dtype))
+        if device_copy:
+            idx = slots if slots is not None else to_device_async([r.slot for r in batch], self.device, dtype=torch.long)
+            self.images.index_copy_(0, idx, retouch.detach().to(self.images.dtype))
         self.rng.shuffle(self.image_pool)
         for i, r in enumerate(batch):
             r = Dict(slot=r.slot, label=r.label, path=r.path, shape=r.shape, state=states[i].copy())

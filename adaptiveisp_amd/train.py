@@ -64,10 +64,9 @@ class Trainer:
         self.history = []
 
     def step(self):
-        feed = self.replay.get_feed_dict_and_states(self.batch_size)
         if self.graph_mode and self.iter >= self.graph_warmup:
-            return self._step_graph(feed)
-        return self._step_ordinary(feed)
+            return self._step_graph()
+        return self._step_ordinary(self.replay.get_feed_dict_and_states(self.batch_size))
 
     def _step_ordinary(self, feed):
         it = self.iter
@@ -138,27 +137,33 @@ class Trainer:
         return rec
 
     # ---- the iteration as ONE hipGraph ----------------------------------------------------------------------------------
-    def _step_graph(self, feed):
+    def _device_feed(self, hf):
+        """A host-only draw (replay.get_feed_dict_and_states(host_only=True)) as the ordinary loop's feed."""
+        from .util import to_device_async
+        dev = self.replay.device
+        idx = to_device_async(hf["slots"], dev, dtype=torch.long)
+        return dict(hf, im=self.replay.images.index_select(0, idx), state=to_device_async(hf["state"], dev),
+                    z=to_device_async(hf["z"], dev), slots=idx)
+
+    def _step_graph(self):
         """step() with the device side of the iteration replayed from a hipGraph (_GraphIteration). What stays on the host:
-        drawing the batch (replay.py), the labels' target assignment (yolo.loss.assign_labels_host), ONE upload of the tables
-        and the iteration's three scalars, the replay, the guard's verdict and the pool update. Same arithmetic, same order of
-        launches as the ordinary step."""
+        drawing the batch (replay.py), the labels' target assignment (yolo.loss.assign_labels_host), filling ONE pinned block
+        (tables, pool rows, states, noise, the iteration's three scalars), the replay, the guard's verdict and the pool's
+        bookkeeping. Same arithmetic, same order of launches as the ordinary step."""
         it = self.iter
         progress = float(it) / self.max_iter_step
+        feed = self.replay.get_feed_dict_and_states(self.batch_size, host_only=True)
         G = self._git
         if G is None:
-            G = self._git = _GraphIteration(self, feed, split=self.graph_split)
-        while not G.tables.fill(feed["label"]):              # more matches than the tables hold: larger tables, new capture
-            G = self._git = _GraphIteration(self, feed, cap=2 * G.tables.cap, split=self.graph_split)
-        G.set_scalars((1.0 - progress) * self.cfg.exploration_penalty, self.agent_optimizer.param_groups[0]["lr"],
-                      self.value_optimizer.param_groups[0]["lr"])
-        G.im.copy_(feed["im"])
-        G.z.copy_(feed["z"])
-        G.state.copy_(feed["state"])
-        G.tables.upload()
+            G = self._git = _GraphIteration(self, self.replay.images, split=self.graph_split)
+        coef = (1.0 - progress) * self.cfg.exploration_penalty
+        lrs = (self.agent_optimizer.param_groups[0]["lr"], self.value_optimizer.param_groups[0]["lr"])
+        while not G.stage(feed["label"], feed["slots"], feed["state"], feed["z"], coef, *lrs):
+            # more matches than the tables hold: larger tables, new capture
+            G = self._git = _GraphIteration(self, self.replay.images, cap=2 * G.tables.cap, split=self.graph_split)
         if G.graph is None:
             try:
-                G.capture()
+                G.capture()                                  # (drains the device first: whatever ran before is complete)
             except Exception as e:                           # noqa: BLE001 — nothing has run yet: this iteration and the rest take the ordinary loop
                 import warnings
                 warnings.warn(f"adaptiveisp_amd.train: the iteration could not be captured as a hipGraph ({type(e).__name__}: "
@@ -167,7 +172,7 @@ class Trainer:
                 for opt in (self.agent_optimizer, self.value_optimizer):
                     opt.zero_grad(set_to_none=True)
                 torch.cuda.synchronize(G.dev)
-                return self._step_ordinary(feed)
+                return self._step_ordinary(self._device_feed(feed))
         G.replay()
         for opt in (self.agent_optimizer, self.value_optimizer):     # what Optimizer.step's wrapper records (LambdaLR looks at it)
             opt._opt_called = True
@@ -179,13 +184,13 @@ class Trainer:
         if bad:
             self.replay.drop_batch(feed["records"])
         else:
-            self.replay.replace_memory(feed["records"], G.out["retouch"], states_host, slots=feed.get("slots"))
-        slot = G.keep_scalars(it)
+            self.replay.replace_memory(feed["records"], None, states_host, device_copy=False)    # (the graph scattered the images)
+        slot = G.kept_scalars()
         rec = dict(iter=it, agent_loss=slot[0], value_loss=slot[1], reward=slot[2], dropped=bad)
         self.history.append(rec)
         self.iter += 1
         if it % 256 == 255:
-            self.materialize()                               # (and frees the 256 slots of G.keep_scalars)
+            self.materialize()                               # (before the ring of G.scalars comes round)
         if self.save_dir and self.rank == 0 and it % self.cfg.save_model_freq == 0 and it > 0:
             self.save(it)
         return rec
@@ -213,45 +218,68 @@ class Trainer:
 
 class _GraphIteration:
     """One RL iteration (rl.train_iteration over the pair engine) captured as a hipGraph. Everything that changes between
-    iterations enters through memory of fixed address:
-      im / z / state                 the batch the replay pool drew (copied in before the replay)
+    iterations enters through ONE pinned host block, copied by the graph's first node into the buffers its kernels read:
       tables                         the labels' target assignment, fixed row count, padded with rows of no image
-                                     (yolo.loss.StaticLabelTables), and behind it in the SAME upload the iteration's scalars:
+                                     (yolo.loss.StaticLabelTables)
       coef (fp32)                    (1 - progress) * exploration_penalty   -> adaisp_policy_tail_args.entropy_coef_dev
       lr[0], lr[1] (fp64)            the two optimizers' learning rates      -> adaisp_clip_adam_step_dev
+      slots (int64 [B])              the batch's rows of the replay pool: the graph's second node gathers pool[slots] -> im
+      state [B,S], z [B,Z]           the records' state vectors, the noise
     and leaves through pinned host memory the device writes ~1 ms into the iteration, on the side stream, in this order: the
     guard's flag (train.py:374-381), the new state vectors, a sequence number. The host polls the sequence number
     (wait_guard) — an event recorded inside a capture cannot be waited on from the host — reads flag and states, and does the
-    pool's bookkeeping and the next batch's label assignment while the iteration's backward runs. The detector engines launch
-    their kernels one by one inside the capture (train_engine._graph: no nested graph replay); the critic's two calls and the
-    guard fork onto the side stream inside the capture and join before its end.
+    pool's bookkeeping and the next batch's label assignment while the iteration's backward runs. The retouched batch re-enters
+    the pool INSIDE the graph, behind the guard on the side stream (pool[slots] = flag ? pool[slots] : retouch — replace_memory's
+    scatter, train.py:380), and the iteration's three scalars go into a ring indexed by the sequence number: between two replays
+    the stream holds nothing but the pool's refills — the gather, the three input copies, the uploads and the scatter of the
+    first version sat there with 30-250 us of engine hand-over each, 0.6 ms per iteration in which no kernel ran
+    (tools/train_timeline.sh). The detector engines launch their kernels one by one inside the capture (train_engine._graph: no
+    nested graph replay); the critic's two calls and the guard fork onto the side stream inside the capture and join before its end.
     Nothing is executed at capture time: the captured iteration runs for the first time at its first replay, so a trainer
     in graph mode makes the same sequence of updates as one in the ordinary loop (tests/test_gpu_train_graph.py)."""
 
-    def __init__(self, tr, feed, cap=512, split=False):
+    def __init__(self, tr, pool, cap=512, split=False):
+        import numpy as np
+
         from .yolo.loss import StaticLabelTables
-        self.tr, self.split = tr, bool(split)
-        dev = feed["im"].device
+        self.tr, self.split, self.pool = tr, bool(split), pool
+        dev = pool.device
         self.dev = dev
-        B = tr.batch_size
-        self.tables = StaticLabelTables(tr.loss_fn, tr.detector.head_shapes(), B, dev, cap=cap, extra_words=6)
+        B, S, Z = tr.batch_size, int(tr.cfg.num_state_dim), int(tr.cfg.z_dim)
+        extra = 6 + 2 * B + B * S + B * Z
+        self.tables = StaticLabelTables(tr.loss_fn, tr.detector.head_shapes(), B, dev, cap=cap, extra_words=extra + (extra & 1))
         ed, eh = self.tables.extra_dev, self.tables.extra_host.numpy()
+        o_sl, o_st, o_z = 6, 6 + 2 * B, 6 + 2 * B + B * S
         self.coef = ed[0:1].view(torch.float32)
         self.lr = [ed[2:4].view(torch.float64), ed[4:6].view(torch.float64)]
-        import numpy as np
+        self.slots = ed[o_sl:o_st].view(torch.int64)
+        self.state = ed[o_st:o_z].view(torch.float32).view(B, S)
+        self.z = ed[o_z:o_z + B * Z].view(torch.float32).view(B, Z)
         self._coef_h, self._lr_h = eh[0:1].view(np.float32), [eh[2:4].view(np.float64), eh[4:6].view(np.float64)]
-        self.im, self.z, self.state = (torch.empty_like(feed[k]) for k in ("im", "z", "state"))
+        self._slots_h = eh[o_sl:o_st].view(np.int64)
+        self._state_h = eh[o_st:o_z].view(np.float32).reshape(B, S)
+        self._z_h = eh[o_z:o_z + B * Z].view(np.float32).reshape(B, Z)
+        self.im = torch.empty((B,) + tuple(pool.shape[1:]), dtype=pool.dtype, device=dev)
         self.flag_host = torch.zeros((1,), dtype=torch.bool, pin_memory=True)
-        self.states_host = torch.zeros(tuple(feed["state"].shape), dtype=feed["state"].dtype, pin_memory=True)
+        self.states_host = torch.zeros((B, S), dtype=torch.float32, pin_memory=True)
         self.seq_host = torch.zeros((1,), dtype=torch.int32, pin_memory=True)
         self.seq_dev = torch.zeros((1,), dtype=torch.int32, device=dev)
         self._seq_np, self._replays = self.seq_host.numpy(), 0
         self.scalars = torch.zeros((256, 3), dtype=torch.float32, device=dev)
-        self.graph = self.graph_step = self.out = self.vec3 = None
+        self.graph = self.graph_step = self.out = None
 
-    def set_scalars(self, coef, lr_agent, lr_value):
+    def stage(self, labels, slots, states, z, coef, lr_agent, lr_value):
+        """The next iteration's inputs into the pinned block (the graph's first copy node reads it). False — nothing usable
+        written — when the labels need more rows than the tables hold. Call only after wait_guard() of this graph's previous
+        replay (that copy has then long run)."""
+        if not self.tables.fill(labels):
+            return False
         self._coef_h[0] = coef                               # (rounded to fp32 as the by-value kernel argument is)
         self._lr_h[0][0], self._lr_h[1][0] = lr_agent, lr_value
+        self._slots_h[:] = slots
+        self._state_h[:] = states
+        self._z_h[:] = z
+        return True
 
     def _guard(self, retouch, stats, new_states):
         from .rl import _side_stream
@@ -261,14 +289,20 @@ class _GraphIteration:
         with torch.cuda.stream(side):
             mean = stats[:, 0].mean()
             flag = ((stats[:, 1].sum() > 0) | ~torch.isfinite(mean) | (mean < 0.01) | (mean > tr.max_bri)).reshape(1)
+            # replace_memory's scatter (a dropped batch leaves the pool as it is) — BEFORE the host is told: once it has read the
+            # sequence number it refills released rows of the pool, and nothing of this iteration may touch the pool after that
+            keep = self.pool.index_select(0, self.slots)
+            self.pool.index_copy_(0, self.slots, torch.where(flag.view(1, 1, 1, 1), keep, retouch.to(self.pool.dtype)))
             self.flag_host.copy_(flag, non_blocking=True)
             self.states_host.copy_(new_states, non_blocking=True)
             self.seq_dev.add_(1)
             self.seq_host.copy_(self.seq_dev, non_blocking=True)
         stats.record_stream(side)
         new_states.record_stream(side)
+        retouch.record_stream(side)
 
     def capture(self):
+        from . import dist as adist
         from .rl import _side_stream
         tr = self.tr
         for m in (tr.agent, tr.value):
@@ -276,18 +310,23 @@ class _GraphIteration:
                 m.train()
         tr.agent.entropy_coef_dev = self.coef
         torch.cuda.synchronize(self.dev)
-        from . import dist as adist
+        from . import optim as aoptim
         g, g2 = torch.cuda.CUDAGraph(), None
         opts = [tr.agent_optimizer, tr.value_optimizer]
+        for o in opts:
+            aoptim.reserve_capture_table(o)                                          # (pinned: not inside the capture)
         try:
             with torch.cuda.graph(g):
+                self.tables.upload()                                                 # the pinned block -> what the kernels read
+                torch.index_select(self.pool, 0, self.slots, out=self.im)            # the batch: a gather from the pool
                 out = train_iteration(tr.cfg, tr.agent, tr.value, tr.detector, tr.loss_fn, self.im, self.z, self.state, None, 0.0,
                                       opts, buckets=tr.buckets, use_truncated=tr.use_truncated, max_bri=tr.max_bri,
                                       on_retouch=self._guard, assigned=(self.tables.packed, self.tables.packed_pair),
                                       lr_dev=self.lr, step=not self.split)
-                self.vec3 = torch.stack([out["agent_loss"].detach().reshape(()), out["value_loss"].detach().reshape(()),
-                                         out["reward"].detach().mean()])
+                vec3 = torch.stack([out["agent_loss"].detach().reshape(()), out["value_loss"].detach().reshape(()),
+                                    out["reward"].detach().mean()])
                 torch.cuda.current_stream().wait_stream(_side_stream(self.dev))      # (joined whatever the stream switches say)
+                self.scalars.index_copy_(0, ((self.seq_dev - 1) % 256).to(torch.int64), vec3.view(1, 3))
             if self.split:
                 # the gradients now sit at fixed addresses (every replay of the first graph writes them there); the collective
                 # runs on them between the two replays; the second graph clips and steps from the same addresses
@@ -318,10 +357,9 @@ class _GraphIteration:
                                    f"(it reads {int(self._seq_np[0])})")
         return bool(self.flag_host[0]), self.states_host.numpy().copy()
 
-    def keep_scalars(self, it):
-        slot = self.scalars[it % 256]
-        slot.copy_(self.vec3)
-        return slot
+    def kept_scalars(self):
+        """(agent loss, value loss, mean reward) of the replay launched last: a row of the device-side ring."""
+        return self.scalars[(self._replays - 1) % 256]
 
 
 # ---------------------------------------------------------------------------------------------------------------

@@ -274,7 +274,8 @@ class StaticLabelTables:
         return True
 
     def upload(self):
-        """One copy of the staging block (tables + extra words) to the device, on the current stream."""
+        """One copy of the host block (tables + extra words) to the device, on the current stream (capturable: the copy node of
+        a graph reads the pinned block at every replay)."""
         self.dev.copy_(self.host, non_blocking=True)
 
 

@@ -212,24 +212,27 @@ def test_a_replayed_iteration_is_the_ordinary_iteration():
     restore()
     tr = types.SimpleNamespace(cfg=cfg, agent=agent, value=value, detector=eng, loss_fn=loss_fn, batch_size=B, max_bri=0.9,
                                use_truncated=True, agent_optimizer=opts[0], value_optimizer=opts[1], buckets=None)
-    G = _GraphIteration(tr, feed(2), cap=256)
+    pool = torch.cat([feed(2)["im"], feed(3)["im"]], 0)          # the "replay pool": the graph gathers its batch from it by row
+    pool0 = pool.clone()
+    G = _GraphIteration(tr, pool, cap=256)
     got = []
     for i, (prog, lra, lrv) in enumerate(sched):
         f = feed(2 + i)
-        assert G.tables.fill(f["label"])
-        G.set_scalars((1.0 - prog) * cfg.exploration_penalty, lra, lrv)
-        G.im.copy_(f["im"])
-        G.z.copy_(f["z"])
-        G.state.copy_(f["state"])
-        G.tables.upload()
+        rows = list(range(i * B, (i + 1) * B))
+        assert G.stage(f["label"], rows, f["state"].cpu().numpy(), f["z"].cpu().numpy(), (1.0 - prog) * cfg.exploration_penalty, lra, lrv)
         if G.graph is None:
             G.capture()
-        G.graph.replay()
+        G.replay()
         bad, states_host = G.wait_guard(timeout=30.0)
         torch.cuda.synchronize()
         got.append({k: G.out[k].detach().clone() for k in KEYS})
         assert not bad
         assert np.array_equal(states_host, got[-1]["new_states"].cpu().numpy())          # what the host read mid-iteration
+        assert torch.equal(pool[rows], got[-1]["retouch"])                               # replace_memory's scatter, inside the graph
+        kept = G.kept_scalars()
+        assert float(kept[0]) == float(got[-1]["agent_loss"]) and float(kept[1]) == float(got[-1]["value_loss"])
+        assert float(kept[2]) == float(got[-1]["reward"].mean())
+    assert torch.equal(pool[B:], got[1]["retouch"]) and not torch.equal(pool[:B], pool0[:B])
     params = [p.detach().clone() for p in list(agent.parameters()) + list(value.parameters())]
     for k in KEYS:
         assert torch.equal(got[0][k], ref[0][k]), k
@@ -243,6 +246,36 @@ def test_a_replayed_iteration_is_the_ordinary_iteration():
     gap_stale = abs(float(stale[1]["agent_loss"]) - float(ref[1]["agent_loss"]))
     gap_graph = abs(float(got[1]["agent_loss"]) - float(ref[1]["agent_loss"]))
     assert gap_stale > 100 * max(gap_graph, 1e-7), (gap_stale, gap_graph)
+
+
+def test_a_dropped_batch_leaves_the_pool_as_it_is():
+    """The guard of train.py:374-381 inside the captured iteration: with a brightness bound every retouched batch violates, the
+    host reads `bad`, and the scatter behind the guard keeps the pool's rows (pool[slots] = flag ? pool[slots] : retouch)."""
+    import types
+
+    from _synth import test_image
+    from adaptiveisp_amd.rl import train_iteration
+    from adaptiveisp_amd.train import _GraphIteration
+    B, H, W = 4, 64, 96
+    eng, loss_fn = _detector(B, H, W)
+    cfg, agent, value = _fresh(B)
+    opts = [torch.optim.Adam(agent.parameters(), lr=3e-5, fused=True), torch.optim.Adam(value.parameters(), lr=3e-5, fused=True)]
+    im = torch.from_numpy(test_image(B, H, W, seed=31, special=False)).to(DEV)
+    z, st = torch.full((B, cfg.z_dim), 0.4, device=DEV), torch.zeros(B, cfg.num_state_dim, device=DEV)
+    train_iteration(cfg, agent, value, eng, loss_fn, im, z, st, _labels(B, 0), 0.1, opts)      # Adam's state exists
+    torch.cuda.synchronize()
+    tr = types.SimpleNamespace(cfg=cfg, agent=agent, value=value, detector=eng, loss_fn=loss_fn, batch_size=B, max_bri=-1.0,
+                               use_truncated=True, agent_optimizer=opts[0], value_optimizer=opts[1], buckets=None)
+    pool = torch.cat([im, im * 0.5], 0)
+    pool0 = pool.clone()
+    G = _GraphIteration(tr, pool, cap=256)
+    assert G.stage(_labels(B, 1), [4, 5, 6, 7], st.cpu().numpy(), z.cpu().numpy(), 0.01, 3e-5, 3e-5)
+    G.capture()
+    G.replay()
+    bad, _ = G.wait_guard(timeout=30.0)
+    torch.cuda.synchronize()
+    assert bad and torch.equal(pool, pool0)
+    assert torch.equal(G.im, pool0[4:]) and not torch.equal(G.out["retouch"], pool0[4:])
 
 
 def test_graph_trainer_runs_the_schedule_and_keeps_the_pool():

@@ -40,6 +40,12 @@ print(f"one iteration (k_td_fwd to k_td_fwd): span {span/1e6:.3f} ms, some kerne
 print("largest gaps with nothing running:")
 for g, at, p, n in sorted(gaps, reverse=True)[:12]:
     print(f"   {g/1e3:7.1f} us at +{at/1e6:.3f} ms   after {p}   before {n}")
+g, at, _, _ = max(gaps)
+print(f"around the largest gap (+{at/1e6:.3f} ms): start offset us, duration us, queue, kernel")
+for r in seg:
+    s0, e0 = int(r["Start_Timestamp"]) - t0, int(r["End_Timestamp"]) - t0
+    if at - 60000 <= s0 <= at + g + 120000:
+        print(f"   {s0/1e3:9.1f} {(e0-s0)/1e3:7.1f}  q{r.get('Queue_Id', '?'):>3s}  {r['Kernel_Name'].split('(')[0][-70:]}")
 print("per 200 us: kernel-time by family (us; > 200 = overlap of streams)")
 nb = span // 200000 + 1
 buckets = [collections.Counter() for _ in range(nb)]
