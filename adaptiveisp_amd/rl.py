@@ -139,7 +139,7 @@ def retouch_stats(retouch):
 
 
 def train_iteration(cfg, agent, value, detector, loss_fn, imgs, z, states, labels, progress, optimizers, buckets=None,
-                    use_truncated=True, max_bri=0.9, on_retouch=None, assigned=None, lr_dev=None, step=True):
+                    use_truncated=True, max_bri=0.9, on_retouch=None, assigned=None, lr_dev=None, step=True, one_stream=False):
     """One optimisation step (train.py:255-351). `detector(x)` must return the three raw head maps with autograd
     through to x (the frozen reward model); `buckets` (adaptiveisp_amd.dist.GradBucket per model) enables the
     data-parallel gradient all-reduce before the 1e-5 clip. `on_retouch(retouch)` is called as soon as the retouched batch
@@ -148,7 +148,8 @@ def train_iteration(cfg, agent, value, detector, loss_fn, imgs, z, states, label
     `assigned` = (packed, packed_pair): the labels' target assignment already on the device (yolo.loss.StaticLabelTables — an
     iteration captured in a hipGraph reads tables of fixed address; `labels` is then unused); `lr_dev`: dist.synced_step;
     `step=False`: stop after backward() — the caller runs the collective and the optimizers (a capture split around an
-    all-reduce that stays outside it).
+    all-reduce that stays outside it). `one_stream`: nothing forks onto the second stream (a hipGraph with a fork / join inside
+    costs ~0.3 ms of idle device per replay and ten times the launch work on this runtime: tools/graph_launch_gap.py).
     Returns the scalars of td_losses plus the retouched batch."""
     from . import dist as adist
     from .yolo.loss import batched_per_sample_loss as per_sample_loss
@@ -164,7 +165,7 @@ def train_iteration(cfg, agent, value, detector, loss_fn, imgs, z, states, label
         else:
             with torch.no_grad():
                 packed, packed_pair = assign_labels_packed(loss_fn, detector.head_shapes(), labels, imgs.device, pair=True)
-        if imgs.is_cuda and getattr(detector, "begin_input_half", None) is not None:
+        if imgs.is_cuda and getattr(detector, "begin_input_half", None) is not None and not one_stream:
             # the detector's shallow layers on the INPUT batch need nothing the agent computes: beside the agent's forward
             # (yolo.YoloTrainPairEngine.begin_input_half), on the stream the critic uses later
             cur0, side0 = torch.cuda.current_stream(), _side_stream(imgs.device)
@@ -176,7 +177,7 @@ def train_iteration(cfg, agent, value, detector, loss_fn, imgs, z, states, label
         stats = retouch_stats(retouch)
         if on_retouch is not None:
             on_retouch(retouch.detach(), stats, new_states.detach())
-        if imgs.is_cuda and hasattr(value, "forward_pair") and os.environ.get("ADAISP_CRITIC_STREAM", "1") == "1":
+        if imgs.is_cuda and hasattr(value, "forward_pair") and os.environ.get("ADAISP_CRITIC_STREAM", "1") == "1" and not one_stream:
             # the critic needs the retouched batch, not the detector: its two calls run on a second stream beside the detector's
             # forward — and, autograd replaying every node on its forward's stream, its backward beside the detector's: chains of
             # 5-15 us launches next to launches that fill the chip (7.0 -> 6.7 ms per iteration, four interleaved pairs; the same

@@ -243,6 +243,12 @@ class _GraphIteration:
 
         from .yolo.loss import StaticLabelTables
         self.tr, self.split, self.pool = tr, bool(split), pool
+        # ADAISP_TRAIN_GRAPH_STREAMS=2 (default): the critic, the guard and the input half's shallow detector layers fork onto a
+        # second stream inside the capture, as in the ordinary loop. 1: one chain of launches — on this runtime a fork / join
+        # inside a graph costs ~0.3 ms of idle device per replay and ten times the launch work (tools/graph_launch_gap.py), but
+        # the small launches of critic and guard then no longer run beside the detector's: 6.7-6.9 ms per iteration against
+        # 6.5-6.7, host work 0.7 ms against 1.4
+        self.one_stream = os.environ.get("ADAISP_TRAIN_GRAPH_STREAMS", "2") == "1"
         dev = pool.device
         self.dev = dev
         B, S, Z = tr.batch_size, int(tr.cfg.num_state_dim), int(tr.cfg.z_dim)
@@ -284,7 +290,8 @@ class _GraphIteration:
     def _guard(self, retouch, stats, new_states):
         from .rl import _side_stream
         tr = self.tr
-        cur, side = torch.cuda.current_stream(), _side_stream(self.dev)
+        cur = torch.cuda.current_stream()
+        side = cur if self.one_stream else _side_stream(self.dev)
         side.wait_stream(cur)
         with torch.cuda.stream(side):
             mean = stats[:, 0].mean()
@@ -322,10 +329,11 @@ class _GraphIteration:
                 out = train_iteration(tr.cfg, tr.agent, tr.value, tr.detector, tr.loss_fn, self.im, self.z, self.state, None, 0.0,
                                       opts, buckets=tr.buckets, use_truncated=tr.use_truncated, max_bri=tr.max_bri,
                                       on_retouch=self._guard, assigned=(self.tables.packed, self.tables.packed_pair),
-                                      lr_dev=self.lr, step=not self.split)
+                                      lr_dev=self.lr, step=not self.split, one_stream=self.one_stream)
                 vec3 = torch.stack([out["agent_loss"].detach().reshape(()), out["value_loss"].detach().reshape(()),
                                     out["reward"].detach().mean()])
-                torch.cuda.current_stream().wait_stream(_side_stream(self.dev))      # (joined whatever the stream switches say)
+                if not self.one_stream:
+                    torch.cuda.current_stream().wait_stream(_side_stream(self.dev))  # (joined whatever the stream switches say)
                 self.scalars.index_copy_(0, ((self.seq_dev - 1) % 256).to(torch.int64), vec3.view(1, 3))
             if self.split:
                 # the gradients now sit at fixed addresses (every replay of the first graph writes them there); the collective

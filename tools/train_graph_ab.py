@@ -20,6 +20,7 @@ ap.add_argument("--rounds", type=int, default=3)
 ap.add_argument("--batch", type=int, default=8)
 ap.add_argument("--size", type=int, default=512)
 ap.add_argument("--early", default="", help="comma list of ADAYOLO_TRAIN_EARLY values: graph-mode trainers only, one per value")
+ap.add_argument("--streams", default="", help="comma list of ADAISP_TRAIN_GRAPH_STREAMS values (1, 2): graph-mode trainers, one per value")
 ap.add_argument("--ordinary", action="store_true", help="with --early: the ordinary loop instead of graph mode")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
@@ -40,8 +41,12 @@ torch.cuda.Event.synchronize = timed(torch.cuda.Event.synchronize)
 atrain._GraphIteration.wait_guard = timed(atrain._GraphIteration.wait_guard)
 trainers = {}
 modes = [("early=" + v) for v in a.early.split(",")] if a.early else [False, True]
+if a.streams:
+    modes = [("streams=" + v) for v in a.streams.split(",")]
 for mode in modes:
-    if isinstance(mode, str):
+    if isinstance(mode, str) and mode.startswith("streams="):
+        os.environ["ADAISP_TRAIN_GRAPH"], os.environ["ADAISP_TRAIN_GRAPH_STREAMS"] = "1", mode.split("=")[1]
+    elif isinstance(mode, str):
         os.environ["ADAISP_TRAIN_GRAPH"], os.environ["ADAYOLO_TRAIN_EARLY"] = "0" if a.ordinary else "1", mode.split("=")[1]
     else:
         os.environ["ADAISP_TRAIN_GRAPH"] = "1" if mode else "0"
@@ -61,6 +66,10 @@ for rnd in range(a.rounds):
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         res[mode].append((dt / a.iters * 1e3, (t_host - waited[0]) / a.iters * 1e3, waited[0] / a.iters * 1e3))
+        tr.materialize()
+        nonfinite = [r["iter"] for r in tr.history if not all(x == x and abs(x) != float("inf") for x in (r["agent_loss"], r["value_loss"], r["reward"]))]
+        if nonfinite:
+            print(f"   !! {mode}: non-finite losses from iteration {nonfinite[0]} on ({len(nonfinite)} so far; dropped batches {sum(r['dropped'] for r in tr.history)})", flush=True)
         print(f"round {rnd} {mode if isinstance(mode, str) else ('graph   ' if mode else 'ordinary')}: {res[mode][-1][0]:.3f} ms / iteration, host busy {res[mode][-1][1]:.3f} ms, "
               f"host waiting {res[mode][-1][2]:.3f} ms", flush=True)
 for mode, v in res.items():

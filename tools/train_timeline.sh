@@ -8,7 +8,7 @@ OUT=$R/gpurun_out
 mkdir -p "$OUT"
 for kv in "$@"; do export "$kv"; done
 cd /tmp && export TMPDIR=/tmp PYTHONPATH=$R${PYTHONPATH:+:$PYTHONPATH}
-rocprofv3 --kernel-trace --output-format csv -d "$OUT/train_timeline" -o tl -- python3 -m adaptiveisp_amd.train --iters 40 --warmup 10 > "$OUT/train_timeline.log" 2>&1
+rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d "$OUT/train_timeline" -o tl -- python3 -m adaptiveisp_amd.train --iters 40 --warmup 10 > "$OUT/train_timeline.log" 2>&1
 tail -1 "$OUT/train_timeline.log" | cut -c1-200
 python3 - "$(find $OUT/train_timeline -name '*kernel_trace.csv' | head -1)" <<'PY'
 import csv, sys, collections, re
@@ -46,6 +46,15 @@ for r in seg:
     s0, e0 = int(r["Start_Timestamp"]) - t0, int(r["End_Timestamp"]) - t0
     if at - 60000 <= s0 <= at + g + 120000:
         print(f"   {s0/1e3:9.1f} {(e0-s0)/1e3:7.1f}  q{r.get('Queue_Id', '?'):>3s}  {r['Kernel_Name'].split('(')[0][-70:]}")
+import glob, os
+mc = glob.glob(os.path.join(os.path.dirname(sys.argv[1]), "*memory_copy_trace.csv"))
+if mc:
+    cp = list(csv.DictReader(open(mc[0])))
+    print("memory copies of the iteration (start offset us, duration us, direction, bytes):")
+    for r in cp:
+        s0, e0 = int(r["Start_Timestamp"]) - t0, int(r["End_Timestamp"]) - t0
+        if 0 <= s0 <= span:
+            print(f"   {s0/1e3:9.1f} {(e0-s0)/1e3:7.1f}  {r.get('Direction', r.get('Kind', '?'))}  {r.get('Size', r.get('Bytes', '?'))}")
 print("per 200 us: kernel-time by family (us; > 200 = overlap of streams)")
 nb = span // 200000 + 1
 buckets = [collections.Counter() for _ in range(nb)]
