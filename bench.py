@@ -162,7 +162,7 @@ def build_workload(a, dev):
     return step, engine, agent, x0, sched
 
 
-def build_pipeline(step, engine, x0, cut=None, gate=None, detector_eager=False):
+def build_pipeline(step, engine, x0, cut=None, gate=None, detector_eager=False, two_graphs=None):
     """Two-stage software pipeline over consecutive batches, captured as two hipGraphs (even / odd): one replay runs
     one ISP episode's worth of work (latency-bound: pooling, policy heads, one filter kernel per RL step) on one stream
     and the detector forward of batch i (MFMA-bound) on another. Every replay still does one whole ISP pass and one
@@ -181,7 +181,16 @@ def build_pipeline(step, engine, x0, cut=None, gate=None, detector_eager=False):
 
     detector_eager: the measuring form of the SAME arrangement — the graphs hold only the ISP stream's part and `run()`
     launches the detector eagerly on the second stream beside the graph replay, so that its launches can be bracketed by
-    HIP events (event-record nodes inside a captured graph are not available on this ROCm: round 3)."""
+    HIP events (event-record nodes inside a captured graph are not available on this ROCm: round 3).
+
+    two_graphs (BENCH_PIPELINE_GRAPHS=2; not the default): the two stages as TWO one-stream hipGraphs per step, each launched on its
+    own stream and held in lockstep by events recorded and waited for BETWEEN the launches, instead of one graph with the detector
+    forked onto the second stream inside it. A fork / join inside a hipGraph costs ~0.3 ms of idle device per replay in isolation
+    (tools/graph_launch_gap.py) — measured here it costs this step nothing: 4.394 (one graph) against 4.405 ms, five
+    interleaved rounds, host work per step 0.23 against 0.08 ms (tools/pipeline_graphs_ab.py, profiles/round6_pipeline_graphs_ab.txt).
+    Same launches, same buffers, same dependencies (every part of step i after every part of step i - 1). Needs gate = 0."""
+    if two_graphs is None:
+        two_graphs = os.environ.get("BENCH_PIPELINE_GRAPHS", "1") == "2"
     sched = step.sched
     nh = 2 * len(sched)
     if cut is None:
@@ -216,8 +225,19 @@ def build_pipeline(step, engine, x0, cut=None, gate=None, detector_eager=False):
     if cut:                                               # slots exist before capture (their addresses are baked in)
         head(0); head(1)
         torch.cuda.synchronize()
+    two_graphs = bool(two_graphs) and not gate and not detector_eager
     graphs = []
     for p in range(2):
+        if two_graphs:
+            gi, gd = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gi, stream=hp):
+                step.isp_chain(out=xbuf[p], start=cut, carry=carry(1 - p) if cut else None)   # rest of batch i+1 -> hand-over buffer
+                if cut:
+                    head(p)                              # first half-steps of batch i+2 -> mid-episode slot
+            with torch.cuda.graph(gd, stream=side), torch.no_grad():
+                engine(xbuf[1 - p])                      # detector of the batch the previous replay retouched
+            graphs.append((gi, gd))
+            continue
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g, stream=hp):
             cur = torch.cuda.current_stream()
@@ -237,6 +257,7 @@ def build_pipeline(step, engine, x0, cut=None, gate=None, detector_eager=False):
                 cur.wait_stream(side)
         graphs.append(g)
     state = {"i": 0}
+    done = [torch.cuda.Event(), torch.cuda.Event()] if two_graphs else None     # (ISP stream, detector stream) of the last step
 
     def prime():
         step.isp_chain(out=xbuf[1])
@@ -246,6 +267,23 @@ def build_pipeline(step, engine, x0, cut=None, gate=None, detector_eager=False):
 
     def run():
         p = state["i"] & 1
+        if two_graphs:
+            cur = torch.cuda.current_stream()
+            for st in (hp, side):                        # what the caller enqueued (prime(), the previous step's consumers) first;
+                st.wait_stream(cur)                      # both parts of step i after both parts of step i - 1
+                if state["i"]:
+                    st.wait_event(done[0])
+                    st.wait_event(done[1])
+            with torch.cuda.stream(hp):
+                graphs[p][0].replay()
+                done[0].record(hp)
+            with torch.cuda.stream(side):
+                graphs[p][1].replay()
+                done[1].record(side)
+            cur.wait_event(done[0])                      # the caller's stream sees the step as one unit, as with the one-graph form
+            cur.wait_event(done[1])
+            state["i"] += 1
+            return
         if detector_eager:
             cur = torch.cuda.current_stream()
             side.wait_stream(cur)
