@@ -115,11 +115,18 @@ def test_headline_pipeline_with_the_persistent_chain_is_bit_reproducible():
     ref = step().clone()
     xref = step.isp_chain().clone()
     torch.cuda.synchronize()
-    prime, run = bench.build_pipeline(step, engine, x0)
-    prime()
-    for i in range(24):
-        run()
+    for two in (False, True):                                # one graph with the detector forked inside / two one-stream graphs + events
+        prime, run = bench.build_pipeline(step, engine, x0, two_graphs=two)
+        prime()
+        for i in range(24):
+            run()
+            torch.cuda.synchronize()
+            assert torch.equal(run.xbuf[i & 1], xref), (two, i)
+            assert torch.equal(engine.pred, ref), (two, i)
+        # ... and without a host synchronisation between the steps (what the timed loop does)
+        prime()
+        for i in range(12):
+            run()
         torch.cuda.synchronize()
-        assert torch.equal(run.xbuf[i & 1], xref), i
-        assert torch.equal(engine.pred, ref), i
+        assert torch.equal(run.xbuf[11 & 1], xref) and torch.equal(engine.pred, ref), two
     assert engine.chain_status() == 0
