@@ -316,6 +316,7 @@ class _GraphIteration:
             if not m.training:
                 m.train()
         tr.agent.entropy_coef_dev = self.coef
+        getattr(tr.detector, "prepare_capture", lambda: None)()                      # (launch plans: building them probes kernels)
         torch.cuda.synchronize(self.dev)
         from . import optim as aoptim
         g, g2 = torch.cuda.CUDAGraph(), None

@@ -615,6 +615,9 @@ class YoloTrainPairEngine:
         # input batch; `half` (images [B, 2B)) runs the retouched batch's. ADAYOLO_TRAIN_EARLY = the number of stride-2 convs
         # inside the shallow part (default 2: everything in front of 128 -> 256 s2 — measured best of 0..4, tools/train_graph_ab.py --early), 0 = one 2B-image forward as before.
         self.early_cut = int(os.environ.get("ADAYOLO_TRAIN_EARLY", "2"))
+        # (the ordinary loop walks the same three pieces launch by launch — ~75 launches where the one-piece forward is one replay
+        # of the engine's own graph, 0.3 ms more host work per iteration: both loops make the same launches, so a replayed
+        # iteration stays the ordinary iteration bit for bit)
         self.first = None
         if self.early_cut > 0:
             self.first = YoloTrainEngine(model, self.B, height, width, device, share_with=self.full, first_image=0, capture=())
@@ -657,10 +660,18 @@ class YoloTrainPairEngine:
                            self.full._forward_plan()[cut[id(self.full)]:])
         return self._split[1:]
 
+    def _early_now(self):
+        return self.first is not None
+
+    def prepare_capture(self):
+        """Build every launch plan a captured iteration will walk (building probes kernels: not inside the capture)."""
+        if self.first is not None:
+            self._plans_split()
+
     def begin_input_half(self, imgs):
         """Enqueue the shallow layers of the INPUT batch on the current stream (the caller's side stream) and record the event
         the deep layers wait for. Optional: per_sample_loss_pair runs them itself when this was not called for `imgs`."""
-        if self.first is None:
+        if not self._early_now():
             return
         if imgs.shape != (self.B, 3, self.H, self.W) or imgs.dtype != torch.float32 or imgs.device != self.dev:
             raise ValueError(f"expected fp32 {(self.B, 3, self.H, self.W)} on {self.dev}")
@@ -691,7 +702,7 @@ class YoloTrainPairEngine:
         if loss_fn.nc + 5 != full.no or len(packed_pair) != len(full.raw) or loss_fn.hyp.get("fl_gamma", 0.0) != 0.0:
             raise ValueError("loss / detector mismatch (classes, layers) or focal loss requested: use the PyTorch loss")
         loss = torch.empty((2 * self.B,), dtype=torch.float32, device=self.dev)
-        if self.first is None:
+        if not self._early_now():
             full._forward_raw_halves(imgs.detach().contiguous(), retouch.detach().contiguous())
         else:
             imgs_c, ret_c = imgs.detach().contiguous(), retouch.detach().contiguous()
