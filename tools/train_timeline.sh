@@ -66,6 +66,11 @@ for s, e, n, f in ivs:
         s, b = hi, b + 1
 for b, c in enumerate(buckets):
     print(f"   +{b*0.2:4.1f} ms  " + "  ".join(f"{k} {v/1e3:.0f}" for k, v in c.most_common()))
+if os.environ.get("TIMELINE_ALL"):
+    with open(os.environ["TIMELINE_ALL"], "w") as f:
+        for r in seg:
+            s0, e0 = int(r["Start_Timestamp"]) - t0, int(r["End_Timestamp"]) - t0
+            f.write(f"{s0/1e3:9.1f} {(e0-s0)/1e3:7.1f} q{r.get('Queue_Id', '?')} {fam(r['Kernel_Name']):9s} {r['Kernel_Name'][:150]}\n")
 fams = collections.Counter()
 for s, e, n, f in ivs:
     fams[f] += e - s
