@@ -20,13 +20,13 @@ NLM_EXACT = 2      # NLM patch sums in the reference's running-sum order (slower
 NLM_SEP_V1 = 4     # the compiler-scheduled form of the separable kernel (cross-check / measurement)
 NO_USM = 8         # adaisp_forward: no image selects the unsharp mask (its empty launch is skipped)
 NLM_TILE32 = 16    # the 32-row tile of the default NLM kernel (cross-check / measurement)
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 EXPORTS = ("adaisp_forward", "adaisp_forward_uniform", "adaisp_process", "adaisp_backward_params", "adaisp_pool64", "adaisp_pool64_backward", "adaisp_demosaic", "adaisp_nlm_general", "adaisp_nlm_general_workspace_bytes", "adaisp_num_params",
            "adaisp_policy_conv", "adaisp_policy_fc1", "adaisp_policy_finish",
            "adaisp_trunk_train_fwd", "adaisp_trunk_train_bwd", "adaisp_trunk_train_workspace_bytes", "adaisp_trunk_train_scratch_bytes",
            "adaisp_critic_planes_fwd", "adaisp_critic_planes_bwd", "adaisp_td_fwd", "adaisp_td_bwd",
-           "adaisp_policy_tail_fwd", "adaisp_policy_tail_bwd", "adaisp_image_stats", "adaisp_clip_adam_step", "adaisp_clip_adam_step_dev",
+           "adaisp_policy_tail_fwd", "adaisp_policy_tail_bwd", "adaisp_image_stats", "adaisp_clip_adam_step", "adaisp_clip_adam_step_dev", "adaisp_heads_fwd", "adaisp_heads_bwd",
            "adaisp_strerror", "adaisp_abi_version")
 
 _lib = None
@@ -61,7 +61,7 @@ def load():
     L.adaisp_nlm_general_workspace_bytes.argtypes = [ci, ci, ci]
     L.adaisp_nlm_general_workspace_bytes.restype = ctypes.c_size_t
     for name in ("adaisp_trunk_train_fwd", "adaisp_trunk_train_bwd", "adaisp_critic_planes_fwd", "adaisp_critic_planes_bwd",
-                 "adaisp_td_fwd", "adaisp_td_bwd", "adaisp_policy_tail_fwd", "adaisp_policy_tail_bwd"):
+                 "adaisp_td_fwd", "adaisp_td_bwd", "adaisp_policy_tail_fwd", "adaisp_policy_tail_bwd", "adaisp_heads_fwd", "adaisp_heads_bwd"):
         getattr(L, name).argtypes = [vp, vp]
         getattr(L, name).restype = ci
     for name in ("adaisp_trunk_train_workspace_bytes", "adaisp_trunk_train_scratch_bytes"):

@@ -361,11 +361,15 @@ class Agent(nn.Module):
         if batched and x_down.is_cuda and (isinstance(entropy_coef, (int, float)) or
                                            (isinstance(entropy_coef, torch.Tensor) and entropy_coef.numel() == 1)):
             # regressors, pdf, sampling, surrogate, gather, state update, penalties: one launch each way (policy_train.py)
-            from . import policy_train
-            x = self._heads_pre(filter_features)
+            from . import heads_train, policy_train
             if selector_features is None:
                 selector_features = sel_trunk(net_in)
-            logits = self.fc2(self.lrelu(self.fc1(selector_features)))
+            if heads_train.serves(self, filter_features, selector_features):
+                # every filter's fc1 / fc_filter and the selector's fc1 / fc2 on the parameters themselves: 2 launches, 4 backward
+                x, logits = heads_train.heads(self, filter_features, selector_features)
+            else:
+                x = self._heads_pre(filter_features)
+                logits = self.fc2(self.lrelu(self.fc1(selector_features)))
             if policy_train.serves(self, x, logits, entropy_coef):
                 return policy_train.policy_tail(self, x, logits, noise, states, entropy_coef, sample=True, forced_id=forced_id)
         if batched:

@@ -16,7 +16,7 @@ ISP_FLAGS = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math"
 LIBS = {
     "libadaisp.so": dict(
         sources=["isp_pointwise.hip", "isp_conv.hip", "isp_nlm.hip", "isp_pool.hip", "isp_demosaic.hip", "isp_backward.hip",
-                 "isp_policy.hip", "isp_trunk_train.hip", "isp_rl_train.hip", "isp_api.hip"],
+                 "isp_policy.hip", "isp_trunk_train.hip", "isp_rl_train.hip", "isp_heads_train.hip", "isp_api.hip"],
         headers=["isp_internal.h", "../../include/adaisp.h"],
         flags=ISP_FLAGS),
     "libadayolo.so": dict(

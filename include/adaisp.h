@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define ADAISP_ABI_VERSION 7
+#define ADAISP_ABI_VERSION 8
 
 /* Kernel op codes. 0..9 follow the reference's default filter order (config.py:19-22). */
 enum adaisp_op {
@@ -380,6 +380,33 @@ int adaisp_clip_adam_step(const adaisp_adam_tensor* table, int ntensors, long nc
  * the LambdaLR schedule (train.py:206-218, 350-351) without a new kernel argument. Same arithmetic, same three launches. */
 int adaisp_clip_adam_step_dev(const adaisp_adam_tensor* table, int ntensors, long nchunks, float* workspace, float max_norm,
                               const double* lr_dev, double beta1, double beta2, double eps, void* stream);
+
+/*
+ * The policy's parameter heads in TRAINING mode, forward and backward on the filters' own parameter tensors (agent.py:103-116: per
+ * filter `fc1` D -> hid, LeakyReLU 0.2, `fc_filter` hid -> n_f; agent.py:117-121: the selector's `fc1` D -> hid on ITS trunk's features,
+ * LeakyReLU, `fc2` hid -> F). Forward (2 launches): hidden [B][F+1][hid] = the pre-activations of every fc1 (group F = the selector),
+ * x [B][F][pw] = every fc_filter's output, zero in the slots >= n_f (what adaisp_policy_tail_fwd reads), logits [B][F]. Backward
+ * (4 launches) from dx / dlogits: the gradient of every weight and bias into the caller's tensors (written, not accumulated) and of
+ * both feature rows; `dhid` [B][F+1][hid] and `part` [(F+1)][B][D] are scratch. Every sum in a fixed order. B <= 8, hid a multiple of
+ * 8, D a multiple of 1024.
+ */
+#define ADAISP_HEADS_MAX_B 8
+typedef struct adaisp_heads_args {
+    int32_t B, F, D, hid, pw;
+    int32_t n[ADAISP_POLICY_MAX_FILTERS];
+    const float *feat_f, *feat_s;                              /* [B][D] each                                     */
+    const float *w1[ADAISP_POLICY_MAX_FILTERS], *b1[ADAISP_POLICY_MAX_FILTERS];   /* [hid][D], [hid]            */
+    const float *wf[ADAISP_POLICY_MAX_FILTERS], *bf[ADAISP_POLICY_MAX_FILTERS];   /* [n_f][hid], [n_f]          */
+    const float *ws1, *bs1, *ws2, *bs2;                        /* selector: [hid][D], [hid], [F][hid], [F]       */
+    float *hidden, *x, *logits;
+    /* backward only */
+    const float *dx, *dlogits;
+    float *dhid, *part;
+    float *dw1[ADAISP_POLICY_MAX_FILTERS], *db1[ADAISP_POLICY_MAX_FILTERS], *dwf[ADAISP_POLICY_MAX_FILTERS], *dbf[ADAISP_POLICY_MAX_FILTERS];
+    float *dws1, *dbs1, *dws2, *dbs2, *dfeat_f, *dfeat_s;
+} adaisp_heads_args;
+int adaisp_heads_fwd(const adaisp_heads_args* args, void* stream);
+int adaisp_heads_bwd(const adaisp_heads_args* args, void* stream);
 
 /* Number of regressed parameters an op reads per image (0 for ADAISP_OP_ZERO, -1 if unknown). */
 int adaisp_num_params(int op);

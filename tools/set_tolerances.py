@@ -36,7 +36,7 @@ WINDOW = 4                                  # runs per label that decide "varies
 # the critic and every torch-autograd comparison. Their error is a draw from the libraries' reduction order: four samples that
 # happen to coincide do not make them deterministic, so they ALWAYS get the 16x-the-worst rule, whatever the window
 # shows. Everything else (a HIP kernel against a golden vector / the C oracle) is classed by its measured runs.
-LIBRARY_PATH = re.compile(r"^(critic_to_actor_|fused_eval_path_matches_torch_path|policy_selection|value#|teacher_forced_step:param:|"
+LIBRARY_PATH = re.compile(r"^(heads_train\.|critic_to_actor_|fused_eval_path_matches_torch_path|policy_selection|value#|teacher_forced_step:param:|"
                           r"trunk_train\.(agent|b24|critic|value|agent_step)\.|yolo\.pair_engine\.)")
 
 

@@ -21,6 +21,8 @@ ap.add_argument("--batch", type=int, default=8)
 ap.add_argument("--size", type=int, default=512)
 ap.add_argument("--early", default="", help="comma list of ADAYOLO_TRAIN_EARLY values: graph-mode trainers only, one per value")
 ap.add_argument("--streams", default="", help="comma list of ADAISP_TRAIN_GRAPH_STREAMS values (1, 2): graph-mode trainers, one per value")
+ap.add_argument("--headsk", default="", help="comma list of ADAISP_HEADS_KERNEL values (1, 0): graph-mode trainers, one per value (the "
+                "switch is read while the iteration is captured)")
 ap.add_argument("--ordinary", action="store_true", help="with --early: the ordinary loop instead of graph mode")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
@@ -43,8 +45,12 @@ trainers = {}
 modes = [("early=" + v) for v in a.early.split(",")] if a.early else [False, True]
 if a.streams:
     modes = [("streams=" + v) for v in a.streams.split(",")]
+if a.headsk:
+    modes = [("headsk=" + v) for v in a.headsk.split(",")]
 for mode in modes:
-    if isinstance(mode, str) and mode.startswith("streams="):
+    if isinstance(mode, str) and mode.startswith("headsk="):
+        os.environ["ADAISP_TRAIN_GRAPH"], os.environ["ADAISP_HEADS_KERNEL"] = "1", mode.split("=")[1]
+    elif isinstance(mode, str) and mode.startswith("streams="):
         os.environ["ADAISP_TRAIN_GRAPH"], os.environ["ADAISP_TRAIN_GRAPH_STREAMS"] = "1", mode.split("=")[1]
     elif isinstance(mode, str):
         os.environ["ADAISP_TRAIN_GRAPH"], os.environ["ADAYOLO_TRAIN_EARLY"] = "0" if a.ordinary else "1", mode.split("=")[1]
