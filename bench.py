@@ -187,7 +187,8 @@ def build_pipeline(step, engine, x0, cut=None, gate=None, detector_eager=False, 
     own stream and held in lockstep by events recorded and waited for BETWEEN the launches, instead of one graph with the detector
     forked onto the second stream inside it. A fork / join inside a hipGraph costs ~0.3 ms of idle device per replay in isolation
     (tools/graph_launch_gap.py) — measured here it costs this step nothing: 4.394 (one graph) against 4.405 ms, five
-    interleaved rounds, host work per step 0.23 against 0.08 ms (tools/pipeline_graphs_ab.py, profiles/round6_pipeline_graphs_ab.txt).
+    interleaved rounds, host work per step 0.23 against 0.08 ms (tools/pipeline_graphs_ab.py, profiles/round6_pipeline_graphs_ab.txt);
+    in this file's own timed loop, fresh processes interleaved, the two-graph form is the SLOWER one (4.79 against 4.37 ms).
     Same launches, same buffers, same dependencies (every part of step i after every part of step i - 1). Needs gate = 0."""
     if two_graphs is None:
         two_graphs = os.environ.get("BENCH_PIPELINE_GRAPHS", "1") == "2"
